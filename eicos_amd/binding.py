@@ -1,0 +1,239 @@
+"""ctypes mirror of include/eicos_amd.h (the C ABI of libeicos_amd.so).
+
+No torch types cross the boundary: host numpy arrays or raw device pointers (ints) only.
+If the HIP library is missing or no GPU is visible every compute call raises -- there is no
+CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXIT_NAMES = {0: "optimal", 1: "primal_infeasible", 2: "dual_infeasible", -1: "maxit", -2: "numerics",
+              -3: "outcone", -7: "fatal", 10: "close_to_optimal", 11: "close_to_primal_infeasible",
+              12: "close_to_dual_infeasible", -87: "not_converged_yet"}
+
+
+class Info(C.Structure):
+    """struct eicos_info (mirror of EiCOS::Information, reference include/eicos.hpp:49-73)."""
+    _fields_ = [(k, C.c_double) for k in (
+        "pcost", "dcost", "pres", "dres", "gap", "relgap", "sigma", "mu", "step", "step_aff",
+        "kapovert", "pinfres", "dinfres", "tau", "kap")] + [(k, C.c_int) for k in (
+        "has_relgap", "has_pinfres", "has_dinfres", "pinf", "dinf", "iter", "nitref1", "nitref2",
+        "nitref3", "exitcode", "n_factor", "n_ldlsolve")]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Dims(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n", "m", "p", "l", "ncones", "dim_K", "nnzA", "nnzG", "nnzK", "nnzL",
+                                       "nlevels", "order_mode", "batch", "device")] + \
+               [("factor_pairs", C.c_longlong), ("inst_bytes", C.c_size_t), ("work_bytes", C.c_size_t),
+                ("pattern_bytes", C.c_size_t), ("threads_per_block", C.c_int), ("resident_blocks", C.c_int)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libeicos_amd.so")
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(path)
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.eicos_last_error.restype = C.c_char_p
+        L.eicos_batch_create.argtypes = [C.c_int] * 5 + [ip] * 5 + [C.c_int, C.c_int, C.POINTER(vp)]
+        L.eicos_batch_update.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+        L.eicos_batch_update_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.eicos_batch_solve.argtypes = [vp, ip]
+        L.eicos_batch_solve_async.argtypes = [vp]
+        L.eicos_batch_sync.argtypes = [vp]
+        L.eicos_batch_solution.argtypes = [vp, dp]
+        L.eicos_batch_duals.argtypes = [vp, dp, dp, dp]
+        L.eicos_batch_info.argtypes = [vp, C.POINTER(Info)]
+        L.eicos_batch_solution_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.eicos_batch_dims.argtypes = [vp, C.POINTER(Dims)]
+        L.eicos_batch_set_stream.argtypes = [vp, vp]
+        L.eicos_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.eicos_batch_last_update_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.eicos_batch_destroy.argtypes = [vp]
+        L.eicos_debug_factor.argtypes = [vp, C.c_int, dp, dp]
+        L.eicos_debug_pattern.argtypes = [vp, ip, ip, ip]
+        L.eicos_debug_host_check.restype = C.c_double
+        L.eicos_debug_host_check.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
+        for f in ("create", "update", "update_device", "solve", "solve_async", "sync", "solution", "duals", "info",
+                  "solution_device", "dims", "set_stream", "last_solve_ms", "last_update_ms", "destroy"):
+            getattr(L, "eicos_batch_" + f).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def device_count() -> int:
+    return int(_lib().eicos_device_count())
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError(f"eicos_amd error {rc}: {_lib().eicos_last_error().decode()}")
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class BatchSolver:
+    """One sparsity pattern, `batch` numeric instances on one GPU.
+
+    Mirrors the reference's Solver surface (ctor / updateData / solve / solution / getInfo,
+    reference include/eicos.hpp:137-163) with a leading batch dimension on every array.
+    """
+
+    def __init__(self, pat, batch: int, device: int = -1):
+        L = _lib()
+        self.pat, self.batch = pat, int(batch)
+        self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (pat.q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)]
+        q, Gjc, Gir, Ajc, Air = self._keep
+        h = C.c_void_p()
+        _chk(L.eicos_batch_create(pat.n, pat.m, pat.p, pat.l, pat.ncones, _ip(q) if pat.ncones else None,
+                                  _ip(Gjc) if pat.m > 0 else None, _ip(Gir) if pat.m > 0 else None,
+                                  _ip(Ajc) if pat.p > 0 else None, _ip(Air) if pat.p > 0 else None,
+                                  self.batch, device, C.byref(h)))
+        self._h = h
+
+    # ---- updateData ----
+    def update(self, Gpr=None, Apr=None, c=None, h=None, b=None, first: int = 0, count: int | None = None):
+        """Host arrays shaped [count, ...]; None keeps the group (reference semantics)."""
+        arrs = []
+        for a in (Gpr, Apr, c, h, b):
+            arrs.append(None if a is None else np.ascontiguousarray(a, dtype=np.float64))
+        if count is None:
+            count = next((a.shape[0] for a in arrs if a is not None and a.ndim == 2), self.batch)
+        pat = self.pat
+        for a, w in zip(arrs, (pat.nnzG, pat.nnzA, pat.n, pat.m, pat.p)):
+            if a is not None and a.size != count * w:
+                raise ValueError(f"array has {a.size} elements, expected {count}x{w}")
+        # zero-width groups are passed as NULL-safe dummies
+        ptr = [(_dp(a) if (a is not None and a.size) else (_dp(np.zeros(1)) if a is not None else None)) for a in arrs]
+        _chk(_lib().eicos_batch_update(self._h, first, count, *ptr))
+
+    def update_device(self, dG=0, dA=0, dc=0, dh=0, db=0, first: int = 0, count: int | None = None):
+        """Raw device pointers (ints, e.g. torch.Tensor.data_ptr()); 0 keeps the group."""
+        count = self.batch if count is None else count
+        _chk(_lib().eicos_batch_update_device(self._h, first, count, *[C.c_void_p(int(p) or None) for p in (dG, dA, dc, dh, db)]))
+
+    # ---- solve ----
+    def solve(self):
+        codes = np.zeros(self.batch, np.int32)
+        _chk(_lib().eicos_batch_solve(self._h, _ip(codes)))
+        return codes
+
+    def solve_async(self):
+        _chk(_lib().eicos_batch_solve_async(self._h))
+
+    def sync(self):
+        _chk(_lib().eicos_batch_sync(self._h))
+
+    def set_stream(self, stream_ptr: int):
+        _chk(_lib().eicos_batch_set_stream(self._h, C.c_void_p(int(stream_ptr) or None)))
+
+    # ---- results ----
+    def solution(self):
+        x = np.zeros((self.batch, max(self.pat.n, 1)))
+        if self.pat.n:
+            x = np.zeros((self.batch, self.pat.n))
+            _chk(_lib().eicos_batch_solution(self._h, _dp(x)))
+            return x
+        return x[:, :0]
+
+    def duals(self):
+        pat = self.pat
+        y, z, s = np.zeros((self.batch, pat.p)), np.zeros((self.batch, pat.m)), np.zeros((self.batch, pat.m))
+        _chk(_lib().eicos_batch_duals(self._h, _dp(y) if pat.p else None, _dp(z) if pat.m else None, _dp(s) if pat.m else None))
+        return y, z, s
+
+    def info(self):
+        arr = (Info * self.batch)()
+        _chk(_lib().eicos_batch_info(self._h, arr))
+        return [arr[i].asdict() for i in range(self.batch)]
+
+    def info_arrays(self):
+        arr = (Info * self.batch)()
+        _chk(_lib().eicos_batch_info(self._h, arr))
+        raw = np.frombuffer(arr, dtype=np.dtype([(k, "f8") for k, t in Info._fields_ if t is C.c_double] +
+                                                [(k, "i4") for k, t in Info._fields_ if t is C.c_int]))
+        return {k: raw[k].copy() for k in raw.dtype.names}
+
+    def dims(self) -> dict:
+        d = Dims()
+        _chk(_lib().eicos_batch_dims(self._h, C.byref(d)))
+        return d.asdict()
+
+    def last_solve_ms(self) -> float:
+        ms = C.c_float()
+        _chk(_lib().eicos_batch_last_solve_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def last_update_ms(self) -> float:
+        ms = C.c_float()
+        _chk(_lib().eicos_batch_last_update_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def debug_factor(self, inst: int = 0):
+        d = self.dims()
+        D, U = np.zeros(max(d["dim_K"], 1)), np.zeros(max(d["nnzL"], 1))
+        _chk(_lib().eicos_debug_factor(self._h, inst, _dp(D), _dp(U)))
+        return D[: d["dim_K"]], U[: d["nnzL"]]
+
+    def debug_pattern(self):
+        d = self.dims()
+        perm, Lp, Li = np.zeros(max(d["dim_K"], 1), np.int32), np.zeros(d["dim_K"] + 1, np.int32), np.zeros(max(d["nnzL"], 1), np.int32)
+        _chk(_lib().eicos_debug_pattern(self._h, _ip(perm), _ip(Lp), _ip(Li)))
+        return perm[: d["dim_K"]], Lp, Li[: d["nnzL"]]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().eicos_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_check(pat, seed: int = 1, order_mode: int = -1):
+    """Host-only check of the symbolic analysis (no GPU): returns (relative residual, stats dict)."""
+    q, Gjc, Gir, Ajc, Air = [np.ascontiguousarray(a, dtype=np.int32) for a in (pat.q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)]
+    st = np.zeros(8, np.int32)
+    r = _lib().eicos_debug_host_check(pat.n, pat.m, pat.p, pat.ncones, _ip(q) if pat.ncones else None,
+                                      _ip(Gjc) if pat.m else None, _ip(Gir) if pat.m else None,
+                                      _ip(Ajc) if pat.p else None, _ip(Air) if pat.p else None, seed, order_mode, _ip(st))
+    keys = ("dim_K", "nnzK", "nnzL", "nlevels", "factor_pairs", "order_mode", "max_row", "max_col")
+    return float(r), dict(zip(keys, (int(v) for v in st)))

@@ -1,0 +1,496 @@
+// C ABI of the batched solver (include/eicos_amd.h): host-side setup, memory, launches.
+// There is deliberately NO CPU fallback: without a HIP device every compute entry point fails
+// with EICOS_E_NOGPU.
+#include "../../include/eicos_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+#include "launch.hpp"
+#include "symbolic.hpp"
+
+using namespace eicos;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(EICOS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct eicos_batch {
+    ProblemPattern pat;
+    Symbolic sym;
+    DevPat dp{};
+    int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
+    int *d_pattern = nullptr;
+    size_t pattern_ints = 0;
+    double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
+    bool solve_timed = false, update_timed = false;
+    int64_t npairs = 0;
+};
+
+namespace {
+
+struct IntPool { // one int32 buffer for every pattern array
+    std::vector<int> data;
+    size_t add(const std::vector<int> &v) {
+        size_t off = data.size();
+        data.insert(data.end(), v.begin(), v.end());
+        while (data.size() % 4) data.push_back(0); // keep 16-byte alignment of every array
+        if (v.empty()) { data.insert(data.end(), 4, 0); }
+        return off;
+    }
+};
+
+struct SlabLayout {
+    size_t size = 0;
+    int add(size_t count) {
+        int off = (int)size;
+        size += (count + 7) & ~(size_t)7; // 64-byte granules
+        return off;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+const char *eicos_last_error(void) { return g_err.c_str(); }
+
+int eicos_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
+                       const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
+                       int batch, int device, eicos_batch **out) {
+    if (!out) return fail(EICOS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n < 0 || m < 0 || p < 0 || ncones < 0 || batch < 1) return fail(EICOS_E_INVALID, "negative dimension or batch < 1");
+    if (ncones > 0 && !q) return fail(EICOS_E_INVALID, "ncones > 0 but q is NULL");
+    const bool haveG = Gjc && Gir, haveA = Ajc && Air;
+    if (!haveG) { m = 0; ncones = 0; } // reference: groups given as NULL are empty (src/eicos.cpp:103-117)
+    if (!haveA) p = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(EICOS_E_NOGPU, "no HIP device visible: the solver has no CPU fallback");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) return fail(EICOS_E_INVALID, "device index out of range");
+
+    eicos_batch *h = new eicos_batch();
+    try {
+        ProblemPattern &P = h->pat;
+        P.n = n; P.m = m; P.p = p; P.nc = ncones;
+        P.q.assign(q, q + ncones);
+        if (haveG) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else P.Gjc.assign(n + 1, 0);
+        if (haveA) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else P.Ajc.assign(n + 1, 0);
+        for (int r : P.Gir) if (r < 0 || r >= m) throw std::invalid_argument("G row index out of range");
+        for (int r : P.Air) if (r < 0 || r >= p) throw std::invalid_argument("A row index out of range");
+        h->sym = analyze(P, -1);
+    } catch (const std::invalid_argument &e) { delete h; return fail(EICOS_E_INVALID, e.what()); }
+    catch (const std::runtime_error &e) { delete h; return fail(EICOS_E_UNSUPPORTED, e.what()); }
+    catch (const std::exception &e) { delete h; return fail(EICOS_E_INVALID, e.what()); }
+
+    const Symbolic &S = h->sym;
+    const ProblemPattern &P = h->pat;
+    h->batch = batch; h->device = device; h->npairs = S.npairs;
+    if (S.npairs >= (int64_t)1 << 31) { delete h; return fail(EICOS_E_UNSUPPORTED, "factor program exceeds 2^31 pairs"); }
+    DevPat &D = h->dp;
+    D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = S.N; D.mt = S.mt; D.nV = S.nV;
+    D.nnzA = S.nnzA; D.nnzG = S.nnzG; D.nnzL = S.nnzL; D.nlev = S.nlev;
+
+    // ---- slab layouts ----
+    SlabLayout L;
+    D.i_Av = L.add(S.nnzA); D.i_Gv = L.add(S.nnzG); D.i_Atv = L.add(S.nnzA); D.i_Gtv = L.add(S.nnzG);
+    D.i_c = L.add(S.n); D.i_h = L.add(S.m); D.i_b = L.add(S.p);
+    D.i_xe = L.add(S.n); D.i_ae = L.add(S.p); D.i_ge = L.add(S.m);
+    D.i_Vv = L.add(S.nV); D.i_cst = L.add(4);
+    D.i_x = L.add(S.n); D.i_y = L.add(S.p); D.i_z = L.add(S.m); D.i_s = L.add(S.m);
+    D.i_info = L.add(DEVINFO_DOUBLES);
+    D.inst_stride = L.size;
+    SlabLayout Wl;
+    D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m); D.w_blam = Wl.add(S.m);
+    D.w_rx = Wl.add(S.n); D.w_ry = Wl.add(S.p); D.w_rz = Wl.add(S.m); D.w_rhs1 = Wl.add(S.N); D.w_rhs2 = Wl.add(S.N);
+    D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
+    D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
+    D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
+    D.w_xk = Wl.add(S.N); D.w_ek = Wl.add(S.N); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
+    D.w_U = Wl.add(S.nnzL); D.w_Ur = Wl.add(S.nnzL); D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N);
+    D.work_stride = Wl.size;
+
+    // ---- pattern arrays ----
+    IntPool pool;
+    std::vector<int> zexp(S.m), zdsign(S.m, 1), cone_vbase(S.nc), cone_small, cone_big;
+    for (int i = 0; i < S.l; i++) zexp[i] = i;
+    {
+        int vb = S.l;
+        for (int c = 0; c < S.nc; c++) {
+            const int o = S.cone_off[c], d = S.q[c];
+            for (int k = 0; k < d; k++) zexp[o + k] = o + k + 2 * c;
+            zdsign[o + d - 1] = -1; // last cone row: -delta in the refinement operator (ref src/eicos.cpp:1552)
+            cone_vbase[c] = vb; vb += 3 * d + 1;
+            (d >= CONE_BIG ? cone_big : cone_small).push_back(c);
+        }
+    }
+    std::vector<int> Air_k(S.nnzA), Gir_k(S.nnzG);
+    for (int k = 0; k < S.nnzA; k++) Air_k[k] = S.n + P.Air[k];
+    for (int k = 0; k < S.nnzG; k++) Gir_k[k] = S.n + S.p + zexp[P.Gir[k]];
+    std::vector<int> AG_long, At_long, Gt_long;
+    for (int j = 0; j < S.n; j++)
+        if ((P.Ajc[j + 1] - P.Ajc[j]) + (P.Gjc[j + 1] - P.Gjc[j]) > LONG_SEG) AG_long.push_back(j);
+    for (int r = 0; r < S.p; r++) if (S.At_ptr[r + 1] - S.At_ptr[r] > LONG_SEG) At_long.push_back(r);
+    for (int r = 0; r < S.m; r++) if (S.Gt_ptr[r + 1] - S.Gt_ptr[r] > LONG_SEG) Gt_long.push_back(r);
+    std::vector<int> fwd_long_ptr(S.nlev + 1, 0), fwd_long, bwd_long_ptr(S.nlev + 1, 0), bwd_long, ftask_nlong(S.nlev, 0);
+    for (int v = 0; v < S.nlev; v++) {
+        for (int i = S.lev_ptr[v]; i < S.lev_ptr[v + 1]; i++) {
+            if (S.Rp[i + 1] - S.Rp[i] > LONG_SEG) fwd_long.push_back(i);
+            if (S.Lp[i + 1] - S.Lp[i] > LONG_SEG) bwd_long.push_back(i);
+        }
+        fwd_long_ptr[v + 1] = (int)fwd_long.size(); bwd_long_ptr[v + 1] = (int)bwd_long.size();
+        for (int t = S.ftask_ptr[v]; t < S.ftask_ptr[v + 1]; t++)
+            if (S.tp[S.ftask[t] + 1] - S.tp[S.ftask[t]] > LONG_SEG) ftask_nlong[v]++;
+    }
+    std::vector<int> tp32(S.tp.size());
+    for (size_t i = 0; i < S.tp.size(); i++) tp32[i] = (int)S.tp[i];
+    auto srcoff = [&](int kind, int src) {
+        switch (kind) {
+        case SRC_A: return D.i_Av + src;
+        case SRC_G: return D.i_Gv + src;
+        case SRC_V: return D.i_Vv + src;
+        case SRC_POSDELTA: return D.i_cst + 0;
+        case SRC_NEGDELTA: return D.i_cst + 1;
+        default: return D.i_cst + 2;
+        }
+    };
+    std::vector<int> Lsrc(S.nnzL), Dsrc(S.N);
+    for (int e = 0; e < S.nnzL; e++) Lsrc[e] = srcoff(S.Lkind[e], S.Lsrc[e]);
+    for (int j = 0; j < S.N; j++) Dsrc[j] = srcoff(S.Dkind[j], S.Dsrc[j]);
+
+    struct Slot { const int **dst; size_t off; };
+    std::vector<Slot> slots;
+    auto put = [&](const int *&field, const std::vector<int> &v) { slots.push_back({&field, pool.add(v)}); };
+    put(D.Ajc, P.Ajc); put(D.Air, P.Air); put(D.Air_k, Air_k); put(D.At_ptr, S.At_ptr); put(D.At_col, S.At_col); put(D.At_pos, S.At_pos);
+    put(D.Gjc, P.Gjc); put(D.Gir, P.Gir); put(D.Gir_k, Gir_k); put(D.Gt_ptr, S.Gt_ptr); put(D.Gt_col, S.Gt_col); put(D.Gt_pos, S.Gt_pos);
+    put(D.A_long, AG_long); put(D.At_long, At_long); put(D.Gt_long, Gt_long);
+    D.G_long = nullptr; D.nG_long = 0;
+    D.nA_long = (int)AG_long.size(); D.nAt_long = (int)At_long.size(); D.nGt_long = (int)Gt_long.size();
+    put(D.cq, S.q); put(D.cone_off, S.cone_off); put(D.cone_vbase, cone_vbase); put(D.cone_small, cone_small); put(D.cone_big, cone_big);
+    D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
+    put(D.zexp, zexp); put(D.zdsign, zdsign);
+    put(D.perm, S.perm); put(D.lev_ptr, S.lev_ptr); put(D.Rp, S.Rp); put(D.Rj, S.Rj); put(D.Lp, S.Lp); put(D.Li, S.Li); put(D.Cpos, S.Cpos);
+    put(D.fwd_long_ptr, fwd_long_ptr); put(D.fwd_long, fwd_long); put(D.bwd_long_ptr, bwd_long_ptr); put(D.bwd_long, bwd_long);
+    put(D.ftask_ptr, S.ftask_ptr); put(D.ftask, S.ftask); put(D.ftask_nlong, ftask_nlong); put(D.tp, tp32);
+    put(D.pa, S.pa); put(D.pb, S.pb); put(D.pk, S.pk); put(D.Lsrc, Lsrc); put(D.Dsrc, Dsrc);
+
+    // ---- device resources ----
+    auto bail = [&](int code, const std::string &msg) { eicos_batch_destroy(h); return fail(code, msg); };
+#define HIP_TRY_H(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return bail(EICOS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    HIP_TRY_H(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY_H(hipGetDeviceProperties(&prop, device));
+    h->threads = 256;
+    int bpc = 1;
+    HIP_TRY_H(solve_occupancy(h->threads, &bpc));
+    bpc = std::max(1, std::min(bpc, 8));
+    const int resident = prop.multiProcessorCount * bpc;
+    h->grid = std::min(batch, resident);
+    h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
+    h->pattern_ints = pool.data.size();
+    HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
+    HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (auto &s : slots) *s.dst = h->d_pattern + s.off;
+    HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
+    HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
+    HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
+    HIP_TRY_H(hipMemset(h->d_work, 0, (size_t)h->grid * D.work_stride * sizeof(double)));
+    HIP_TRY_H(hipMalloc(&h->d_scratch, (size_t)h->upd_grid * (size_t)(S.n + S.p + S.m + 8) * sizeof(double)));
+    HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIP_TRY_H(hipEventCreate(&h->ev_s0)); HIP_TRY_H(hipEventCreate(&h->ev_s1));
+    HIP_TRY_H(hipEventCreate(&h->ev_u0)); HIP_TRY_H(hipEventCreate(&h->ev_u1));
+    HIP_TRY_H(hipDeviceSynchronize());
+    *out = h;
+    return EICOS_OK;
+}
+
+int eicos_batch_destroy(eicos_batch *h) {
+    if (!h) return EICOS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
+    for (hipEvent_t e : {h->ev_s0, h->ev_s1, h->ev_u0, h->ev_u1}) if (e) (void)hipEventDestroy(e);
+    if (h->d_pattern) (void)hipFree(h->d_pattern);
+    if (h->d_inst) (void)hipFree(h->d_inst);
+    if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    delete h;
+    return EICOS_OK;
+}
+
+int eicos_batch_set_stream(eicos_batch *h, void *hip_stream) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return EICOS_OK;
+}
+
+int eicos_batch_update_device(eicos_batch *h, int first, int count, const double *dG, const double *dA,
+                              const double *dc, const double *dh, const double *db) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    if (first < 0 || count < 0 || first + count > h->batch) return fail(EICOS_E_INVALID, "instance range out of bounds");
+    if (dG && !dh && h->dp.m > 0) return fail(EICOS_E_INVALID, "Gpr given without h");
+    if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+    HIP_TRY(launch_update(h->dp, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
+    HIP_TRY(hipEventRecord(h->ev_u1, h->stream));
+    h->update_timed = true;
+    return EICOS_OK;
+}
+
+int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, const double *A,
+                       const double *c, const double *hh, const double *b) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    if (first < 0 || count < 0 || first + count > h->batch) return fail(EICOS_E_INVALID, "instance range out of bounds");
+    const DevPat &D = h->dp;
+    if (G && !hh && D.m > 0) return fail(EICOS_E_INVALID, "Gpr given without h");
+    if (A && !b && D.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
+    HIP_TRY(hipSetDevice(h->device));
+    const int chunk = 256;
+    const size_t per = (size_t)D.nnzG + D.nnzA + D.n + D.m + D.p + 5 * 8;
+    double *stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, (size_t)std::min(count > 0 ? count : 1, chunk) * per * sizeof(double)));
+    int rc = EICOS_OK;
+    for (int o = 0; o < count && rc == EICOS_OK; o += chunk) {
+        const int cnt = std::min(chunk, count - o);
+        double *dG = stage, *dA = dG + (size_t)cnt * D.nnzG + 8, *dc = dA + (size_t)cnt * D.nnzA + 8;
+        double *dh = dc + (size_t)cnt * D.n + 8, *db = dh + (size_t)cnt * D.m + 8;
+        auto up = [&](double *dst, const double *src, size_t w) -> hipError_t {
+            if (!src || w == 0) return hipSuccess;
+            return hipMemcpyAsync(dst, src + (size_t)o * w, (size_t)cnt * w * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        };
+        hipError_t e = up(dG, G, D.nnzG);
+        if (e == hipSuccess) e = up(dA, A, D.nnzA);
+        if (e == hipSuccess) e = up(dc, c, D.n);
+        if (e == hipSuccess && G) e = up(dh, hh, D.m);
+        if (e == hipSuccess && A) e = up(db, b, D.p);
+        if (e != hipSuccess) { rc = fail(EICOS_E_HIP, hipGetErrorString(e)); break; }
+        rc = eicos_batch_update_device(h, first + o, cnt, G ? dG : nullptr, A ? dA : nullptr, c ? dc : nullptr,
+                                       G ? dh : nullptr, A ? db : nullptr);
+        if (rc == EICOS_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(EICOS_E_HIP, "stream sync failed in update");
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+int eicos_batch_solve_async(eicos_batch *h) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
+    HIP_TRY(launch_solve(h->dp, h->d_inst, h->d_work, h->batch, h->grid, h->threads, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
+    h->solve_timed = true;
+    return EICOS_OK;
+}
+
+int eicos_batch_sync(eicos_batch *h) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return EICOS_OK;
+}
+
+static int fetch_rows(eicos_batch *h, double *dst, int off, int width) {
+    if (!dst || width == 0) return EICOS_OK;
+    HIP_TRY(hipMemcpy2D(dst, (size_t)width * sizeof(double), h->d_inst + off, h->dp.inst_stride * sizeof(double),
+                        (size_t)width * sizeof(double), (size_t)h->batch, hipMemcpyDeviceToHost));
+    return EICOS_OK;
+}
+
+int eicos_batch_info(eicos_batch *h, eicos_info *info) {
+    if (!h || !info) return fail(EICOS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<DevInfo> tmp(h->batch);
+    HIP_TRY(hipMemcpy2D(tmp.data(), sizeof(DevInfo), h->d_inst + h->dp.i_info, h->dp.inst_stride * sizeof(double),
+                        sizeof(DevInfo), (size_t)h->batch, hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->batch; i++) {
+        const DevInfo &d = tmp[i];
+        eicos_info &o = info[i];
+        o.pcost = d.pcost; o.dcost = d.dcost; o.pres = d.pres; o.dres = d.dres; o.gap = d.gap; o.relgap = d.relgap;
+        o.sigma = d.sigma; o.mu = d.mu; o.step = d.step; o.step_aff = d.step_aff; o.kapovert = d.kapovert;
+        o.pinfres = d.pinfres; o.dinfres = d.dinfres; o.tau = d.tau; o.kap = d.kap;
+        o.has_relgap = d.has_relgap; o.has_pinfres = d.has_pinfres; o.has_dinfres = d.has_dinfres;
+        o.pinf = d.pinf; o.dinf = d.dinf; o.iter = d.iter; o.nitref1 = d.nitref1; o.nitref2 = d.nitref2;
+        o.nitref3 = d.nitref3; o.exitcode = d.exitcode; o.n_factor = d.n_factor; o.n_ldlsolve = d.n_ldlsolve;
+    }
+    return EICOS_OK;
+}
+
+int eicos_batch_solve(eicos_batch *h, int *exitcodes) {
+    int rc = eicos_batch_solve_async(h);
+    if (rc != EICOS_OK) return rc;
+    rc = eicos_batch_sync(h);
+    if (rc != EICOS_OK) return rc;
+    if (exitcodes) {
+        std::vector<eicos_info> info(h->batch);
+        rc = eicos_batch_info(h, info.data());
+        if (rc != EICOS_OK) return rc;
+        for (int i = 0; i < h->batch; i++) exitcodes[i] = info[i].exitcode;
+    }
+    return EICOS_OK;
+}
+
+int eicos_batch_solution(eicos_batch *h, double *x) {
+    if (!h || !x) return fail(EICOS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return fetch_rows(h, x, h->dp.i_x, h->dp.n);
+}
+
+int eicos_batch_duals(eicos_batch *h, double *y, double *z, double *s) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int rc = fetch_rows(h, y, h->dp.i_y, h->dp.p);
+    if (rc == EICOS_OK) rc = fetch_rows(h, z, h->dp.i_z, h->dp.m);
+    if (rc == EICOS_OK) rc = fetch_rows(h, s, h->dp.i_s, h->dp.m);
+    return rc;
+}
+
+int eicos_batch_solution_device(eicos_batch *h, const double **dx, size_t *stride) {
+    if (!h || !dx || !stride) return fail(EICOS_E_INVALID, "NULL argument");
+    *dx = h->d_inst + h->dp.i_x; *stride = h->dp.inst_stride;
+    return EICOS_OK;
+}
+
+int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
+    if (!h || !o) return fail(EICOS_E_INVALID, "NULL argument");
+    const Symbolic &S = h->sym;
+    o->n = S.n; o->m = S.m; o->p = S.p; o->l = S.l; o->ncones = S.nc; o->dim_K = S.N; o->nnzA = S.nnzA; o->nnzG = S.nnzG;
+    o->nnzK = S.nnzK; o->nnzL = S.nnzL; o->nlevels = S.nlev; o->order_mode = S.order_mode; o->batch = h->batch; o->device = h->device;
+    o->factor_pairs = S.npairs;
+    o->inst_bytes = h->dp.inst_stride * sizeof(double); o->work_bytes = h->dp.work_stride * sizeof(double);
+    o->pattern_bytes = h->pattern_ints * sizeof(int);
+    o->threads_per_block = h->threads; o->resident_blocks = h->grid;
+    return EICOS_OK;
+}
+
+static int elapsed(eicos_batch *h, bool ok, hipEvent_t a, hipEvent_t b, float *ms) {
+    if (!h || !ms) return fail(EICOS_E_INVALID, "NULL argument");
+    if (!ok) return fail(EICOS_E_INVALID, "nothing timed yet");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(b));
+    HIP_TRY(hipEventElapsedTime(ms, a, b));
+    return EICOS_OK;
+}
+int eicos_batch_last_solve_ms(eicos_batch *h, float *ms) { return elapsed(h, h && h->solve_timed, h ? h->ev_s0 : nullptr, h ? h->ev_s1 : nullptr, ms); }
+int eicos_batch_last_update_ms(eicos_batch *h, float *ms) { return elapsed(h, h && h->update_timed, h ? h->ev_u0 : nullptr, h ? h->ev_u1 : nullptr, ms); }
+
+int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
+    if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(launch_debug_factor(h->dp, h->d_inst, h->d_work, inst, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->dp.N * sizeof(double), hipMemcpyDeviceToHost));
+    if (Uout) HIP_TRY(hipMemcpy(Uout, h->d_work + h->dp.w_U, (size_t)h->dp.nnzL * sizeof(double), hipMemcpyDeviceToHost));
+    return EICOS_OK;
+}
+
+int eicos_debug_pattern(eicos_batch *h, int *perm, int *Lp, int *Li) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    const Symbolic &S = h->sym;
+    if (perm) std::copy(S.perm.begin(), S.perm.end(), perm);
+    if (Lp) std::copy(S.Lp.begin(), S.Lp.end(), Lp);
+    if (Li) std::copy(S.Li.begin(), S.Li.end(), Li);
+    return EICOS_OK;
+}
+
+
+// Host-only self check of the symbolic analysis (no GPU needed): random quasi-definite values
+// on the KKT pattern, the factor program and the level-scheduled gather solves executed
+// sequentially exactly as the kernels index them, then || K x - b ||_inf / || b ||_inf.
+double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                              const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats /*[8] or NULL*/) {
+    try {
+        ProblemPattern P;
+        P.n = n; P.m = m; P.p = p; P.nc = ncones; P.q.assign(q, q + ncones);
+        if (Gjc && Gir) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else { P.Gjc.assign(n + 1, 0); P.m = 0; P.nc = 0; P.q.clear(); }
+        if (Ajc && Air) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else { P.Ajc.assign(n + 1, 0); P.p = 0; }
+        Symbolic S = analyze(P, order_mode);
+        const int N = S.N;
+        if (stats) { stats[0] = N; stats[1] = S.nnzK; stats[2] = S.nnzL; stats[3] = S.nlev; stats[4] = (int)std::min<int64_t>(S.npairs, 2147483647); stats[5] = S.order_mode; stats[6] = S.max_row_len; stats[7] = S.max_col_len; }
+        // permutation sanity
+        std::vector<char> seen(N, 0);
+        for (int k = 0; k < N; k++) { if (S.perm[k] < 0 || S.perm[k] >= N || seen[S.perm[k]]) return -1.0; seen[S.perm[k]] = 1; }
+        unsigned long long st = seed * 2654435761ull + 12345;
+        auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return ((st >> 11) & 0xFFFFFFFFFFFFull) / (double)(1ull << 48); };
+        std::vector<double> Kv(S.nnzK);
+        for (int e = 0; e < S.nnzK; e++) {
+            const int r = S.K_row[e], c = S.K_col[e];
+            if (r == c) Kv[e] = (r < S.n ? 1.0 : -1.0) * (4.0 + rnd());
+            else Kv[e] = 0.2 * (rnd() - 0.5);
+        }
+        // values per L entry / diagonal in permuted order
+        std::vector<double> U(S.nnzL, 0.0), Ur(S.nnzL, 0.0), D(N, 0.0), invD(N, 0.0), Lv(S.nnzL, 0.0), Dv(N, 0.0);
+        for (int e = 0; e < S.nnzK; e++) {
+            const int a = S.iperm[S.K_row[e]], b = S.iperm[S.K_col[e]];
+            if (a == b) Dv[a] = Kv[e];
+            else {
+                const int i = std::max(a, b), j = std::min(a, b);
+                auto it = std::lower_bound(S.Li.begin() + S.Lp[j], S.Li.begin() + S.Lp[j + 1], i);
+                Lv[it - S.Li.begin()] = Kv[e];
+            }
+        }
+        for (int v = 0; v < S.nlev; v++)
+            for (int t = S.ftask_ptr[v]; t < S.ftask_ptr[v + 1]; t++) {
+                const int tgt = S.ftask[t];
+                double s = 0;
+                for (int64_t k = S.tp[tgt]; k < S.tp[tgt + 1]; k++) s += U[S.pa[k]] * U[S.pb[k]] * invD[S.pk[k]];
+                if (tgt < N) { D[tgt] = Dv[tgt] - s; invD[tgt] = 1.0 / D[tgt]; }
+                else { const int e = tgt - N; U[e] = Lv[e] - s; Ur[S.Cpos[e]] = U[e]; }
+            }
+        std::vector<double> rhs(N), ws(N), x(N);
+        for (int i = 0; i < N; i++) rhs[i] = rnd() - 0.5;
+        for (int v = 0; v < S.nlev; v++)
+            for (int i = S.lev_ptr[v]; i < S.lev_ptr[v + 1]; i++) {
+                double s = 0;
+                for (int e = S.Rp[i]; e < S.Rp[i + 1]; e++) s += Ur[e] * ws[S.Rj[e]];
+                ws[i] = (rhs[S.perm[i]] - s) * invD[i];
+            }
+        for (int v = S.nlev - 1; v >= 0; v--)
+            for (int j = S.lev_ptr[v]; j < S.lev_ptr[v + 1]; j++) {
+                double s = 0;
+                for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) s += U[e] * ws[S.Li[e]];
+                ws[j] -= invD[j] * s; x[S.perm[j]] = ws[j];
+            }
+        std::vector<double> r(rhs);
+        for (int e = 0; e < S.nnzK; e++) {
+            const int a = S.K_row[e], b = S.K_col[e];
+            r[a] -= Kv[e] * x[b];
+            if (a != b) r[b] -= Kv[e] * x[a];
+        }
+        double nr = 0, nb = 0;
+        for (int i = 0; i < N; i++) { nr = std::max(nr, std::fabs(r[i])); nb = std::max(nb, std::fabs(rhs[i])); }
+        return N ? nr / nb : 0.0;
+    } catch (const std::exception &e) { g_err = e.what(); return -2.0; }
+}
+
+} // extern "C"

@@ -1,0 +1,269 @@
+// Host-side symbolic analysis (see symbolic.hpp).  Plain C++17, no GPU code.
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+
+namespace eicos {
+namespace {
+
+using ivec = std::vector<int>;
+
+void transpose_pattern(int rows, int cols, const ivec &jc, const ivec &ir, ivec &tptr, ivec &tcol, ivec &tpos) {
+    const int nnz = (int)ir.size();
+    tptr.assign(rows + 1, 0); tcol.resize(nnz); tpos.resize(nnz);
+    for (int k = 0; k < nnz; k++) tptr[ir[k] + 1]++;
+    for (int r = 0; r < rows; r++) tptr[r + 1] += tptr[r];
+    ivec next(tptr.begin(), tptr.end() - 1);
+    for (int j = 0; j < cols; j++)
+        for (int k = jc[j]; k < jc[j + 1]; k++) { int d = next[ir[k]]++; tcol[d] = j; tpos[d] = k; }
+}
+
+// Minimum-degree ordering on the explicit elimination graph.
+// mode 1: each round eliminates a maximal independent set of minimum-degree nodes
+// (multiple elimination), which keeps the elimination tree bushy -- tree height is the
+// number of dependent steps of every GPU triangular solve, so it matters as much as fill.
+ivec order_min_degree(int N, const ivec &er, const ivec &ec, int mode) {
+    std::vector<ivec> adj(N);
+    for (size_t e = 0; e < er.size(); e++)
+        if (er[e] != ec[e]) { adj[er[e]].push_back(ec[e]); adj[ec[e]].push_back(er[e]); }
+    for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    std::vector<char> dead(N, 0);
+    ivec order; order.reserve(N);
+    ivec mark(N, -1), cand, chosen, merged, nv;
+    int round = 0, alive = N;
+    while (alive > 0) {
+        size_t mind = (size_t)-1;
+        for (int v = 0; v < N; v++) if (!dead[v]) mind = std::min(mind, adj[v].size());
+        chosen.clear();
+        if (mode == 0) {
+            for (int v = 0; v < N; v++) if (!dead[v] && adj[v].size() == mind) { chosen.push_back(v); break; }
+        } else {
+            // mode = 1 + slack: nodes within `slack` of the minimum degree are eligible too,
+            // lowest degree first (plain minimum degree peels chain-like graphs from their
+            // two ends, which gives a tree as deep as the chain is long).
+            const size_t slack = (size_t)(mode - 1);
+            cand.clear();
+            for (size_t d = mind; d <= mind + slack; d++)
+                for (int v = 0; v < N; v++) if (!dead[v] && adj[v].size() == d) cand.push_back(v);
+            for (int v : cand) {
+                if (mark[v] == round) continue;
+                chosen.push_back(v);
+                mark[v] = round;
+                for (int u : adj[v]) mark[u] = round;
+            }
+        }
+        for (int v : chosen) {
+            dead[v] = 1; order.push_back(v); alive--;
+            nv.swap(adj[v]); adj[v].clear();
+            for (int u : nv) {
+                merged.clear();
+                std::set_union(adj[u].begin(), adj[u].end(), nv.begin(), nv.end(), std::back_inserter(merged));
+                ivec &au = adj[u]; au.clear();
+                for (int w : merged) if (w != u && w != v) au.push_back(w);
+            }
+        }
+        round++;
+    }
+    return order;
+}
+
+// For a symmetric pattern given by upper entries under permutation iperm: per new column,
+// the list of new rows < column.
+std::vector<ivec> permuted_upper(int N, const ivec &er, const ivec &ec, const ivec &iperm) {
+    std::vector<ivec> up(N);
+    for (size_t e = 0; e < er.size(); e++) {
+        int a = iperm[er[e]], b = iperm[ec[e]];
+        if (a == b) continue;
+        up[std::max(a, b)].push_back(std::min(a, b));
+    }
+    return up;
+}
+
+// Elimination tree + row patterns of L (row k = set of columns i<k with L[k,i] != 0).
+void etree_rows(int N, const std::vector<ivec> &up, ivec &parent, std::vector<ivec> *rows) {
+    parent.assign(N, -1);
+    ivec flag(N, -1);
+    if (rows) rows->assign(N, ivec());
+    for (int k = 0; k < N; k++) {
+        flag[k] = k;
+        for (int i0 : up[k])
+            for (int i = i0; flag[i] != k; i = parent[i]) {
+                if (parent[i] < 0) parent[i] = k;
+                flag[i] = k;
+                if (rows) (*rows)[k].push_back(i);
+            }
+    }
+}
+
+} // namespace
+
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode);
+
+// order_mode < 0: try several slacks and keep the cheapest under a simple cost model:
+// every level costs the GPU one workgroup barrier + a dependent memory round trip, which is
+// priced here like LEVEL_COST entries of L.
+Symbolic analyze(const ProblemPattern &P, int order_mode) {
+    if (order_mode >= 0) return analyze_mode(P, order_mode);
+    constexpr double LEVEL_COST = 64.0;
+    Symbolic best;
+    double best_cost = -1;
+    for (int mode : {1, 2, 3, 4, 6}) {
+        Symbolic S = analyze_mode(P, mode);
+        const double cost = S.nnzL + LEVEL_COST * S.nlev;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = std::move(S); }
+    }
+    return best;
+}
+
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
+    Symbolic S;
+    S.order_mode = order_mode;
+    S.n = P.n; S.p = P.p; S.m = P.m; S.nc = P.nc; S.q = P.q;
+    int qsum = 0;
+    for (int d : P.q) { if (d < 1) throw std::invalid_argument("cone dimension < 1"); qsum += d; }
+    S.l = P.m - qsum;
+    if (S.l < 0) throw std::invalid_argument("sum(q) > m");
+    S.N = P.n + P.p + P.m + 2 * P.nc;
+    S.mt = P.m + 2 * P.nc;
+    S.nnzA = P.nnzA(); S.nnzG = P.nnzG();
+    S.cone_off.resize(P.nc);
+    { int o = S.l; for (int c = 0; c < P.nc; c++) { S.cone_off[c] = o; o += P.q[c]; } }
+    S.nV = S.l; for (int d : P.q) S.nV += 3 * d + 1;
+
+    transpose_pattern(P.p, P.n, P.Ajc, P.Air, S.At_ptr, S.At_col, S.At_pos);
+    transpose_pattern(P.m, P.n, P.Gjc, P.Gir, S.Gt_ptr, S.Gt_col, S.Gt_pos);
+
+    // ---- KKT pattern, reference layout (src/eicos.cpp:1765-1878) ----
+    auto addK = [&](int r, int c, int kind, int src) { S.K_row.push_back(r); S.K_col.push_back(c); S.K_kind.push_back(kind); S.K_src.push_back(src); };
+    const int n = S.n, p = S.p;
+    for (int j = 0; j < n; j++) addK(j, j, SRC_POSDELTA, 0);
+    for (int r = 0; r < p; r++) {
+        for (int k = S.At_ptr[r]; k < S.At_ptr[r + 1]; k++) addK(S.At_col[k], n + r, SRC_A, S.At_pos[k]);
+        addK(n + r, n + r, SRC_NEGDELTA, 0);
+    }
+    int grow = 0, col = n + p, vs = 0;
+    for (int i = 0; i < S.l; i++, grow++, col++) {
+        for (int k = S.Gt_ptr[grow]; k < S.Gt_ptr[grow + 1]; k++) addK(S.Gt_col[k], col, SRC_G, S.Gt_pos[k]);
+        addK(col, col, SRC_V, vs++);
+    }
+    for (int c = 0; c < S.nc; c++) {
+        const int d = P.q[c], c0 = col, base = vs;
+        for (int i = 0; i < d; i++, grow++, col++) {
+            for (int k = S.Gt_ptr[grow]; k < S.Gt_ptr[grow + 1]; k++) addK(S.Gt_col[k], col, SRC_G, S.Gt_pos[k]);
+            addK(col, col, SRC_V, base + i);                       // D_i
+        }
+        for (int i = 1; i < d; i++) addK(c0 + i, col, SRC_V, base + d + i); // v_{i-1} at slot d+1+(i-1)
+        addK(col, col, SRC_V, base + d);                           // v diagonal
+        col++;
+        for (int i = 0; i < d; i++) addK(c0 + i, col, SRC_V, base + 2 * d + 1 + i); // u_i
+        addK(col, col, SRC_V, base + 2 * d);                       // u diagonal
+        col++;
+        vs += 3 * d + 1;
+    }
+    S.nnzK = (int)S.K_row.size();
+    const int N = S.N;
+
+    // ---- ordering, then renumber so that etree levels are contiguous ----
+    ivec perm0 = order_min_degree(N, S.K_row, S.K_col, order_mode);
+    ivec iperm0(N);
+    for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
+    {
+        auto up = permuted_upper(N, S.K_row, S.K_col, iperm0);
+        ivec par; etree_rows(N, up, par, nullptr);
+        ivec level(N, 0);
+        for (int k = 0; k < N; k++) if (par[k] >= 0) level[par[k]] = std::max(level[par[k]], level[k] + 1);
+        ivec idx(N); std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level[a] < level[b]; });
+        S.perm.resize(N); S.iperm.resize(N);
+        for (int k = 0; k < N; k++) { S.perm[k] = perm0[idx[k]]; S.iperm[S.perm[k]] = k; }
+        S.nlev = N ? level[idx[N - 1]] + 1 : 0;
+        S.lev_ptr.assign(S.nlev + 1, 0);
+        for (int k = 0; k < N; k++) S.lev_ptr[level[idx[k]] + 1]++;
+        for (int v = 0; v < S.nlev; v++) S.lev_ptr[v + 1] += S.lev_ptr[v];
+    }
+
+    // ---- L pattern under the final ordering ----
+    std::vector<ivec> rows;
+    {
+        auto up = permuted_upper(N, S.K_row, S.K_col, S.iperm);
+        etree_rows(N, up, S.parent, &rows);
+    }
+    S.Rp.assign(N + 1, 0);
+    for (int i = 0; i < N; i++) { std::sort(rows[i].begin(), rows[i].end()); S.Rp[i + 1] = S.Rp[i] + (int)rows[i].size(); }
+    S.nnzL = S.Rp[N];
+    S.Rj.resize(S.nnzL);
+    for (int i = 0; i < N; i++) std::copy(rows[i].begin(), rows[i].end(), S.Rj.begin() + S.Rp[i]);
+    S.Lp.assign(N + 1, 0);
+    for (int e = 0; e < S.nnzL; e++) S.Lp[S.Rj[e] + 1]++;
+    for (int j = 0; j < N; j++) S.Lp[j + 1] += S.Lp[j];
+    S.Li.resize(S.nnzL); S.Rpos.resize(S.nnzL); S.Cpos.resize(S.nnzL);
+    {
+        ivec next(S.Lp.begin(), S.Lp.end() - 1);
+        for (int i = 0; i < N; i++)
+            for (int e = S.Rp[i]; e < S.Rp[i + 1]; e++) { int d = next[S.Rj[e]]++; S.Li[d] = i; S.Rpos[e] = d; S.Cpos[d] = e; }
+    }
+    for (int i = 0; i < N; i++) S.max_row_len = std::max(S.max_row_len, S.Rp[i + 1] - S.Rp[i]);
+    for (int j = 0; j < N; j++) S.max_col_len = std::max(S.max_col_len, S.Lp[j + 1] - S.Lp[j]);
+
+    auto find_csc = [&](int i, int j) { // position of L[i,j], i>j
+        auto b = S.Li.begin() + S.Lp[j], e = S.Li.begin() + S.Lp[j + 1];
+        auto it = std::lower_bound(b, e, i);
+        if (it == e || *it != i) throw std::logic_error("symbolic: entry missing from L pattern");
+        return (int)(it - S.Li.begin());
+    };
+
+    // ---- numeric sources ----
+    S.Lkind.assign(S.nnzL, SRC_ZERO); S.Lsrc.assign(S.nnzL, 0);
+    S.Dkind.assign(N, SRC_ZERO); S.Dsrc.assign(N, 0);
+    for (int e = 0; e < S.nnzK; e++) {
+        int a = S.iperm[S.K_row[e]], b = S.iperm[S.K_col[e]];
+        if (a == b) { S.Dkind[a] = S.K_kind[e]; S.Dsrc[a] = S.K_src[e]; }
+        else { int pos = find_csc(std::max(a, b), std::min(a, b)); S.Lkind[pos] = S.K_kind[e]; S.Lsrc[pos] = S.K_src[e]; }
+    }
+
+    // ---- factor program ----
+    const int64_t NT = (int64_t)N + S.nnzL;
+    S.tp.assign(NT + 1, 0);
+    auto for_each_pair = [&](auto &&fn) {
+        for (int k = 0; k < N; k++) {
+            const int b0 = S.Lp[k], b1 = S.Lp[k + 1];
+            for (int eb = b0; eb < b1; eb++) {
+                const int rb = S.Li[eb];
+                fn((int64_t)rb, eb, eb, k);
+                for (int ea = eb + 1; ea < b1; ea++) fn((int64_t)N + find_csc(S.Li[ea], rb), ea, eb, k);
+            }
+        }
+    };
+    int64_t np = 0;
+    for (int k = 0; k < N; k++) { int64_t c = S.Lp[k + 1] - S.Lp[k]; np += c * (c + 1) / 2; }
+    S.npairs = np;
+    if (np > (int64_t)400 * 1000 * 1000)
+        throw std::runtime_error("symbolic: factor program too large (dense fronts need the supernodal path)");
+    for_each_pair([&](int64_t t, int, int, int) { S.tp[t + 1]++; });
+    for (int64_t t = 0; t < NT; t++) S.tp[t + 1] += S.tp[t];
+    S.pa.resize(np); S.pb.resize(np); S.pk.resize(np);
+    {
+        std::vector<int64_t> next(S.tp.begin(), S.tp.end() - 1);
+        for_each_pair([&](int64_t t, int ea, int eb, int k) { int64_t d = next[t]++; S.pa[d] = ea; S.pb[d] = eb; S.pk[d] = k; });
+    }
+    S.flops_factor = 3.0 * (double)np + N;
+
+    // ---- per-level task lists, longest first ----
+    S.ftask_ptr.assign(S.nlev + 1, 0);
+    S.ftask.reserve(NT);
+    for (int v = 0; v < S.nlev; v++) {
+        const int j0 = S.lev_ptr[v], j1 = S.lev_ptr[v + 1];
+        const size_t start = S.ftask.size();
+        for (int j = j0; j < j1; j++) S.ftask.push_back(j);
+        for (int e = S.Lp[j0]; e < S.Lp[j1]; e++) S.ftask.push_back(N + e);
+        std::stable_sort(S.ftask.begin() + start, S.ftask.end(), [&](int a, int b) {
+            return (S.tp[a + 1] - S.tp[a]) > (S.tp[b + 1] - S.tp[b]);
+        });
+        S.ftask_ptr[v + 1] = (int)S.ftask.size();
+    }
+    return S;
+}
+
+} // namespace eicos

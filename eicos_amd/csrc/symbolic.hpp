@@ -1,0 +1,62 @@
+// Host-side symbolic analysis for the batched KKT LDL' (one pattern, many numeric instances).
+//
+// Replaces, for the product path, what the reference obtains from
+// Eigen::SimplicialLDLT::analyzePattern (reference src/eicos.cpp:897) and from
+// setupKKT/cacheIndices (src/eicos.cpp:1734-1988): the KKT pattern, a fill-reducing
+// ordering, the elimination tree, the pattern of L -- plus what a GPU needs on top:
+// a level schedule (nodes renumbered so each etree level is a contiguous index range),
+// CSR and CSC views of L, and an explicit update program for the numeric factorisation.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace eicos {
+
+struct ProblemPattern {
+    int n = 0, m = 0, p = 0, l = 0, nc = 0;
+    std::vector<int> q;
+    std::vector<int> Gjc, Gir, Ajc, Air; // CSC patterns (G: m x n, A: p x n)
+    int nnzG() const { return (int)Gir.size(); }
+    int nnzA() const { return (int)Air.size(); }
+};
+
+// Where one KKT entry's numeric value comes from, per instance.
+enum SrcKind : int { SRC_ZERO = 0, SRC_A = 1, SRC_G = 2, SRC_V = 3, SRC_POSDELTA = 4, SRC_NEGDELTA = 5 };
+
+struct Symbolic {
+    // dimensions (reference src/eicos.cpp:152-165)
+    int n = 0, p = 0, m = 0, l = 0, nc = 0, N = 0, mt = 0, nV = 0, nnzA = 0, nnzG = 0, nnzK = 0;
+    std::vector<int> q, cone_off;   // cone_off[c] = first row of cone c in z/s (un-expanded)
+    // transposed (row-major) views of A and G: ptr over rows, column index, position in CSC values
+    std::vector<int> At_ptr, At_col, At_pos, Gt_ptr, Gt_col, Gt_pos;
+    // KKT upper triangle in the reference's column layout (Appendix B of SURVEY.md)
+    std::vector<int> K_row, K_col, K_kind, K_src; // per entry: coordinates, SrcKind, index into that source
+    // ordering: perm[new] = old KKT index ; iperm[old] = new
+    std::vector<int> perm, iperm;
+    // L pattern (strictly lower), nodes in level order
+    int nnzL = 0, nlev = 0;
+    std::vector<int> lev_ptr;           // nlev+1: node range of each level
+    std::vector<int> Lp, Li;            // CSC: column j holds rows i>j   (used by backward solve)
+    std::vector<int> Rp, Rj, Rpos;      // CSR: row i holds cols k<i ; Rpos = position in CSC arrays
+    std::vector<int> Cpos;              // CSC entry -> position in CSR arrays
+    std::vector<int> parent;
+    // numeric sources of the permuted lower triangle: per CSC entry / per diagonal: (kind, src) or SRC_ZERO (fill)
+    std::vector<int> Lkind, Lsrc, Dkind, Dsrc;
+    // factor program: target t in [0,N) = diagonal t ; t in [N, N+nnzL) = CSC entry t-N.
+    // pairs of target t: [tp[t], tp[t+1]) ; value -= U[pa]*U[pb]*invD[pk]   (positions in CSC order)
+    std::vector<int64_t> tp;
+    std::vector<int> pa, pb, pk;
+    int64_t npairs = 0;
+    // per-level task lists (targets sorted by decreasing pair count)
+    std::vector<int> ftask_ptr, ftask;  // nlev+1 ; target ids
+    double flops_factor = 0;            // 2*npairs + divisions
+    int max_row_len = 0, max_col_len = 0;
+    int order_mode = 0;                 // slack+1 actually used
+};
+
+// order_mode: 0 = minimum degree, ties by index (sequential; deep trees)
+//             k>=1 = multiple independent elimination of nodes within k-1 of the minimum degree
+//             <0 = try several k, keep the best under a fill + tree-height cost model (default)
+Symbolic analyze(const ProblemPattern &P, int order_mode = -1);
+
+} // namespace eicos

@@ -1,0 +1,79 @@
+"""Synthetic instance generator for batched benchmarks/tests.
+
+Given a pattern and base values (A, G), every instance i draws a strictly feasible
+primal-dual pair and derives (c, h, b) from it, so each instance is guaranteed OPTIMAL:
+    x0 ~ N(0,1)^n ; y0 ~ N(0,1)^p ; s0, z0 strictly inside the cone
+    (LP part U(0.5,2); SOC: tail ~ N(0,1), head = ||tail|| + U(0.5,2))
+    h = G x0 + s0 ;  b = A x0 ;  c = -A' y0 - G' z0
+Randomness: numpy Philox keyed by (seed, GLOBAL instance index) -- any shard of the batch
+regenerates exactly its own instances, on any rank.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.sparse import csc_matrix
+
+from .problem_io import Pattern, Values
+
+SEED = 20261002
+
+
+def _cone_point(rng, pat: Pattern):
+    v = np.empty(pat.m)
+    v[: pat.l] = rng.uniform(0.5, 2.0, pat.l)
+    o = pat.l
+    for d in pat.q:
+        tail = rng.standard_normal(d - 1)
+        v[o] = np.linalg.norm(tail) + rng.uniform(0.5, 2.0)
+        v[o + 1: o + d] = tail
+        o += d
+    return v
+
+
+def feasible_batch(pat: Pattern, base: Values, first: int, count: int, seed: int = SEED):
+    """Return dict of arrays [count, ...]: Gpr, Apr (base values repeated), c, h, b."""
+    G = csc_matrix((base.Gpr, pat.Gir, pat.Gjc), shape=(pat.m, pat.n))
+    A = csc_matrix((base.Apr, pat.Air, pat.Ajc), shape=(pat.p, pat.n))
+    c = np.empty((count, pat.n)); h = np.empty((count, pat.m)); b = np.empty((count, pat.p))
+    for k in range(count):
+        rng = np.random.Generator(np.random.Philox(key=[seed, first + k]))
+        x0 = rng.standard_normal(pat.n)
+        y0 = rng.standard_normal(pat.p)
+        s0 = _cone_point(rng, pat)
+        z0 = _cone_point(rng, pat)
+        h[k] = G @ x0 + s0
+        b[k] = A @ x0
+        c[k] = -(A.T @ y0) - (G.T @ z0)
+    return dict(Gpr=np.broadcast_to(base.Gpr, (count, pat.nnzG)).copy(),
+                Apr=np.broadcast_to(base.Apr, (count, pat.nnzA)).copy(), c=c, h=h, b=b)
+
+
+def perturbed_batch(pat: Pattern, base: Values, first: int, count: int, seed: int = SEED):
+    """LPnetlib-style batch: keep A, G, b; c <- c(1+0.01 U(-1,1));
+    h <- h + 0.01 (1+|h|) U(0,1) (pure relaxation); global instance 0 is unperturbed."""
+    c = np.empty((count, pat.n)); h = np.empty((count, pat.m))
+    for k in range(count):
+        rng = np.random.Generator(np.random.Philox(key=[seed, first + k]))
+        if first + k == 0:
+            c[k], h[k] = base.c, base.h
+        else:
+            c[k] = base.c * (1 + 0.01 * rng.uniform(-1, 1, pat.n))
+            h[k] = base.h + 0.01 * (1 + np.abs(base.h)) * rng.uniform(0, 1, pat.m)
+    rep = lambda a, w: np.broadcast_to(a, (count, w)).copy()
+    return dict(Gpr=rep(base.Gpr, pat.nnzG), Apr=rep(base.Apr, pat.nnzA), c=c, h=h, b=rep(base.b, pat.p))
+
+
+def mpc_soc_variant(pat: Pattern, base: Values, rows_from: int = 3000, dim: int = 3):
+    """'MPC-SOC' pattern: rows >= rows_from of an LP-only pattern are
+    regrouped, in order, into second-order cones of size `dim` (row order unchanged)."""
+    assert pat.ncones == 0 and (pat.m - rows_from) % dim == 0
+    k = (pat.m - rows_from) // dim
+    q = np.full(k, dim, np.int32)
+    return Pattern(pat.n, pat.m, pat.p, rows_from, q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous shard [first, first+count) of `total` instances for `rank` of `world`."""
+    base, rem = divmod(total, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)

@@ -1,0 +1,131 @@
+/*
+ * include/eicos_amd.h -- C ABI of the MI355X batched SOCP interior-point solver.
+ *
+ * This is the drop-in boundary for the EiCOS hot path.  The reference has no FFI of its own;
+ * its public surface is class EiCOS::Solver (reference include/eicos.hpp:137-163) and the
+ * closest thing to a C ABI is the ECOS shim of reference test/ecos.h:11-34
+ * (ECOS_setup / ECOS_solve / ECOS_updateData / ECOS_cleanup).  Each entry point below names
+ * the reference interface it replaces.  include/eicos.hpp (this repo) re-creates
+ * class EiCOS::Solver on top of this ABI with batch = 1; INTEGRATION.md shows the bindings.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer it passes; all
+ * functions return 0 on success or a negative EICOS_E_* code (never throw across the ABI);
+ * eicos_last_error() returns a thread-local message for the last failure.
+ * All arithmetic is fp64, indices are 32-bit int (Eigen's default StorageIndex).
+ *
+ * One handle = one sparsity pattern (G: m x n CSC, A: p x n CSC, cone sizes q) analysed once
+ * on the host + `batch` numeric instances resident in HBM on one GPU.  Instances are
+ * independent; a multi-GPU job creates one handle per rank with its shard of the batch.
+ */
+#ifndef EICOS_AMD_H
+#define EICOS_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eicos_batch eicos_batch; /* opaque */
+
+enum {
+    EICOS_OK = 0,
+    EICOS_E_INVALID = -1,   /* bad argument / inconsistent dimensions          */
+    EICOS_E_NOGPU = -2,     /* no usable HIP device (there is NO CPU fallback) */
+    EICOS_E_HIP = -3,       /* a HIP runtime call failed                       */
+    EICOS_E_UNSUPPORTED = -4 /* pattern too dense for the current factor path  */
+};
+
+/* exit codes per instance: values of enum class EiCOS::exitcode (reference include/eicos.hpp:8-21) */
+enum {
+    EICOS_OPTIMAL = 0, EICOS_PINF = 1, EICOS_DINF = 2, EICOS_MAXIT = -1, EICOS_NUMERICS = -2,
+    EICOS_OUTCONE = -3, EICOS_FATAL = -7, EICOS_INACC_OFFSET = 10
+};
+
+/* Mirror of struct EiCOS::Information (reference include/eicos.hpp:49-73); the three
+ * std::optional<double> members are flattened into value + has_* flag.  tau/kap/exitcode and
+ * the n_* counters are additions (the counters feed the roofline byte model of bench.py). */
+typedef struct eicos_info {
+    double pcost, dcost, pres, dres, gap, relgap, sigma, mu, step, step_aff, kapovert;
+    double pinfres, dinfres, tau, kap;
+    int has_relgap, has_pinfres, has_dinfres, pinf, dinf;
+    int iter, nitref1, nitref2, nitref3, exitcode;
+    int n_factor;   /* numeric LDL' factorisations in the last solve (1 + completed passes) */
+    int n_ldlsolve; /* LDL' solves in the last solve (incl. refinement solves)             */
+} eicos_info;
+
+/* Pattern / size report of a handle (for byte accounting and tests). */
+typedef struct eicos_dims {
+    int n, m, p, l, ncones, dim_K, nnzA, nnzG, nnzK, nnzL, nlevels, order_mode, batch, device;
+    long long factor_pairs;      /* multiply-subtract pairs of one numeric factorisation */
+    size_t inst_bytes, work_bytes, pattern_bytes;
+    int threads_per_block, resident_blocks;
+} eicos_dims;
+
+/* ---- construction: replaces Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)
+ * (reference include/eicos.hpp:151-154, src/eicos.cpp:91-120) + build() (:132-187), for a
+ * whole batch.  Pattern only; values arrive through eicos_batch_update*.  `l` is ignored as in
+ * the reference (src/eicos.cpp:91); NULL Gjc/Gir (or Ajc/Air) mean "no G" ("no A").
+ * device < 0 selects the current HIP device. */
+int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
+                       const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
+                       int batch, int device, eicos_batch **out);
+
+/* ---- updateData: replaces Solver::updateData(double*Gpr,double*Apr,double*c,double*h,double*b)
+ * (reference include/eicos.hpp:155-156, src/eicos.cpp:2053-2082) for instances
+ * [first, first+count).  Arrays are [count][nnzG], [count][nnzA], [count][n], [count][m],
+ * [count][p], row-major, HOST pointers; NULL = keep that group (h is read only with Gpr, b only
+ * with Apr, as in the reference).  Runs un-equilibrate -> copy-in -> setEquilibration (:302-374)
+ * -> transposes -> KKT value refresh on the GPU. */
+int eicos_batch_update(eicos_batch *hd, int first, int count,
+                       const double *Gpr, const double *Apr,
+                       const double *c, const double *h, const double *b);
+/* Same, DEVICE pointers (inputs already resident in HBM; no PCIe traffic). */
+int eicos_batch_update_device(eicos_batch *hd, int first, int count,
+                              const double *dGpr, const double *dApr,
+                              const double *dc, const double *dh, const double *db);
+
+/* ---- solve: replaces exitcode Solver::solve(bool) (reference include/eicos.hpp:158,
+ * src/eicos.cpp:848-1262) for every instance of the batch.  exitcodes (host, [batch]) may be
+ * NULL.  Synchronous: returns after the GPU work has completed. */
+int eicos_batch_solve(eicos_batch *hd, int *exitcodes);
+/* Asynchronous half: enqueue on the handle's stream and return; eicos_batch_sync waits. */
+int eicos_batch_solve_async(eicos_batch *hd);
+int eicos_batch_sync(eicos_batch *hd);
+
+/* ---- results: replaces solution() (reference include/eicos.hpp:160) / getInfo() (:163).
+ * x: [batch][n] host.  y,z,s are extras the reference keeps private; any may be NULL. */
+int eicos_batch_solution(eicos_batch *hd, double *x);
+int eicos_batch_duals(eicos_batch *hd, double *y, double *z, double *s);
+int eicos_batch_info(eicos_batch *hd, eicos_info *info /* [batch] */);
+/* Device-resident results (no copy): pointer to instance 0's x and the stride in doubles. */
+int eicos_batch_solution_device(eicos_batch *hd, const double **dx, size_t *stride_doubles);
+
+/* ---- plumbing */
+int eicos_batch_dims(eicos_batch *hd, eicos_dims *out);
+/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the own stream. */
+int eicos_batch_set_stream(eicos_batch *hd, void *hip_stream);
+/* HIP-event timing of the most recent solve / update kernels on the handle's stream (ms). */
+int eicos_batch_last_solve_ms(eicos_batch *hd, float *ms);
+int eicos_batch_last_update_ms(eicos_batch *hd, float *ms);
+/* replaces the Solver destructor / ECOS_cleanup (reference test/ecos.h:31-34) */
+int eicos_batch_destroy(eicos_batch *hd);
+
+const char *eicos_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU); never initialises a context */
+int eicos_device_count(void);
+
+/* Debug/parity hooks (tests only): numeric LDL' of instance `inst` with the KKT values as they
+ * stand, and one LDL' solve. Host buffers. */
+int eicos_debug_factor(eicos_batch *hd, int inst, double *D /*[dim_K], permuted*/, double *U /*[nnzL] CSC, permuted*/);
+int eicos_debug_pattern(eicos_batch *hd, int *perm /*[dim_K]*/, int *Lp /*[dim_K+1]*/, int *Li /*[nnzL]*/);
+
+/* Host-only self check of the symbolic analysis + factor/solve programs (no GPU needed):
+ * returns ||K x - b||_inf / ||b||_inf for random quasi-definite values, < 0 on error. */
+double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                              const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+/*
+ * oracle/eicos_oracle.h -- C ABI of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library.  The product path
+ * (eicos_amd/, include/) never includes, links or calls anything in oracle/.
+ *
+ * The oracle is a CPU restatement (own code, no Eigen) of the algorithm in the reference
+ * /root/reference/src/eicos.cpp; every function in eicos_oracle.cpp cites the reference
+ * lines it follows.  Parity pins: see the header comment of eicos_oracle.cpp.
+ */
+#ifndef EICOS_ORACLE_H
+#define EICOS_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirror of EiCOS::Information (reference include/eicos.hpp:49-73) with the std::optional
+ * members flattened into value + has_* flag, plus tau/kap and the exit code. */
+typedef struct oracle_info {
+    double pcost, dcost, pres, dres, gap, relgap, sigma, mu, step, step_aff, kapovert;
+    double pinfres, dinfres, tau, kap;
+    int has_relgap, has_pinfres, has_dinfres, pinf, dinf;
+    int iter, nitref1, nitref2, nitref3, exitcode;
+    /* bookkeeping the reference does not expose: totals over the whole solve() */
+    int n_factor; /* numeric factorisations (1 + completed passes)       */
+    int n_ldlsolve; /* LDL solves (first solve + refinement solves)        */
+} oracle_info;
+
+/* Same argument convention as the reference's raw constructor
+ * (include/eicos.hpp:151-154): NULL groups allowed, `l` ignored. */
+void *oracle_create(int n, int m, int p, int l, int ncones, const int *q,
+                    const double *Gpr, const int *Gjc, const int *Gir,
+                    const double *Apr, const int *Ajc, const int *Air,
+                    const double *c, const double *h, const double *b);
+/* reference updateData(double*...) include/eicos.hpp:155-156 : NULL = keep */
+void oracle_update(void *s, const double *Gpr, const double *Apr,
+                   const double *c, const double *h, const double *b);
+int oracle_solve(void *s);
+void oracle_get_info(void *s, oracle_info *out);
+/* x is the only vector the reference exposes (solution()); y,z,s are extras for tests */
+void oracle_get_x(void *s, double *x);
+void oracle_get_yzs(void *s, double *y, double *z, double *sl);
+void oracle_get_dims(void *s, int *dimK, int *nnzK, int *nnzL);
+void oracle_destroy(void *s);
+
+/* CPU-baseline driver: solve `batch` instances that share one pattern, one instance at a
+ * time per thread (first instance via the constructor, the rest via oracle_update --
+ * the reference's updateData path, src/run.cpp:34-50).  Arrays are [batch][...].
+ * Returns wall seconds of the solve phase only (update time returned via *update_s). */
+double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,
+                          const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
+                          int batch, const double *Gpr, const double *Apr,
+                          const double *c, const double *h, const double *b,
+                          int nthreads, int *exitcodes, int *iters, double *pcost,
+                          double *x_out /* [batch][n] or NULL */, double *update_s,
+                          long long *total_ldlsolves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
