@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: IPM iterations/sec (fp64) on batched MPC-shaped SOCPs.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 default)
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): per GPU a batch of 1024 instances on the
+MPC02 sparsity pattern (the MPC01 blob named by BASELINE.json is missing from the reference
+mount), strictly feasible (c,h,b) from eicos_amd.generate keyed by
+(seed, global instance index).  One "step" = one pass of the hot path over the batch with the
+raw inputs already resident in HBM: updateData (equilibrate + transposes, on device) followed
+by the batched cold-start solve.  Metric value = sum over instances of Information.iter / time.
+Multi-GPU: instances are independent -> each rank owns a contiguous shard (weak scaling,
+1024 per GPU), no data-path collective; only the timing/iteration counters are reduced.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
+
+
+def algorithmic_bytes(dims, ia):
+    """Algorithmic HBM bytes of ONE solve launch (fp64 values only; shared index arrays excluded),
+    SURVEY.md 8(d) formula with the measured counters of every instance."""
+    n, p, m = dims["n"], dims["p"], dims["m"]
+    N, nnzK, nnzL = dims["dim_K"], dims["nnzK"], dims["nnzL"]
+    nnzAG = dims["nnzA"] + dims["nnzG"]
+    f = ia["n_factor"].astype(np.float64).sum()
+    r = ia["n_ldlsolve"].astype(np.float64).sum()
+    it = (ia["iter"].astype(np.float64) + 1).sum()
+    per_factor = nnzK + nnzL + N                 # read K values, write L and D
+    per_solve = 2 * nnzL + 3 * N                 # L forward + L backward, D, rhs in / x out
+    per_resid = 2 * nnzAG + 4 * N                # refinement residual: A,A',G,G' values + vectors
+    per_iter = 2 * nnzAG + 6 * (n + p + 2 * m) + 30 * m + 6 * (n + p)  # residuals, scalings, RHS, line searches
+    return 8.0 * (f * per_factor + r * (per_solve + per_resid) + it * per_iter)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--pattern", default="MPC02", help="fixture name under tests/golden")
+    ap.add_argument("--soc", action="store_true", help="MPC-SOC variant (332 cones of dim 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import eicos_amd
+    from eicos_amd.generate import SEED, feasible_batch, mpc_soc_variant
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pat, sets = eicos_amd.read_epb(os.path.join(ROOT, "tests", "golden", args.pattern + ".epb"))
+    if args.soc:
+        pat = mpc_soc_variant(pat)
+    B = args.batch
+    first = rank * B  # weak scaling: every rank owns instances [rank*B, (rank+1)*B)
+    data = feasible_batch(pat, sets[0], first, B, SEED)
+    dev = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in data.items()}
+    ptr = lambda k: dev[k].data_ptr() if dev[k].numel() else 0
+
+    solver = eicos_amd.BatchSolver(pat, B, device=local_rank)
+    dims = solver.dims()
+
+    def step():
+        solver.update_device(ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))
+        solver.solve_async()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        solver.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-launch kernel duration from HIP events recorded on the solver's own stream
+        kernel_ms.append(solver.last_solve_ms())
+    fence()
+    dt = time.perf_counter() - t0
+
+    ia = solver.info_arrays()
+    iters = int(ia["iter"].sum())
+    ok = int((ia["exitcode"] == 0).sum())
+    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    cnt = torch.tensor([iters, ok, B], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    dt_max = float(t.item())
+    tot_iters, tot_ok, tot_B = (int(v) for v in cnt.tolist())
+
+    if rank == 0:
+        ms_step = dt_max / args.steps * 1e3
+        value = tot_iters * args.steps / dt_max
+        k_ms = float(np.mean(kernel_ms))
+        abytes = algorithmic_bytes(dims, ia)
+        achieved = abytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ipm_iterations_per_sec", "value": value, "unit": "iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU x {world} GPU, {args.pattern}{'-SOC' if args.soc else ''} pattern "
+                                   f"(n={dims['n']} m={dims['m']} p={dims['p']} cones={dims['ncones']}), strictly feasible "
+                                   f"generated (c,h,b), updateData+solve per step",
+                       "batch_per_gpu": B, "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"],
+                       "levels": dims["nlevels"], "mean_iter": float(ia["iter"].mean()),
+                       "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
+                       "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B,
+                       "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
+        }
+        if not args.no_cpu_baseline:
+            # CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload
+            from oracle import oracle as orc
+            cores = len(os.sched_getaffinity(0))
+            ns = int(min(B, max(64, 24 * cores)))
+            r = orc.batch_solve(pat, data["Gpr"][:ns], data["Apr"][:ns], data["c"][:ns], data["h"][:ns], data["b"][:ns], cores)
+            wall = r["seconds"] + r["update_seconds"]
+            out["cpu_baseline"] = {"value": float(r["iters"].sum() / wall), "unit": "iter/s", "cores": cores,
+                                   "kind": "port", "sample": f"first {ns} instances of the same batch, one instance per "
+                                   f"thread at a time (updateData+solve), {wall:.2f}s wall",
+                                   "iters_match_gpu": bool(np.array_equal(r["iters"], ia["iter"][:ns])),
+                                   "per_core": float(r["iters"].sum() / wall / cores)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,242 @@
+// include/eicos.hpp -- drop-in re-creation of the reference's public C++ surface
+// (reference include/eicos.hpp:8-73,137-163) on top of the MI355X C ABI (eicos_amd.h).
+//
+//   EiCOS::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)   raw ctor     (ref :151-154)
+//   updateData(Gpr,Apr,c,h,b)                                        raw update   (ref :155-156)
+//   solve(verbose) / solution() / getInfo() / getSettings()                       (ref :158-163)
+//   + the Eigen-typed ctor/updateData (ref :138-148) when <Eigen/Sparse> is available.
+//
+// One Solver = one pattern + ONE instance on the GPU (batch = 1 of the batched engine);
+// EiCOS::BatchSolver below exposes the batched updateData path the hardware is built for.
+// Header-only; link with libeicos_amd.so.  Errors of the C ABI surface as exitcode::fatal
+// from solve() (the reference has no exceptions by design) or std::runtime_error from ctors.
+#pragma once
+
+#include <cstddef>
+#include <cstdio>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "eicos_amd.h"
+
+#if __has_include(<Eigen/Sparse>)
+#include <Eigen/Sparse>
+#define EICOS_HAVE_EIGEN 1
+#endif
+
+namespace EiCOS
+{
+
+    enum class exitcode // values of reference include/eicos.hpp:8-21
+    {
+        optimal = 0,
+        primal_infeasible = 1,
+        dual_infeasible = 2,
+        maxit = -1,
+        numerics = -2,
+        outcone = -3,
+        fatal = -7,
+        close_to_optimal = 10,
+        close_to_primal_infeasible = 11,
+        close_to_dual_infeasible = 12,
+        not_converged_yet = -87
+    };
+
+    struct Settings // reference include/eicos.hpp:23-47; all but `verbose` are compile-time
+    {               // constants of the GPU kernels (eicos_amd/csrc/kernels.hip)
+        const double gamma = 0.99;
+        const double delta = 2e-7;
+        const double deltastat = 7e-8;
+        const double eps = 1e13;
+        const double feastol = 1e-8;
+        const double abstol = 1e-8;
+        const double reltol = 1e-8;
+        const double feastol_inacc = 1e-4;
+        const double abstol_inacc = 5e-5;
+        const double reltol_inacc = 5e-5;
+        const size_t nitref = 9;
+        const size_t maxit = 100;
+        bool verbose = false;
+        const double linsysacc = 1e-14;
+        const double irerrfact = 6;
+        const double stepmin = 1e-6;
+        const double stepmax = 0.999;
+        const double sigmamin = 1e-4;
+        const double sigmamax = 1.;
+        const size_t equil_iters = 3;
+        const size_t iter_max = 100;
+        const size_t safeguard = 500;
+    };
+
+    struct Information // reference include/eicos.hpp:49-73
+    {
+        double pcost = 0, dcost = 0, pres = 0, dres = 0;
+        bool pinf = false, dinf = false;
+        std::optional<double> pinfres, dinfres;
+        double gap = 0;
+        std::optional<double> relgap;
+        double sigma = 0, mu = 0, step = 0, step_aff = 0, kapovert = 0;
+        size_t iter = 0, iter_max = 100, nitref1 = 0, nitref2 = 0, nitref3 = 0;
+
+        static Information from(const eicos_info &i)
+        {
+            Information o;
+            o.pcost = i.pcost; o.dcost = i.dcost; o.pres = i.pres; o.dres = i.dres;
+            o.pinf = i.pinf != 0; o.dinf = i.dinf != 0;
+            if (i.has_pinfres) o.pinfres = i.pinfres;
+            if (i.has_dinfres) o.dinfres = i.dinfres;
+            o.gap = i.gap;
+            if (i.has_relgap) o.relgap = i.relgap;
+            o.sigma = i.sigma; o.mu = i.mu; o.step = i.step; o.step_aff = i.step_aff; o.kapovert = i.kapovert;
+            o.iter = (size_t)i.iter; o.nitref1 = (size_t)i.nitref1; o.nitref2 = (size_t)i.nitref2; o.nitref3 = (size_t)i.nitref3;
+            return o;
+        }
+    };
+
+    namespace detail
+    {
+        inline void check(int rc, const char *what)
+        {
+            if (rc != EICOS_OK) throw std::runtime_error(std::string(what) + ": " + eicos_last_error());
+        }
+    }
+
+    // Batched engine: one pattern, `batch` instances.  Arrays are [batch][...] row-major.
+    class BatchSolver
+    {
+    public:
+        BatchSolver(int n, int m, int p, int ncones, const int *q,
+                    const int *Gjc, const int *Gir, const int *Ajc, const int *Air, int batch, int device = -1)
+            : n_(n), m_(m), p_(p), batch_(batch)
+        {
+            detail::check(eicos_batch_create(n, m, p, 0, ncones, q, Gjc, Gir, Ajc, Air, batch, device, &h_), "eicos_batch_create");
+            eicos_dims d; eicos_batch_dims(h_, &d);
+            n_ = d.n; m_ = d.m; p_ = d.p;
+        }
+        BatchSolver(const BatchSolver &) = delete;
+        BatchSolver &operator=(const BatchSolver &) = delete;
+        ~BatchSolver() { eicos_batch_destroy(h_); }
+
+        void updateData(const double *Gpr, const double *Apr, const double *c, const double *h, const double *b,
+                        int first = 0, int count = -1)
+        {
+            detail::check(eicos_batch_update(h_, first, count < 0 ? batch_ : count, Gpr, Apr, c, h, b), "eicos_batch_update");
+        }
+        std::vector<exitcode> solve()
+        {
+            std::vector<int> codes(batch_);
+            detail::check(eicos_batch_solve(h_, codes.data()), "eicos_batch_solve");
+            std::vector<exitcode> out(batch_);
+            for (int i = 0; i < batch_; i++) out[i] = static_cast<exitcode>(codes[i]);
+            return out;
+        }
+        std::vector<double> solution() const
+        {
+            std::vector<double> x((size_t)batch_ * n_);
+            if (n_ > 0) detail::check(eicos_batch_solution(h_, x.data()), "eicos_batch_solution");
+            return x;
+        }
+        std::vector<Information> getInfo() const
+        {
+            std::vector<eicos_info> raw(batch_);
+            detail::check(eicos_batch_info(h_, raw.data()), "eicos_batch_info");
+            std::vector<Information> out;
+            for (auto &r : raw) out.push_back(Information::from(r));
+            return out;
+        }
+        int batch() const { return batch_; }
+        int n_var() const { return n_; }
+        eicos_batch *handle() const { return h_; }
+
+    private:
+        eicos_batch *h_ = nullptr;
+        int n_, m_, p_, batch_;
+    };
+
+    class Solver
+    {
+    public:
+        // traditional interface (reference include/eicos.hpp:151-154); `l` is ignored as in the
+        // reference (src/eicos.cpp:91); NULL groups are allowed (src/eicos.cpp:103-117)
+        Solver(int n, int m, int p, int /*l*/, int ncones, int *q,
+               double *Gpr, int *Gjc, int *Gir,
+               double *Apr, int *Ajc, int *Air,
+               double *c, double *h, double *b)
+        {
+            const bool haveG = Gpr && Gjc && Gir, haveA = Apr && Ajc && Air;
+            if (!c) n = 0;
+            detail::check(eicos_batch_create(n, haveG ? m : 0, haveA ? p : 0, 0, haveG ? ncones : 0, q,
+                                             haveG ? Gjc : nullptr, haveG ? Gir : nullptr,
+                                             haveA ? Ajc : nullptr, haveA ? Air : nullptr, 1, -1, &h_),
+                          "eicos_batch_create");
+            eicos_dims d; eicos_batch_dims(h_, &d);
+            x_.assign(d.n, 0.0);
+            // first data set: every group that exists must be supplied
+            static double dummy = 0.0;
+            detail::check(eicos_batch_update(h_, 0, 1, haveG ? Gpr : nullptr, haveA ? Apr : nullptr,
+                                             d.n ? c : &dummy, haveG ? h : nullptr, haveA ? b : nullptr),
+                          "eicos_batch_update");
+        }
+        Solver(const Solver &) = delete;
+        Solver &operator=(const Solver &) = delete;
+        ~Solver() { eicos_batch_destroy(h_); }
+
+        // reference include/eicos.hpp:155-156 : NULL = keep; h is read only with Gpr, b only with Apr
+        void updateData(double *Gpr, double *Apr, double *c, double *h, double *b)
+        {
+            detail::check(eicos_batch_update(h_, 0, 1, Gpr, Apr, c, h, b), "eicos_batch_update");
+        }
+
+#ifdef EICOS_HAVE_EIGEN
+        // Eigen-typed surface (reference include/eicos.hpp:138-148).  Inputs are copied.
+        Solver(const Eigen::SparseMatrix<double> &G, const Eigen::SparseMatrix<double> &A,
+               const Eigen::VectorXd &c, const Eigen::VectorXd &h, const Eigen::VectorXd &b,
+               const Eigen::VectorXi &soc_dims)
+            : Solver(int(c.size()), int(G.rows()), int(A.rows()), 0, int(soc_dims.size()),
+                     const_cast<int *>(soc_dims.data()),
+                     const_cast<double *>(G.valuePtr()), const_cast<int *>(G.outerIndexPtr()), const_cast<int *>(G.innerIndexPtr()),
+                     A.rows() ? const_cast<double *>(A.valuePtr()) : nullptr,
+                     A.rows() ? const_cast<int *>(A.outerIndexPtr()) : nullptr,
+                     A.rows() ? const_cast<int *>(A.innerIndexPtr()) : nullptr,
+                     const_cast<double *>(c.data()), const_cast<double *>(h.data()), const_cast<double *>(b.data())) {}
+        void updateData(const Eigen::SparseMatrix<double> &G, const Eigen::SparseMatrix<double> &A,
+                        const Eigen::VectorXd &c, const Eigen::VectorXd &h, const Eigen::VectorXd &b)
+        {
+            updateData(const_cast<double *>(G.valuePtr()), A.rows() ? const_cast<double *>(A.valuePtr()) : nullptr,
+                       const_cast<double *>(c.data()), const_cast<double *>(h.data()), const_cast<double *>(b.data()));
+        }
+#endif
+
+        exitcode solve(bool verbose = false) // reference include/eicos.hpp:158
+        {
+            settings_.verbose = verbose;
+            int code = EICOS_FATAL;
+            if (eicos_batch_solve(h_, &code) != EICOS_OK) return exitcode::fatal;
+            eicos_info raw;
+            if (eicos_batch_info(h_, &raw) != EICOS_OK) return exitcode::fatal;
+            info_ = Information::from(raw);
+            if (!x_.empty()) eicos_batch_solution(h_, x_.data());
+            if (verbose)
+                std::printf("EiCOS(MI355X): exit %d after %d iterations, pcost %.9g dcost %.9g pres %.1e dres %.1e gap %.1e\n",
+                            code, raw.iter, raw.pcost, raw.dcost, raw.pres, raw.dres, raw.gap);
+            return static_cast<exitcode>(code);
+        }
+
+        // reference returns const Eigen::VectorXd& (include/eicos.hpp:160); without Eigen a std::vector
+        const std::vector<double> &solution() const { return x_; }
+#ifdef EICOS_HAVE_EIGEN
+        Eigen::Map<const Eigen::VectorXd> solutionEigen() const { return {x_.data(), Eigen::Index(x_.size())}; }
+#endif
+        Settings &getSettings() { return settings_; }
+        const Information &getInfo() const { return info_; }
+
+    private:
+        eicos_batch *h_ = nullptr;
+        Settings settings_;
+        Information info_;
+        std::vector<double> x_;
+    };
+
+} // namespace EiCOS

