@@ -36,14 +36,16 @@ class Dims(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("n", "m", "p", "l", "ncones", "dim_K", "nnzA", "nnzG", "nnzK", "nnzL",
                                        "nlevels", "order_mode", "batch", "device")] + \
                [("factor_pairs", C.c_longlong), ("inst_bytes", C.c_size_t), ("work_bytes", C.c_size_t),
-                ("pattern_bytes", C.c_size_t), ("threads_per_block", C.c_int), ("resident_blocks", C.c_int)]
+                ("pattern_bytes", C.c_size_t), ("threads_per_block", C.c_int), ("resident_blocks", C.c_int),
+                ("lds_bytes", C.c_int), ("pad_", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libeicos_amd.so")
+    # EICOS_AMD_LIB: alternative build of the same library (used by tuning sweeps only)
+    return os.environ.get("EICOS_AMD_LIB") or os.path.join(_HERE, "libeicos_amd.so")
 
 
 def build_library(force: bool = False) -> str:
@@ -81,6 +83,7 @@ def _lib():
         L.eicos_batch_destroy.argtypes = [vp]
         L.eicos_debug_factor.argtypes = [vp, C.c_int, dp, dp]
         L.eicos_debug_pattern.argtypes = [vp, ip, ip, ip]
+        L.eicos_debug_trace.argtypes = [vp, C.c_int, dp]
         L.eicos_debug_host_check.restype = C.c_double
         L.eicos_debug_host_check.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
         for f in ("create", "update", "update_device", "solve", "solve_async", "sync", "solution", "duals", "info",
@@ -209,6 +212,14 @@ class BatchSolver:
         D, U = np.zeros(max(d["dim_K"], 1)), np.zeros(max(d["nnzL"], 1))
         _chk(_lib().eicos_debug_factor(self._h, inst, _dp(D), _dp(U)))
         return D[: d["dim_K"]], U[: d["nnzL"]]
+
+    TRACE_COLS = ("pcost", "dcost", "gap", "pres", "dres", "kapovert", "mu", "step", "sigma", "tau", "kap", "nitref3")
+
+    def debug_trace(self, inst: int = 0, iters: int | None = None):
+        """Per-iteration history [iters+1, 12] of instance `inst` (needs batch <= resident workgroups)."""
+        out = np.zeros((102, 12))
+        _chk(_lib().eicos_debug_trace(self._h, inst, _dp(out)))
+        return out if iters is None else out[: iters + 1]
 
     def debug_pattern(self):
         d = self.dims()

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -33,6 +34,8 @@ struct eicos_batch {
     DevPat dp{};
     int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
     int *d_pattern = nullptr;
+    DevPat *d_devpat = nullptr;
+    size_t dyn_lds = 0;
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -130,6 +133,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
     D.w_xk = Wl.add(S.N); D.w_ek = Wl.add(S.N); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
     D.w_U = Wl.add(S.nnzL); D.w_Ur = Wl.add(S.nnzL); D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N);
+    D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
     D.work_stride = Wl.size;
 
     // ---- pattern arrays ----
@@ -206,10 +210,17 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     HIP_TRY_H(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY_H(hipGetDeviceProperties(&prop, device));
-    h->threads = 256;
+    // launch shape: env overrides are for experiments (bench sweeps); defaults chosen from measurements
+    auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
+    h->threads = env_int("EICOS_THREADS", 256) == 512 ? 512 : 256;
+    const size_t ws_bytes = (size_t)S.N * sizeof(double);
+    const bool ws_lds = env_int("EICOS_WS_LDS", 1) != 0 && ws_bytes > 0 && ws_bytes <= 96 * 1024;
+    h->dyn_lds = ws_lds ? ((ws_bytes + 15) & ~(size_t)15) : 0;
+    HIP_TRY_H(solve_set_max_lds(h->threads, h->dyn_lds));
     int bpc = 1;
-    HIP_TRY_H(solve_occupancy(h->threads, &bpc));
+    HIP_TRY_H(solve_occupancy(h->threads, h->dyn_lds, &bpc));
     bpc = std::max(1, std::min(bpc, 8));
+    bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min(batch, resident);
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
@@ -217,6 +228,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
     HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
     for (auto &s : slots) *s.dst = h->d_pattern + s.off;
+    HIP_TRY_H(hipMalloc(&h->d_devpat, sizeof(DevPat)));
+    HIP_TRY_H(hipMemcpy(h->d_devpat, &h->dp, sizeof(DevPat), hipMemcpyHostToDevice));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
@@ -237,6 +250,7 @@ int eicos_batch_destroy(eicos_batch *h) {
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
     for (hipEvent_t e : {h->ev_s0, h->ev_s1, h->ev_u0, h->ev_u1}) if (e) (void)hipEventDestroy(e);
     if (h->d_pattern) (void)hipFree(h->d_pattern);
+    if (h->d_devpat) (void)hipFree(h->d_devpat);
     if (h->d_inst) (void)hipFree(h->d_inst);
     if (h->d_work) (void)hipFree(h->d_work);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
@@ -258,7 +272,7 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
-    HIP_TRY(launch_update(h->dp, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
+    HIP_TRY(launch_update(h->d_devpat, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
     HIP_TRY(hipEventRecord(h->ev_u1, h->stream));
     h->update_timed = true;
     return EICOS_OK;
@@ -303,7 +317,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->dp, h->d_inst, h->d_work, h->batch, h->grid, h->threads, h->stream));
+    HIP_TRY(launch_solve(h->d_devpat, h->d_inst, h->d_work, h->batch, h->grid, h->threads, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;
@@ -388,7 +402,7 @@ int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     o->factor_pairs = S.npairs;
     o->inst_bytes = h->dp.inst_stride * sizeof(double); o->work_bytes = h->dp.work_stride * sizeof(double);
     o->pattern_bytes = h->pattern_ints * sizeof(int);
-    o->threads_per_block = h->threads; o->resident_blocks = h->grid;
+    o->threads_per_block = h->threads; o->resident_blocks = h->grid; o->lds_bytes = (int)h->dyn_lds;
     return EICOS_OK;
 }
 
@@ -407,10 +421,20 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(launch_debug_factor(h->dp, h->d_inst, h->d_work, inst, h->stream));
+    HIP_TRY(launch_debug_factor(h->d_devpat, h->d_inst, h->d_work, inst, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->dp.N * sizeof(double), hipMemcpyDeviceToHost));
     if (Uout) HIP_TRY(hipMemcpy(Uout, h->d_work + h->dp.w_U, (size_t)h->dp.nnzL * sizeof(double), hipMemcpyDeviceToHost));
+    return EICOS_OK;
+}
+
+int eicos_debug_trace(eicos_batch *h, int inst, double *out) {
+    if (!h || !out || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
+    if (h->batch > h->grid) return fail(EICOS_E_INVALID, "trace is per workspace slot: needs batch <= resident workgroups");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)inst * h->dp.work_stride + h->dp.w_trace,
+                      (size_t)TRACE_ROWS * TRACE_COLS * sizeof(double), hipMemcpyDeviceToHost));
     return EICOS_OK;
 }
 

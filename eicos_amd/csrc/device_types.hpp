@@ -39,10 +39,11 @@ struct DevPat {
     // workspace slab offsets
     int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
-    int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_ws, w_U, w_Ur, w_D, w_invD;
+    int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_ws, w_U, w_Ur, w_D, w_invD, w_trace;
     size_t inst_stride, work_stride; // in doubles
 };
 
+constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
 constexpr int LONG_SEG = 48;       // segments longer than this are reduced by a whole wavefront
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each
 constexpr int CSC_STRIDE = 20;     // doubles of scaling state per cone

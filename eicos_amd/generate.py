@@ -63,7 +63,7 @@ def perturbed_batch(pat: Pattern, base: Values, first: int, count: int, seed: in
     return dict(Gpr=rep(base.Gpr, pat.nnzG), Apr=rep(base.Apr, pat.nnzA), c=c, h=h, b=rep(base.b, pat.p))
 
 
-def mpc_soc_variant(pat: Pattern, base: Values, rows_from: int = 3000, dim: int = 3):
+def mpc_soc_variant(pat: Pattern, base: Values = None, rows_from: int = 3000, dim: int = 3):
     """'MPC-SOC' pattern: rows >= rows_from of an LP-only pattern are
     regrouped, in order, into second-order cones of size `dim` (row order unchanged)."""
     assert pat.ncones == 0 and (pat.m - rows_from) % dim == 0

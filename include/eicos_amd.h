@@ -60,6 +60,8 @@ typedef struct eicos_dims {
     long long factor_pairs;      /* multiply-subtract pairs of one numeric factorisation */
     size_t inst_bytes, work_bytes, pattern_bytes;
     int threads_per_block, resident_blocks;
+    int lds_bytes; /* dynamic LDS per workgroup (solve vector staged in LDS), 0 if in HBM */
+    int pad_;
 } eicos_dims;
 
 /* ---- construction: replaces Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)
@@ -118,6 +120,9 @@ int eicos_device_count(void);
 /* Debug/parity hooks (tests only): numeric LDL' of instance `inst` with the KKT values as they
  * stand, and one LDL' solve. Host buffers. */
 int eicos_debug_factor(eicos_batch *hd, int inst, double *D /*[dim_K], permuted*/, double *U /*[nnzL] CSC, permuted*/);
+/* per-iteration history of instance `inst` in the last solve: out[102][12] = {pcost,dcost,gap,pres,dres,
+ * kap/tau,mu,step,sigma,tau,kap,nitref3} per IPM pass (valid while batch <= resident workgroups). */
+int eicos_debug_trace(eicos_batch *hd, int inst, double *out);
 int eicos_debug_pattern(eicos_batch *hd, int *perm /*[dim_K]*/, int *Lp /*[dim_K+1]*/, int *Li /*[nnzL]*/);
 
 /* Host-only self check of the symbolic analysis + factor/solve programs (no GPU needed):

@@ -24,10 +24,12 @@
 #include "eicos_oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -264,6 +266,8 @@ struct Solver {
     ivec slotV;  /* K positions of the scaling entries, order of ref cacheIndices :1944-1987 */
     Ldl ldl;
     int n_factor = 0, n_ldlsolve = 0, last_exit = EX_FATAL;
+    std::vector<std::array<double, 12>> history; /* one row per pass of the main loop */
+    bool trace = std::getenv("ORACLE_TRACE") != nullptr; /* per-iteration table like the reference's verbose mode (ref :733-753) */
 
     /* ---------- construction: ref build() src/eicos.cpp:132-187 ---------- */
     void build(int n_, int m_, int p_, int ncones, const int *q,
@@ -766,7 +770,7 @@ struct Solver {
     /* ---------- ref solve src/eicos.cpp:848-1262 ---------- */
     int solve() {
         int code = EX_FATAL;
-        n_factor = 0; n_ldlsolve = 0;
+        n_factor = 0; n_ldlsolve = 0; history.clear();
         reset_kkt_scalings();
         /* rhs1 = [0; b; h expanded], rhs2 = [-c; 0; 0]   (ref :865-886) */
         std::fill(rhs1.begin(), rhs1.end(), 0.0);
@@ -795,6 +799,11 @@ struct Solver {
         for (w.i.iter = 0; w.i.iter <= ITER_MAX; w.i.iter++) {
             compute_residuals();
             update_statistics();
+            history.push_back({w.i.pcost, w.i.dcost, w.i.gap, w.i.pres, w.i.dres, w.i.kapovert, w.i.mu, w.i.step,
+                               w.i.sigma, w.tau, w.kap, (double)w.i.nitref3});
+            if (trace)
+                std::printf("[oracle] it %2d pcost %+.6e dcost %+.6e gap %+.2e pres %.2e dres %.2e k/t %.2e mu %.2e step %.4f sigma %.2e tau %.3e kap %.3e\n",
+                            w.i.iter, w.i.pcost, w.i.dcost, w.i.gap, w.i.pres, w.i.dres, w.i.kapovert, w.i.mu, w.i.step, w.i.sigma, w.tau, w.kap);
             /* safeguard, ref :1010-1041 */
             if (w.i.iter > 0 && (w.i.pres > SAFEGUARD * pres_prev || w.i.gap < 0.)) {
                 w = wbest;
@@ -904,6 +913,12 @@ void oracle_get_dims(void *s, int *dimK, int *nnzK, int *nnzL) {
     if (dimK) *dimK = S->N;
     if (nnzK) *nnzK = S->K.nnz();
     if (nnzL) *nnzL = S->ldl.Lp.empty() ? 0 : S->ldl.Lp[S->N];
+}
+int oracle_get_trace(void *s, double *out, int max_rows) {
+    Solver *S = static_cast<Solver *>(s);
+    const int rows = std::min<int>(max_rows, (int)S->history.size());
+    for (int r = 0; r < rows; r++) std::copy(S->history[r].begin(), S->history[r].end(), out + 12 * r);
+    return (int)S->history.size();
 }
 void oracle_destroy(void *s) { delete static_cast<Solver *>(s); }
 

@@ -43,6 +43,9 @@ void oracle_get_info(void *s, oracle_info *out);
 void oracle_get_x(void *s, double *x);
 void oracle_get_yzs(void *s, double *y, double *z, double *sl);
 void oracle_get_dims(void *s, int *dimK, int *nnzK, int *nnzL);
+/* per-iteration history of the last solve: rows of {pcost,dcost,gap,pres,dres,kap/tau,mu,step,sigma,tau,kap,nitref3};
+ * returns the number of rows available */
+int oracle_get_trace(void *s, double *out, int max_rows);
 void oracle_destroy(void *s);
 
 /* CPU-baseline driver: solve `batch` instances that share one pattern, one instance at a

@@ -49,6 +49,8 @@ def lib():
         L.oracle_get_yzs.argtypes = [C.c_void_p, dp, dp, dp]
         L.oracle_get_dims.argtypes = [C.c_void_p, ip, ip, ip]
         L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_get_trace.argtypes = [C.c_void_p, dp, C.c_int]
+        L.oracle_get_trace.restype = C.c_int
         L.oracle_batch_solve.restype = C.c_double
         L.oracle_batch_solve.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_int] + [dp] * 5 + [C.c_int, ip, ip, dp, dp, dp,
                                                                                   C.POINTER(C.c_longlong)]
@@ -110,6 +112,11 @@ class OracleSolver:
         y, z, s = np.zeros(max(self.pat.p, 1)), np.zeros(max(self.pat.m, 1)), np.zeros(max(self.pat.m, 1))
         lib().oracle_get_yzs(self._h, _dp(y), _dp(z), _dp(s))
         return y[: self.pat.p], z[: self.pat.m], s[: self.pat.m]
+
+    def trace(self):
+        out = np.zeros((102, 12))
+        n = lib().oracle_get_trace(self._h, _dp(out), 102)
+        return out[:n]
 
     def dims(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

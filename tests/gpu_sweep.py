@@ -1,0 +1,20 @@
+"""Dev script (not a pytest file): time the batched solve for the current library / env knobs."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eicos_amd import read_epb, BatchSolver
+from eicos_amd.generate import feasible_batch
+name = sys.argv[1] if len(sys.argv) > 1 else "MPC02"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+pat, sets = read_epb(f'tests/golden/{name}.epb')
+d = feasible_batch(pat, sets[0], 0, min(B, 256))
+tile = lambda a: np.tile(a, ((B + a.shape[0] - 1) // a.shape[0], 1))[:B]
+g = BatchSolver(pat, B)
+g.update(tile(d['Gpr']), tile(d['Apr']), tile(d['c']), tile(d['h']), tile(d['b']))
+ms = []
+for r in range(reps):
+    codes = g.solve(); ms.append(g.last_solve_ms())
+ia = g.info_arrays(); dm = g.dims()
+tag = f"lib={os.path.basename(os.environ.get('EICOS_AMD_LIB','default'))} T={dm['threads_per_block']} lds={dm['lds_bytes']} resident={dm['resident_blocks']}"
+print(f"{name} B={B} {tag}: ms={min(ms):.2f} (all {['%.1f'%m for m in ms]}) iters={ia['iter'].sum()} ok={(codes==0).sum()} -> {ia['iter'].sum()/min(ms)*1e3:.0f} iter/s  pcost0={ia['pcost'][0]:.10e}", flush=True)
