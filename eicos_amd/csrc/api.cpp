@@ -3,13 +3,14 @@
 // with EICOS_E_NOGPU.
 #include "../../include/eicos_amd.h"
 
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -17,10 +18,13 @@
 #include "device_types.hpp"
 #include "launch.hpp"
 #include "symbolic.hpp"
+#include "plans.hpp"
 
 using namespace eicos;
 
 static thread_local std::string g_err;
+static std::mutex g_slot_mu;
+static bool g_slot_used[16][64];
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -34,14 +38,16 @@ struct eicos_batch {
     DevPat dp{};
     int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
     int *d_pattern = nullptr;
-    DevPat *d_devpat = nullptr;
+    int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
     size_t dyn_lds = 0;
+    int nlds = 0;
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
     bool solve_timed = false, update_timed = false;
     int64_t npairs = 0;
+    std::vector<int> posB; // CSC entry of L -> slot in the backward value array
 };
 
 namespace {
@@ -116,6 +122,11 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = S.N; D.mt = S.mt; D.nV = S.nV;
     D.nnzA = S.nnzA; D.nnzG = S.nnzG; D.nnzL = S.nnzL; D.nlev = S.nlev;
 
+    auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
+    {
+        const int t = env_int("EICOS_THREADS", 512);
+        h->threads = (t == 256 || t == 1024) ? t : 512;
+    }
     // ---- slab layouts ----
     SlabLayout L;
     D.i_Av = L.add(S.nnzA); D.i_Gv = L.add(S.nnzG); D.i_Atv = L.add(S.nnzA); D.i_Gtv = L.add(S.nnzG);
@@ -132,9 +143,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
     D.w_xk = Wl.add(S.N); D.w_ek = Wl.add(S.N); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
-    D.w_U = Wl.add(S.nnzL); D.w_Ur = Wl.add(S.nnzL); D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N);
+    D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N); // w_UF / w_UB are added once the slice plans are known
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
-    D.work_stride = Wl.size;
 
     // ---- pattern arrays ----
     IntPool pool;
@@ -158,16 +168,10 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         if ((P.Ajc[j + 1] - P.Ajc[j]) + (P.Gjc[j + 1] - P.Gjc[j]) > LONG_SEG) AG_long.push_back(j);
     for (int r = 0; r < S.p; r++) if (S.At_ptr[r + 1] - S.At_ptr[r] > LONG_SEG) At_long.push_back(r);
     for (int r = 0; r < S.m; r++) if (S.Gt_ptr[r + 1] - S.Gt_ptr[r] > LONG_SEG) Gt_long.push_back(r);
-    std::vector<int> fwd_long_ptr(S.nlev + 1, 0), fwd_long, bwd_long_ptr(S.nlev + 1, 0), bwd_long, ftask_nlong(S.nlev, 0);
-    for (int v = 0; v < S.nlev; v++) {
-        for (int i = S.lev_ptr[v]; i < S.lev_ptr[v + 1]; i++) {
-            if (S.Rp[i + 1] - S.Rp[i] > LONG_SEG) fwd_long.push_back(i);
-            if (S.Lp[i + 1] - S.Lp[i] > LONG_SEG) bwd_long.push_back(i);
-        }
-        fwd_long_ptr[v + 1] = (int)fwd_long.size(); bwd_long_ptr[v + 1] = (int)bwd_long.size();
+    std::vector<int> ftask_nlong(S.nlev, 0);
+    for (int v = 0; v < S.nlev; v++)
         for (int t = S.ftask_ptr[v]; t < S.ftask_ptr[v + 1]; t++)
             if (S.tp[S.ftask[t] + 1] - S.tp[S.ftask[t]] > LONG_SEG) ftask_nlong[v]++;
-    }
     std::vector<int> tp32(S.tp.size());
     for (size_t i = 0; i < S.tp.size(); i++) tp32[i] = (int)S.tp[i];
     auto srcoff = [&](int kind, int src) {
@@ -184,6 +188,23 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     for (int e = 0; e < S.nnzL; e++) Lsrc[e] = srcoff(S.Lkind[e], S.Lsrc[e]);
     for (int j = 0; j < S.N; j++) Dsrc[j] = srcoff(S.Dkind[j], S.Dsrc[j]);
 
+
+    // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
+    TriPlan planF = build_tri_plan(S, h->threads, true), planB = build_tri_plan(S, h->threads, false);
+    D.nfs = (int)planF.sl.size(); D.nbs = (int)planB.sl.size(); D.nUF = planF.slots; D.nUB = planB.slots;
+    D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
+    D.work_stride = Wl.size;
+    h->posB = planB.pos;
+    // the factor program reads L.*D through the backward (column) slots
+    std::vector<int> pa2(S.pa.size()), pb2(S.pb.size());
+    for (size_t i = 0; i < S.pa.size(); i++) { pa2[i] = planB.pos[S.pa[i]]; pb2[i] = planB.pos[S.pb[i]]; }
+    auto meta_ints = [](const std::vector<SliceMeta> &v) {
+        std::vector<int> o(v.size() * 8);
+        if (!v.empty()) std::memcpy(o.data(), v.data(), o.size() * sizeof(int));
+        return o;
+    };
+    std::vector<int> fsl_i = meta_ints(planF.sl), bsl_i = meta_ints(planB.sl);
+
     struct Slot { const int **dst; size_t off; };
     std::vector<Slot> slots;
     auto put = [&](const int *&field, const std::vector<int> &v) { slots.push_back({&field, pool.add(v)}); };
@@ -195,10 +216,12 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(D.cq, S.q); put(D.cone_off, S.cone_off); put(D.cone_vbase, cone_vbase); put(D.cone_small, cone_small); put(D.cone_big, cone_big);
     D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
     put(D.zexp, zexp); put(D.zdsign, zdsign);
-    put(D.perm, S.perm); put(D.lev_ptr, S.lev_ptr); put(D.Rp, S.Rp); put(D.Rj, S.Rj); put(D.Lp, S.Lp); put(D.Li, S.Li); put(D.Cpos, S.Cpos);
-    put(D.fwd_long_ptr, fwd_long_ptr); put(D.fwd_long, fwd_long); put(D.bwd_long_ptr, bwd_long_ptr); put(D.bwd_long, bwd_long);
+    put(D.perm, S.perm); put(D.lev_ptr, S.lev_ptr);
+    put(D.f_idx, planF.idx); put(D.b_idx, planB.idx); put(D.posF, planF.pos); put(D.posB, planB.pos);
+    const int *fsl_p = nullptr, *bsl_p = nullptr;
+    put(fsl_p, fsl_i); put(bsl_p, bsl_i);
     put(D.ftask_ptr, S.ftask_ptr); put(D.ftask, S.ftask); put(D.ftask_nlong, ftask_nlong); put(D.tp, tp32);
-    put(D.pa, S.pa); put(D.pb, S.pb); put(D.pk, S.pk); put(D.Lsrc, Lsrc); put(D.Dsrc, Dsrc);
+    put(D.pa, pa2); put(D.pb, pb2); put(D.pk, S.pk); put(D.Lsrc, Lsrc); put(D.Dsrc, Dsrc);
 
     // ---- device resources ----
     auto bail = [&](int code, const std::string &msg) { eicos_batch_destroy(h); return fail(code, msg); };
@@ -211,14 +234,23 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     hipDeviceProp_t prop;
     HIP_TRY_H(hipGetDeviceProperties(&prop, device));
     // launch shape: env overrides are for experiments (bench sweeps); defaults chosen from measurements
-    auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
-    h->threads = env_int("EICOS_THREADS", 256) == 512 ? 512 : 256;
-    const size_t ws_bytes = (size_t)S.N * sizeof(double);
-    const bool ws_lds = env_int("EICOS_WS_LDS", 1) != 0 && ws_bytes > 0 && ws_bytes <= 96 * 1024;
-    h->dyn_lds = ws_lds ? ((ws_bytes + 15) & ~(size_t)15) : 0;
-    HIP_TRY_H(solve_set_max_lds(h->threads, h->dyn_lds));
+    // KKT-space vectors (solve vector, current solution, refinement residual) live in LDS when they fit:
+    // 160 KiB per CU minus the static block (reductions + scalar state)
+    D.Npad = (S.N + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding
+    {
+        const size_t meta = (size_t)(D.nfs + D.nbs) * sizeof(SliceMeta);
+        const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
+        // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
+        // all-global variant (NLDS = 0, plain __syncthreads between levels) is used
+        int fit = (meta + vec <= avail) ? (int)std::min<size_t>(3, (avail - meta) / vec) : 0;
+        if (S.N == 0) fit = 0;
+        h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", fit)));
+        D.meta_lds = h->nlds >= 1 ? 1 : 0;
+        h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : 0;
+    }
+    HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dyn_lds));
     int bpc = 1;
-    HIP_TRY_H(solve_occupancy(h->threads, h->dyn_lds, &bpc));
+    HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dyn_lds, &bpc));
     bpc = std::max(1, std::min(bpc, 8));
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
     const int resident = prop.multiProcessorCount * bpc;
@@ -228,8 +260,13 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
     HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
     for (auto &s : slots) *s.dst = h->d_pattern + s.off;
-    HIP_TRY_H(hipMalloc(&h->d_devpat, sizeof(DevPat)));
-    HIP_TRY_H(hipMemcpy(h->d_devpat, &h->dp, sizeof(DevPat), hipMemcpyHostToDevice));
+    D.fsl = reinterpret_cast<const SliceMeta *>(fsl_p); D.bsl = reinterpret_cast<const SliceMeta *>(bsl_p);
+    {
+        std::lock_guard<std::mutex> lk(g_slot_mu);
+        for (int q = 0; q < max_patterns() && q < 64; q++) if (!g_slot_used[device % 16][q]) { h->pslot = q; g_slot_used[device % 16][q] = true; break; }
+    }
+    if (h->pslot < 0) return bail(EICOS_E_INVALID, "too many live handles on this device (64)");
+    HIP_TRY_H(upload_pattern(h->pslot, h->dp));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
@@ -250,7 +287,7 @@ int eicos_batch_destroy(eicos_batch *h) {
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
     for (hipEvent_t e : {h->ev_s0, h->ev_s1, h->ev_u0, h->ev_u1}) if (e) (void)hipEventDestroy(e);
     if (h->d_pattern) (void)hipFree(h->d_pattern);
-    if (h->d_devpat) (void)hipFree(h->d_devpat);
+    if (h->pslot >= 0) { std::lock_guard<std::mutex> lk(g_slot_mu); g_slot_used[h->device % 16][h->pslot] = false; }
     if (h->d_inst) (void)hipFree(h->d_inst);
     if (h->d_work) (void)hipFree(h->d_work);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
@@ -272,7 +309,7 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
-    HIP_TRY(launch_update(h->d_devpat, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
+    HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
     HIP_TRY(hipEventRecord(h->ev_u1, h->stream));
     h->update_timed = true;
     return EICOS_OK;
@@ -317,7 +354,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->d_devpat, h->d_inst, h->d_work, h->batch, h->grid, h->threads, h->dyn_lds, h->stream));
+    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->grid, h->threads, h->nlds, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;
@@ -421,10 +458,14 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(launch_debug_factor(h->d_devpat, h->d_inst, h->d_work, inst, h->stream));
+    HIP_TRY(launch_debug_factor(h->pslot, h->d_inst, h->d_work, inst, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->dp.N * sizeof(double), hipMemcpyDeviceToHost));
-    if (Uout) HIP_TRY(hipMemcpy(Uout, h->d_work + h->dp.w_U, (size_t)h->dp.nnzL * sizeof(double), hipMemcpyDeviceToHost));
+    if (Uout) {
+        std::vector<double> ub((size_t)h->dp.nUB + 1);
+        HIP_TRY(hipMemcpy(ub.data(), h->d_work + h->dp.w_UB, (size_t)h->dp.nUB * sizeof(double), hipMemcpyDeviceToHost));
+        for (int e = 0; e < h->dp.nnzL; e++) Uout[e] = ub[h->posB[e]];
+    }
     return EICOS_OK;
 }
 
@@ -491,20 +532,35 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                 if (tgt < N) { D[tgt] = Dv[tgt] - s; invD[tgt] = 1.0 / D[tgt]; }
                 else { const int e = tgt - N; U[e] = Lv[e] - s; Ur[S.Cpos[e]] = U[e]; }
             }
-        std::vector<double> rhs(N), ws(N), x(N);
+        std::vector<double> rhs(N), x(N);
         for (int i = 0; i < N; i++) rhs[i] = rnd() - 0.5;
-        for (int v = 0; v < S.nlev; v++)
-            for (int i = S.lev_ptr[v]; i < S.lev_ptr[v + 1]; i++) {
-                double s = 0;
-                for (int e = S.Rp[i]; e < S.Rp[i + 1]; e++) s += Ur[e] * ws[S.Rj[e]];
-                ws[i] = (rhs[S.perm[i]] - s) * invD[i];
-            }
-        for (int v = S.nlev - 1; v >= 0; v--)
-            for (int j = S.lev_ptr[v]; j < S.lev_ptr[v + 1]; j++) {
-                double s = 0;
-                for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) s += U[e] * ws[S.Li[e]];
-                ws[j] -= invD[j] * s; x[S.perm[j]] = ws[j];
-            }
+        // the two sweeps exactly as the kernel walks its sliced-ELL plans (lane by lane)
+        double plan_err = 0;
+        for (int T : {256, 512, 1024}) {
+            TriPlan pf = build_tri_plan(S, T, true), pb = build_tri_plan(S, T, false);
+            std::vector<double> UF(pf.slots, 0.0), UB(pb.slots, 0.0), ws(N + 1, 0.0);
+            for (int e = 0; e < S.nnzL; e++) { UF[pf.pos[e]] = U[e]; UB[pb.pos[e]] = U[e]; }
+            for (int i = 0; i < N; i++) ws[i] = rhs[S.perm[i]];
+            auto sweep = [&](const TriPlan &pl, const std::vector<double> &val, bool fwd) {
+                for (const SliceMeta &m : pl.sl) {
+                    const int g = 1 << m.lg, lanes = m.cnt * g;
+                    if (lanes > T) throw std::logic_error("slice wider than the workgroup");
+                    std::vector<double> acc(m.cnt, 0.0);
+                    for (int t = 0; t < lanes; t++)
+                        for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + t; acc[t / g] += val[slot] * ws[pl.idx[slot]]; }
+                    for (int r = 0; r < m.cnt; r++) {
+                        const int i = m.row0 + r;
+                        ws[i] = fwd ? (ws[i] - acc[r]) * invD[i] : ws[i] - invD[i] * acc[r];
+                    }
+                }
+            };
+            sweep(pf, UF, true); sweep(pb, UB, false);
+            std::vector<double> xt(N);
+            for (int j = 0; j < N; j++) xt[S.perm[j]] = ws[j];
+            if (T == 256) x = xt;
+            for (int j = 0; j < N; j++) plan_err = std::max(plan_err, std::fabs(xt[j] - x[j]));
+        }
+        if (plan_err > 1e-9) return -3.0;
         std::vector<double> r(rhs);
         for (int e = 0; e < S.nnzK; e++) {
             const int a = S.K_row[e], b = S.K_col[e];

@@ -4,6 +4,19 @@
 
 namespace eicos {
 
+// On the device every slab / pattern pointer is tagged with the global address space: pointers
+// that reach a kernel through a struct in memory (or through a non-inlined function) are
+// otherwise "generic", hipcc emits flat_load/flat_store for them, and flat accesses count on
+// BOTH vmcnt and lgkmcnt -- which couples HBM latency into every LDS wait.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EICOS_GLOBAL __attribute__((address_space(1)))
+#else
+#define EICOS_GLOBAL
+#endif
+typedef const int EICOS_GLOBAL *gint_p;
+typedef double EICOS_GLOBAL *gdbl_p;
+typedef const double EICOS_GLOBAL *gcdbl_p;
+
 // Per-instance persistent scalar state: struct Work's scalars + struct Information
 // (reference include/eicos.hpp:49-73,97-114) with std::optional flattened.
 struct DevInfo {
@@ -15,31 +28,47 @@ struct DevInfo {
 static_assert(sizeof(DevInfo) == 200, "DevInfo layout");
 constexpr int DEVINFO_DOUBLES = 32;
 
+// One slice of a sliced-ELL triangular-solve plan: `cnt` consecutive rows (or columns) of L
+// starting at node row0, each handled by g = 1<<lg adjacent lanes; lane t of the workgroup owns
+// entries q, q+g, ... of row row0 + t/g (q = t%g); entry kk of lane t sits at slot
+// off + kk*(cnt*g) + t, so every load is unit-stride across the workgroup and needs no row
+// pointer.  K = entries per lane (padding slots hold value 0 / index N).  newlev = 1 on the first
+// slice of an elimination-tree level: a workgroup barrier separates it from the previous level.
+struct SliceMeta { int row0, cnt, lg, K, off, newlev, pad0, pad1; };
+constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
+constexpr int TRI_DEPTH = 3; // ... this many slices ahead of their use (plans are padded to a multiple)
+
 // Everything the kernels need to know about the (shared) pattern.  All pointers are device
 // pointers into one int32 pattern buffer; all i_* / w_* members are offsets in doubles into
 // the per-instance slab / the per-resident-workgroup workspace slab.
 struct DevPat {
     int n, p, m, l, nc, N, mt, nV, nnzA, nnzG, nnzL, nlev;
+    int Npad; // N rounded up to 16 doubles: stride of the LDS-resident KKT-space vectors
     // A, G in CSC (column) and transposed (row) form; *_k = row index as KKT index
-    const int *Ajc, *Air, *Air_k, *At_ptr, *At_col, *At_pos;
-    const int *Gjc, *Gir, *Gir_k, *Gt_ptr, *Gt_col, *Gt_pos;
-    const int *A_long, *At_long, *G_long, *Gt_long; // columns / rows longer than LONG_SEG
+    gint_p Ajc, Air, Air_k, At_ptr, At_col, At_pos;
+    gint_p Gjc, Gir, Gir_k, Gt_ptr, Gt_col, Gt_pos;
+    gint_p A_long, At_long, G_long, Gt_long; // columns / rows longer than LONG_SEG
     int nA_long, nAt_long, nG_long, nGt_long;
     // cones
-    const int *cq, *cone_off, *cone_vbase, *cone_small, *cone_big;
+    gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;
-    const int *zexp;    // [m] expanded (rhs / KKT cone block) position of z row i
-    const int *zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
+    gint_p zexp;    // [m] expanded (rhs / KKT cone block) position of z row i
+    gint_p zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
     // LDL' pattern, level ordered
-    const int *perm, *lev_ptr, *Rp, *Rj, *Lp, *Li, *Cpos;
-    const int *fwd_long_ptr, *fwd_long, *bwd_long_ptr, *bwd_long;
-    const int *ftask_ptr, *ftask, *ftask_nlong, *tp, *pa, *pb, *pk, *Lsrc, *Dsrc;
+    gint_p perm, lev_ptr;
+    // triangular solves: sliced-ELL plans (see SliceMeta); UF/UB hold the values of L.*D in the
+    // forward (row) and backward (column) slot order, posF/posB map a CSC entry of L to its slots
+    const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
+    int nfs, nbs, nUF, nUB;
+    int meta_lds; // 1: both slice tables are staged in LDS behind the NLDS vectors
+    gint_p f_idx, b_idx, posF, posB;
+    gint_p ftask_ptr, ftask, ftask_nlong, tp, pa, pb, pk, Lsrc, Dsrc;
     // instance slab offsets
     int i_Av, i_Gv, i_Atv, i_Gtv, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets
     int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
-    int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_ws, w_U, w_Ur, w_D, w_invD, w_trace;
+    int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_ws, w_UF, w_UB, w_D, w_invD, w_trace;
     size_t inst_stride, work_stride; // in doubles
 };
 

@@ -44,9 +44,9 @@ constexpr int EX_NOT_CONVERGED = -87;
 #ifndef EICOS_WAVES_PER_EU
 #define EICOS_WAVES_PER_EU 4
 #endif
-// EICOS_WAVES_PER_EU = workgroups of 256 threads per CU the register budget is sized for
-// (__launch_bounds__ second argument is waves per SIMD; the AMDGPU attributor propagates the
-// budget to the non-inlined stage functions)
+// EICOS_WAVES_PER_EU = waves per SIMD the register budget is sized for (4 -> 128 VGPRs: one
+// 1024-thread workgroup, two of 512 or four of 256 per CU); the AMDGPU attributor propagates the
+// kernel's budget to the non-inlined stage functions
 
 constexpr int RED_SLOTS = 16 * 8; // up to 16 wavefronts x 8 values per reduction
 
@@ -56,14 +56,33 @@ enum { SV_RESX0 = 0, SV_RESY0, SV_RESZ0, SV_PRESPREV, SV_RT, SV_DTAUDEN, SV_DTAU
 enum { FL_FATAL = 0, FL_ACTION, FL_RESTORE, FL_SAVE, FL_CODE, FL_COUNT };
 enum { ACT_CONTINUE = 0, ACT_BREAK = 1 };
 
+// Pattern descriptors live in the constant address space: field loads are scalar (s_load) and
+// need no generic pointer.  One slot per live handle (eicos_batch), written at creation.
+constexpr int MAX_PATTERNS = 64;
+__constant__ DevPat c_pat[MAX_PATTERNS];
+
 struct Sh {
     double red[2 * RED_SLOTS];
     DevInfo wi, bi;
     double sv[SV_COUNT];
     int fl[FL_COUNT];
+    unsigned long long tick[8]; // per-phase time of the current solve (100 MHz ticks), thread 0
 };
+enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_INIT, TK_COUNT };
+#define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
+#define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
 __shared__ Sh g_S;
-extern __shared__ double g_dyn[]; // solve vector ws[N] when WS_LDS
+extern __shared__ double g_dyn[]; // NLDS KKT-space vectors of P.Npad doubles: ws [, xk [, ek]]
+
+// Arguments of non-inlined device functions arrive in VGPRs; the values below are workgroup-uniform,
+// so move them to SGPRs: address math and branches on them become scalar (s_load, s_cbranch) instead
+// of per-lane loads and exec-masked regions.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class Ptr> __device__ __forceinline__ Ptr uni_ptr(Ptr p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (Ptr)(((unsigned long long)hi << 32) | lo);
+}
 
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
@@ -85,7 +104,7 @@ __device__ __forceinline__ void blk_reduce(int &phase, double (&v)[NV]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; i++) v[i] = wave_reduce<Op>(v[i]);
-    double *buf = g_S.red + phase * RED_SLOTS;
+    auto buf = g_S.red + phase * RED_SLOTS;
     phase ^= 1;
     if (lane == 0) {
 #pragma unroll
@@ -109,10 +128,9 @@ __device__ __forceinline__ double blk_reduce1(int &phase, double x) {
 
 // Segmented sparse dot products over rows/columns [r0,r1): short segments one thread each,
 // long ones (listed in longlist) one wavefront each.  epi(r, sum) runs on exactly one thread.
-template <int T, class X, class Epi>
-__device__ __forceinline__ void seg_dots(int r0, int r1, const int *__restrict__ ptr, const int *__restrict__ idx,
-                                         const double *__restrict__ val, X x, const int *__restrict__ longlist,
-                                         int nlong, Epi &&epi) {
+template <int T, class V, class X, class Epi>
+__device__ __forceinline__ void seg_dots(int r0, int r1, gint_p ptr, gint_p idx, V val, X x, gint_p longlist, int nlong,
+                                         Epi &&epi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int r = r0 + tid; r < r1; r += T) {
         const int k0 = ptr[r], k1 = ptr[r + 1];
@@ -132,10 +150,10 @@ __device__ __forceinline__ void seg_dots(int r0, int r1, const int *__restrict__
 }
 
 // Column products with the stacked matrix [A; G]: s_j = sum_k A[k,j] xa[ia[k]] + sum_k G[k,j] xg[ig[k]]
-template <int T, class Epi>
-__device__ __forceinline__ void col_dots_AG(const DevPat &P, const double *__restrict__ Av, const double *__restrict__ Gv,
-                                            const int *__restrict__ ia, const int *__restrict__ ig,
-                                            const double *__restrict__ xa, const double *__restrict__ xg, Epi &&epi) {
+template <int T, class XA, class XG, class Epi>
+__device__ __forceinline__ void col_dots_AG(int ps, gcdbl_p Av, gcdbl_p Gv, gint_p ia, gint_p ig, XA xa, XG xg,
+                                            Epi &&epi) {
+    const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int j = tid; j < P.n; j += T) {
         const int a0 = P.Ajc[j], a1 = P.Ajc[j + 1], g0 = P.Gjc[j], g1 = P.Gjc[j + 1];
@@ -164,7 +182,8 @@ template <int G> __device__ __forceinline__ double grp_sum(double v) {
 // Run body(c, integral_constant<G>, lane) once per cone: small cones one thread each (G=1),
 // big cones one wavefront each (G=64).
 template <int T, class Body>
-__device__ __forceinline__ void for_cones(const DevPat &P, Body &&body) {
+__device__ __forceinline__ void for_cones(int ps, Body &&body) {
+    const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x;
     for (int q = tid; q < P.n_small; q += T) body(P.cone_small[q], std::integral_constant<int, 1>{}, 0);
     for (int q = tid >> 6; q < P.n_big; q += T / 64) body(P.cone_big[q], std::integral_constant<int, 64>{}, tid & 63);
@@ -172,16 +191,91 @@ __device__ __forceinline__ void for_cones(const DevPat &P, Body &&body) {
 
 #define FOR_T(i, cnt) for (int i = threadIdx.x; i < (cnt); i += T)
 
+// Workgroup barrier that orders LDS traffic only.  On gfx9-family parts loads and stores share
+// the vmcnt counter, so __syncthreads() (release fence) drains every outstanding global LOAD as
+// well -- which would serialise the software prefetch below behind each level barrier.  The
+// level-to-level hand-off of the triangular sweeps goes through LDS only, so waiting for
+// lgkmcnt(0) before s_barrier is sufficient there.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// One triangular sweep of the level-scheduled LDL' solve over a sliced-ELL plan (SliceMeta):
+// forward:  ws[i] = (ws[i] - sum_k UF[i,k] ws[k]) * invD[i]   (t = D^-1 L^-1 b, rows by level)
+// backward: ws[j] =  ws[j] - invD[j] * sum_i UB[i,j] ws[i]    (x = L^-T t, columns by level, top down)
+// Index/value/invD loads run TRI_DEPTH slices ahead of their use: they do not depend on ws, so
+// their HBM/L2 latency overlaps earlier levels and the dependent part of a level is only LDS
+// gathers + one LDS store + the barrier.  `sm` points to the slice table (LDS copy when staged).
+template <int T, bool FORWARD, bool LDSBAR, class SM, class WS>
+__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcdbl_p eval, gcdbl_p invD, WS ws,
+                                          int dummy_slot) {
+    const int t = threadIdx.x;
+    int qi[TRI_DEPTH][ELL_KMAX]; double qv[TRI_DEPTH][ELL_KMAX]; double qd[TRI_DEPTH];
+    // every slice issues exactly 2*ELL_KMAX+1 loads per lane (inactive lanes / padding read the
+    // plan's dummy slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
+    auto meta = [&](int s) { // slice descriptors are workgroup-uniform: keep them in SGPRs
+        SliceMeta m = sm[s];
+        m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off); m.newlev = uni(m.newlev);
+        return m;
+    };
+    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX], double &nd) {
+        const SliceMeta nm = meta(s);
+        const int lanes = nm.cnt << nm.lg;
+        const bool act = t < lanes;
+#pragma unroll
+        for (int kk = 0; kk < ELL_KMAX; kk++) {
+            const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
+            ni[kk] = eidx[slot];
+            nv[kk] = eval[slot];
+        }
+        nd = invD[act ? nm.row0 + (t >> nm.lg) : 0];
+    };
+    // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
+    // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
+#pragma unroll
+    for (int d = 0; d < TRI_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qd[d]);
+    for (int s0 = 0; s0 < ns; s0 += TRI_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < TRI_DEPTH; d++) {
+            const int s = s0 + d;
+            const SliceMeta cm = meta(s);
+            int ci[ELL_KMAX]; double cv[ELL_KMAX];
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
+            const double cd = qd[d];
+            load(min(s + TRI_DEPTH, ns - 1), qi[d], qv[d], qd[d]);
+            if (cm.newlev) { if (LDSBAR) lds_barrier(); else __syncthreads(); }
+            const int lanes = cm.cnt << cm.lg;
+            double acc = 0.;
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk] * ws[ci[kk]];
+            for (int kk = ELL_KMAX; kk < cm.K; kk++) { // very long rows: the tail is not prefetched
+                if (t < lanes) { const int slot = cm.off + kk * lanes + t; acc += eval[slot] * ws[eidx[slot]]; }
+            }
+            for (int o = (1 << cm.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (t < lanes && (t & ((1 << cm.lg) - 1)) == 0) {
+                const int r = cm.row0 + (t >> cm.lg);
+                if (FORWARD) ws[r] = (ws[r] - acc) * cd;
+                else ws[r] = ws[r] - cd * acc;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------- lambda = W z (ref scale :485-507); ends with a barrier ----------------
 template <int T>
-__device__ __noinline__ void dev_scale(const DevPat &P, const double *__restrict__ W, const double *__restrict__ zz,
-                                       double *__restrict__ out) {
-    const double *lpw = W + P.w_lpw, *csc = W + P.w_csc, *qv = W + P.w_qv;
+__device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out) {
+    ps = uni(ps); W = uni_ptr(W); zz = uni_ptr(zz); out = uni_ptr(out);
+    const DevPat &P = c_pat[ps];
+    gcdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
     FOR_T(i, P.l) out[i] = lpw[i] * zz[i];
-    for_cones<T>(P, [&](int c, auto G, int lane) {
+    for_cones<T>(ps, [&](int c, auto G, int lane) {
         constexpr int g = decltype(G)::value;
         const int o = P.cone_off[c], d = P.cq[c];
-        const double *cs = csc + c * CSC_STRIDE;
+        gcdbl_p cs = csc + c * CSC_STRIDE;
         double zeta = 0.;
         for (int k = 1 + lane; k < d; k += g) zeta += qv[o + k] * zz[o + k];
         zeta = grp_sum<g>(zeta);
@@ -196,13 +290,14 @@ __device__ __noinline__ void dev_scale(const DevPat &P, const double *__restrict
 
 // ---------------- bringToCone (ref :761-805): s = sgn*r shifted into the cone ----------------
 template <int T>
-__device__ __noinline__ void dev_bring_to_cone(const DevPat &P, const double *__restrict__ r, double sgn,
-                                               double *__restrict__ s) {
+__device__ __noinline__ void dev_bring_to_cone(int ps, gcdbl_p r, double sgn, gdbl_p s) {
+    ps = uni(ps); r = uni_ptr(r); s = uni_ptr(s);
+    const DevPat &P = c_pat[ps];
     int phase = 0;
     __syncthreads();
     double a = -GAMMA;
     FOR_T(i, P.l) { const double ri = sgn * r[i]; if (ri <= 0. && -ri > a) a = -ri; }
-    for_cones<T>(P, [&](int c, auto G, int lane) {
+    for_cones<T>(ps, [&](int c, auto G, int lane) {
         constexpr int g = decltype(G)::value;
         const int o = P.cone_off[c], d = P.cq[c];
         double t = 0.;
@@ -220,9 +315,11 @@ __device__ __noinline__ void dev_bring_to_cone(const DevPat &P, const double *__
 
 // ---------------- lineSearch (ref :1380-1469); result to every thread ----------------
 template <int T>
-__device__ __noinline__ double dev_line_search(const DevPat &P, const double *__restrict__ W, double tau, double dtau,
+__device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, double dtau,
                                                double kap, double dkap) {
-    const double *lam = W + P.w_lam, *ds = W + P.w_dsw, *dz = W + P.w_wdz;
+    ps = uni(ps); W = uni_ptr(W);
+    const DevPat &P = c_pat[ps];
+    gcdbl_p lam = W + P.w_lam, ds = W + P.w_dsw, dz = W + P.w_wdz;
     const int l = P.l;
     int phase = 0;
     __syncthreads();
@@ -252,7 +349,7 @@ __device__ __noinline__ double dev_line_search(const DevPat &P, const double *__
         rn = grp_sum<g>(rn); sn = grp_sum<g>(sn);
         return fmax(0., fmax(sqrt(sn) - sig0, sqrt(rn) - rho0));
     };
-    for_cones<T>(P, [&](int c, auto G, int lane) {
+    for_cones<T>(ps, [&](int c, auto G, int lane) {
         bool sk;
         const double st = cone_step(P.cone_off[c], P.cq[c], G, lane, sk);
         if (sk) bad = 1.; else cstep = fmax(cstep, st);
@@ -339,6 +436,8 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
 // straight-line form keeps ~45 per-thread array base addresses live and spills heavily.
 // ============================================================================================
 #define STAGE_PROLOGUE                                                                                  \
+    ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W);                                                       \
+    const DevPat &P = c_pat[ps];                                                                        \
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;                              \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                      \
     DevInfo &wi = g_S.wi;                                                                               \
@@ -347,10 +446,12 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
 
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
 template <int T>
-__device__ __noinline__ int stage_factor(const DevPat &P, double *__restrict__ I, double *__restrict__ W, int iter) {
+__device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
-    double *U = W + P.w_U, *Ur = W + P.w_Ur, *D = W + P.w_D, *invD = W + P.w_invD;
+    iter = uni(iter);
+    gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD; // pa/pb index UB slots
     __syncthreads();
+    TICK_BEGIN;
     for (int v = 0; v < P.nlev; v++) {
         const int q0 = P.ftask_ptr[v], q1 = P.ftask_ptr[v + 1], nl = P.ftask_nlong[v];
         auto store = [&](int tgt, double s) {
@@ -361,7 +462,7 @@ __device__ __noinline__ int stage_factor(const DevPat &P, double *__restrict__ I
             } else {
                 const int e = tgt - N;
                 const double u = I[P.Lsrc[e]] - s;
-                U[e] = u; Ur[P.Cpos[e]] = u;
+                U[P.posB[e]] = u; UF[P.posF[e]] = u;
             }
         };
         for (int q = q0 + wave; q < q0 + nl; q += T / 64) {
@@ -383,24 +484,27 @@ __device__ __noinline__ int stage_factor(const DevPat &P, double *__restrict__ I
     }
     if (tid == 0) wi.n_factor++;
     __syncthreads();
+    TICK_END(TK_FACTOR);
     if (g_S.fl[FL_FATAL]) return ST_DONE; // ref :901-905,1166-1170 (no backscale)
     return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
 template <int T>
-__device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I, double *__restrict__ W, int iter) {
+__device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
-    double *Av = I + P.i_Av, *Gv = I + P.i_Gv, *Atv = I + P.i_Atv, *Gtv = I + P.i_Gtv;
-    double *cv = I + P.i_c, *hv = I + P.i_h, *bv = I + P.i_b, *Vv = I + P.i_Vv;
-    double *wx = I + P.i_x, *wy = I + P.i_y, *wz = I + P.i_z, *wsl = I + P.i_s;
-    double *lam = W + P.w_lam, *rx = W + P.w_rx, *ry = W + P.w_ry, *rz = W + P.w_rz;
-    double *lpw = W + P.w_lpw, *lpv = W + P.w_lpv, *csc = W + P.w_csc, *qv = W + P.w_qv;
+    iter = uni(iter);
+    gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, Atv = I + P.i_Atv, Gtv = I + P.i_Gtv;
+    gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
+    gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
+    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
+    gdbl_p lpw = W + P.w_lpw, lpv = W + P.w_lpv, csc = W + P.w_csc, qv = W + P.w_qv;
     __syncthreads();
+    TICK_BEGIN;
     // ---- computeResiduals (ref :643-689) + updateStatistics (ref :691-754) ----
     const double tau = wi.tau;
     double r8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hresx2 rx2 cx nx2 | hresy2 ry2 by ny2
-    col_dots_AG<T>(P, Av, Gv, P.Air, P.Gir, wy, wz, [&](int j, double s) {
+    col_dots_AG<T>(ps, Av, Gv, P.Air, P.Gir, wy, wz, [&](int j, double s) {
         const double hr = -s, c_ = cv[j], xj = wx[j];
         const double r = hr - tau * c_;
         rx[j] = r;
@@ -446,7 +550,7 @@ __device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I,
             wi.dinfres = fmax(hresy / fmax(nx, 1.), hresz / fmax(nx + ns, 1.)); wi.has_dinfres = 1;
         }
         { // per-iteration history (the reference's verbose table, ref :733-753), kept per workspace slot
-            double *tr = W + P.w_trace + (size_t)iter * TRACE_COLS;
+            gdbl_p tr = W + P.w_trace + (size_t)iter * TRACE_COLS;
             tr[0] = wi.pcost; tr[1] = wi.dcost; tr[2] = wi.gap; tr[3] = wi.pres; tr[4] = wi.dres; tr[5] = wi.kapovert;
             tr[6] = wi.mu; tr[7] = wi.step; tr[8] = wi.sigma; tr[9] = wi.tau; tr[10] = wi.kap; tr[11] = (double)wi.nitref3;
         }
@@ -485,7 +589,7 @@ __device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I,
         g_S.fl[FL_ACTION] = action; g_S.fl[FL_RESTORE] = restore; g_S.fl[FL_SAVE] = save; g_S.fl[FL_CODE] = code;
     }
     __syncthreads();
-    double *bx_ = W + P.w_bx, *by_ = W + P.w_by, *bz_ = W + P.w_bz, *bs_ = W + P.w_bs, *blam = W + P.w_blam;
+    gdbl_p bx_ = W + P.w_bx, by_ = W + P.w_by, bz_ = W + P.w_bz, bs_ = W + P.w_bs, blam = W + P.w_blam;
     if (g_S.fl[FL_RESTORE]) { // w = w_best (vectors)
         FOR_T(j, n) wx[j] = bx_[j];
         FOR_T(j, p) wy[j] = by_[j];
@@ -494,7 +598,7 @@ __device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I,
     if (g_S.fl[FL_ACTION] == ACT_BREAK) {
         // backscale (ref :1271-1277)
         __syncthreads();
-        const double *xe = I + P.i_xe, *ae = I + P.i_ae, *ge = I + P.i_ge;
+        gcdbl_p xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
         const double tau2 = wi.tau;
         FOR_T(j, n) wx[j] = wx[j] / (xe[j] * tau2);
         FOR_T(r, p) wy[r] = wy[r] / (ae[r] * tau2);
@@ -510,10 +614,10 @@ __device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I,
     FOR_T(i, l) { const double v = wsl[i] / wz[i]; lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; }
     double firstfail = 1e300;
     if (P.nc > 0) {
-        for_cones<T>(P, [&](int c, auto G, int ln) { // phase 1: candidate scalings per cone
+        for_cones<T>(ps, [&](int c, auto G, int ln) { // phase 1: candidate scalings per cone
             constexpr int g = decltype(G)::value;
             const int o = P.cone_off[c], d = P.cq[c];
-            double *cs = csc + c * CSC_STRIDE;
+            gdbl_p cs = csc + c * CSC_STRIDE;
             double s1 = 0., z1 = 0.;
             for (int k = 1 + ln; k < d; k += g) { s1 += wsl[o + k] * wsl[o + k]; z1 += wz[o + k] * wz[o + k]; }
             s1 = grp_sum<g>(s1); z1 = grp_sum<g>(z1);
@@ -550,12 +654,12 @@ __device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I,
         // cone (ref :428-431,460-463): earlier cones keep their new scalings, later ones their old
         // ones, and lambda is not refreshed.
         firstfail = blk_reduce1<OpMin, T>(phase, firstfail);
-        for_cones<T>(P, [&](int c, auto G, int ln) { // phase 2: commit + updateKKTScalings
+        for_cones<T>(ps, [&](int c, auto G, int ln) { // phase 2: commit + updateKKTScalings
             constexpr int g = decltype(G)::value;
             if ((double)c >= firstfail) return;
             const int o = P.cone_off[c], d = P.cq[c];
-            double *cs = csc + c * CSC_STRIDE;
-            double *v = Vv + P.cone_vbase[c];
+            gdbl_p cs = csc + c * CSC_STRIDE;
+            gdbl_p v = Vv + P.cone_vbase[c];
             const double a = cs[CN_A], d1 = cs[CN_D1], eta2 = cs[CN_ETA2], u0 = cs[CN_U0], u1 = cs[CN_U1], v1 = cs[CN_V1];
             const double snorm = cs[CN_SN], znorm = cs[CN_ZN], gam = cs[CN_GAM];
             if (ln == 0) {
@@ -573,73 +677,82 @@ __device__ __noinline__ int stage_resid(const DevPat &P, double *__restrict__ I,
         });
     }
     __syncthreads();
-    if (firstfail >= 1e299) dev_scale<T>(P, W, wz, lam); // lambda = W z only when every cone succeeded (ref :476)
+    if (firstfail >= 1e299) dev_scale<T>(ps, W, wz, lam); // lambda = W z only when every cone succeeded (ref :476)
+    TICK_END(TK_RESID);
     return ST_FACTOR;
 }
 
 // ---------------- the KKT stages: pick rhs / outputs, solveKKT, post-process ----------------
-template <int T, bool WS_LDS>
-__device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, double *__restrict__ W, int stage, int &iter) {
+template <int T, int NLDS>
+__device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     STAGE_PROLOGUE
-    double *Av = I + P.i_Av, *Gv = I + P.i_Gv, *Atv = I + P.i_Atv, *Gtv = I + P.i_Gtv;
-    double *cv = I + P.i_c, *hv = I + P.i_h, *bv = I + P.i_b;
-    double *wx = I + P.i_x, *wy = I + P.i_y, *wz = I + P.i_z, *wsl = I + P.i_s;
-    double *lam = W + P.w_lam, *rx = W + P.w_rx, *ry = W + P.w_ry, *rz = W + P.w_rz, *rhs1 = W + P.w_rhs1, *rhs2 = W + P.w_rhs2;
-    double *dx1 = W + P.w_dx1, *dy1 = W + P.w_dy1, *dz1 = W + P.w_dz1, *dx2 = W + P.w_dx2, *dy2 = W + P.w_dy2, *dz2 = W + P.w_dz2;
-    double *dsw = W + P.w_dsw, *wdz = W + P.w_wdz, *dsa = W + P.w_dsa, *t1 = W + P.w_t1, *t2 = W + P.w_t2;
-    double *lpw = W + P.w_lpw, *lpv = W + P.w_lpv, *csc = W + P.w_csc, *qv = W + P.w_qv;
-    double *xk = W + P.w_xk, *ek = W + P.w_ek, *dxr = W + P.w_dxr;
-    double *U = W + P.w_U, *Ur = W + P.w_Ur, *invD = W + P.w_invD;
+    stage = uni(stage);
+    gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, Atv = I + P.i_Atv, Gtv = I + P.i_Gtv;
+    gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b;
+    gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
+    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz, rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;
+    gdbl_p dx1 = W + P.w_dx1, dy1 = W + P.w_dy1, dz1 = W + P.w_dz1, dx2 = W + P.w_dx2, dy2 = W + P.w_dy2, dz2 = W + P.w_dz2;
+    gdbl_p dsw = W + P.w_dsw, wdz = W + P.w_wdz, dsa = W + P.w_dsa, t1 = W + P.w_t1, t2 = W + P.w_t2;
+    gdbl_p lpw = W + P.w_lpw, lpv = W + P.w_lpv, csc = W + P.w_csc, qv = W + P.w_qv;
+    // KKT-space vectors: in LDS when they fit (NLDS of them), else in the workspace slab
+    // KKT-space vectors: LDS when they fit (NLDS of them), else the workspace slab (typed per instantiation)
+    auto xk = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else return W + P.w_xk; }();
+    auto ek = [&] { if constexpr (NLDS >= 3) return g_dyn + 2 * P.Npad; else return W + P.w_ek; }();
+    gdbl_p dxr = W + P.w_dxr;
+    gdbl_p UF = W + P.w_UF, UB = W + P.w_UB, invD = W + P.w_invD;
     __syncthreads();
+    TICK_BEGIN;
     const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
-    const double *rhs = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? rhs1 : rhs2;
-    double *dx = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dx1 : dx2;
-    double *dy = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dy1 : dy2;
-    double *dz = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dz1 : dz2;
+    auto rhs = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? rhs1 : rhs2;
+    auto dx = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dx1 : dx2;
+    auto dy = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dy1 : dy2;
+    auto dz = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dz1 : dz2;
     int kref;
     {
         // ---------------- solveKKT (ref :1471-1620) ----------------
-        const double *bx = rhs, *by = rhs + n, *bz = rhs + np;
-        double *ex = ek, *ey = ek + n, *ez = ek + np;
-        const double *xz = xk + np; // expanded dz ("dz_true")
+        gcdbl_p bx = rhs, by = rhs + n, bz = rhs + np;
+        auto ex = ek, ey = ek + n, ez = ek + np;
+        auto xz = xk + np; // expanded dz ("dz_true")
         double nr = 0.;
         FOR_T(i, N) nr = fmax(nr, fabs(rhs[i]));
         nr = blk_reduce1<OpMax, T>(phase, nr);
         const double thr = (1. + nr) * LINSYSACC;
         double nerr_prev = DBL_MAX;
-        const double *srhs = rhs;
-        double *sout = xk;
         int k = -1;
         for (;;) {
             // -------- x = P' L^-T D^-1 L^-1 P rhs (replaces ldlt.solve, ref :1477,1599) --------
             {
-                double *wsg = W + P.w_ws;
-                auto fwd = [&](auto ws) {
-                    for (int v = 0; v < P.nlev; v++) {
-                        const int f0 = P.fwd_long_ptr[v];
-                        seg_dots<T>(P.lev_ptr[v], P.lev_ptr[v + 1], P.Rp, P.Rj, Ur, ws, P.fwd_long + f0,
-                                    P.fwd_long_ptr[v + 1] - f0,
-                                    [&](int i, double s) { ws[i] = (srhs[P.perm[i]] - s) * invD[i]; });
-                        __syncthreads();
+                auto run = [&](auto ws) {
+                    // permute in (first solve: rhs, refinement: the residual e); slots >= N stay 0 (ELL padding)
+                    if (k < 0) { FOR_T(i, P.Npad) ws[i] = (i < N) ? rhs[P.perm[i]] : 0.; }
+                    else { FOR_T(i, P.Npad) ws[i] = (i < N) ? ek[P.perm[i]] : 0.; }
+                    // slice tables: staged in LDS behind the vectors when they fit (P.meta_lds), else read from L2
+                    __syncthreads();
+                    if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
+                        const SliceMeta *fsl = reinterpret_cast<const SliceMeta *>(g_dyn + (size_t)NLDS * P.Npad);
+                        tri_sweep<T, true, true>(fsl, P.nfs, P.f_idx, UF, invD, ws, P.nUF); // barriers at level starts + end
+                        tri_sweep<T, false, true>(fsl + P.nfs, P.nbs, P.b_idx, UB, invD, ws, P.nUB);
+                    } else {
+                        tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, ws, P.nUF);
+                        tri_sweep<T, false, false>(P.bsl, P.nbs, P.b_idx, UB, invD, ws, P.nUB);
                     }
-                    for (int v = P.nlev - 1; v >= 0; v--) {
-                        const int f0 = P.bwd_long_ptr[v];
-                        seg_dots<T>(P.lev_ptr[v], P.lev_ptr[v + 1], P.Lp, P.Li, U, ws, P.bwd_long + f0,
-                                    P.bwd_long_ptr[v + 1] - f0, [&](int j, double s) {
-                                        const double xj = ws[j] - invD[j] * s;
-                                        ws[j] = xj; sout[P.perm[j]] = xj;
-                                    });
-                        __syncthreads();
+                    FOR_T(jn, N) { // permute out; a refinement solve also adds its correction to x (ref :1602)
+                        const double xj = ws[jn];
+                        const int o = P.perm[jn];
+                        if (k < 0) xk[o] = xj;
+                        else { dxr[o] = xj; xk[o] += xj; }
                     }
+                    __syncthreads();
                 };
-                if constexpr (WS_LDS) fwd(g_dyn); else fwd(wsg);
+                TICK_END(TK_KRES);
+                if constexpr (NLDS >= 1) run(g_dyn); else run(W + P.w_ws);
                 if (tid == 0) wi.n_ldlsolve++;
+                TICK_END(TK_LDL);
             }
-            if (k >= 0) { FOR_T(i, N) xk[i] += dxr[i]; __syncthreads(); }
             k++;
             // ex = bx - G'dz - A'dy - delta dx   (ref :1515-1521); dz, dy read straight from xk
             double nex = 0., ney = 0., nez = 0.;
-            col_dots_AG<T>(P, Av, Gv, P.Air_k, P.Gir_k, xk, xk, [&](int j, double s) {
+            col_dots_AG<T>(ps, Av, Gv, P.Air_k, P.Gir_k, xk, xk, [&](int j, double s) {
                 const double e = bx[j] - s - DELTASTAT * xk[j];
                 ex[j] = e; nex = fmax(nex, fabs(e));
             });
@@ -658,7 +771,7 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
             if (P.nc > 0) {
                 __syncthreads();
                 // cone blocks (expanded): ez += dz_true (init) or scale2add (ref :1629-1662)
-                for_cones<T>(P, [&](int c, auto G, int ln) {
+                for_cones<T>(ps, [&](int c, auto G, int ln) {
                     constexpr int g = decltype(G)::value;
                     const int d = P.cq[c], o = P.cone_off[c], i1 = o + 2 * c, i3 = i1 + d, i4 = i3 + 1;
                     double mx = 0.;
@@ -666,7 +779,7 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
                         for (int q = ln; q < d; q += g) { const double v = ez[i1 + q] + xz[i1 + q]; ez[i1 + q] = v; mx = fmax(mx, fabs(v)); }
                         if (ln == 0) { ez[i3] = xz[i3]; ez[i4] = xz[i4]; mx = fmax(mx, fmax(fabs(xz[i3]), fabs(xz[i4]))); }
                     } else {
-                        const double *cs = csc + c * CSC_STRIDE;
+                        gcdbl_p cs = csc + c * CSC_STRIDE;
                         const double eta2 = cs[CS_ETA2], x1 = xz[i1], x3 = xz[i3], x4 = xz[i4];
                         const double tt = cs[CS_V1] * x3 + cs[CS_U1] * x4;
                         double qtx = 0.;
@@ -699,7 +812,6 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
             }
             if (k == NITREF || nerr < thr || (k > 0 && nerr_prev < IRERRFACT * nerr)) break;
             nerr_prev = nerr;
-            srhs = ek; sout = dxr;
         }
         __syncthreads();
         FOR_T(j, n) dx[j] = xk[j];
@@ -707,17 +819,18 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
         FOR_T(i, m) dz[i] = xz[P.zexp[i]];
         __syncthreads();
         kref = k;
+        TICK_END(TK_KRES);
     }
 
     // ---------------- post-processing of each KKT stage ----------------
     if (stage == ST_KKT_INIT1) { // ref :933-939
         if (tid == 0) wi.nitref1 = kref;
         FOR_T(j, n) wx[j] = dx1[j];
-        dev_bring_to_cone<T>(P, dz1, -1., wsl);
+        dev_bring_to_cone<T>(ps, dz1, -1., wsl);
         stage = ST_KKT_INIT2;
     } else if (stage == ST_KKT_INIT2) { // ref :966-992
         FOR_T(j, p) wy[j] = dy2[j];
-        dev_bring_to_cone<T>(P, dz2, 1., wz);
+        dev_bring_to_cone<T>(ps, dz2, 1., wz);
         FOR_T(j, n) rhs1[j] = -cv[j];
         if (tid == 0) {
             wi.nitref2 = kref;
@@ -725,7 +838,6 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
             g_S.sv[SV_PRESPREV] = DBL_MAX;
         }
         __syncthreads();
-        iter = 0;
         stage = ST_RESID;
     } else if (stage == ST_KKT1) { // RHSaffine (ref :1670-1689)
         FOR_T(j, n) rhs2[j] = rx[j];
@@ -746,9 +858,9 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
         FOR_T(i, m) dz2[i] += dtauaff * dz1[i];
         __syncthreads();
         if (tid == 0) { g_S.sv[SV_DTAUDEN] = dtau_denom; g_S.sv[SV_DTAUAFF] = dtauaff; g_S.sv[SV_DKAPAFF] = dkapaff; }
-        dev_scale<T>(P, W, dz2, wdz);
+        dev_scale<T>(ps, W, dz2, wdz);
         FOR_T(i, m) dsw[i] = -wdz[i] - lam[i];
-        const double step_aff = dev_line_search<T>(P, W, tau, dtauaff, kap, dkapaff);
+        const double step_aff = dev_line_search<T>(ps, W, tau, dtauaff, kap, dkapaff);
         const double oms_ = 1. - step_aff;
         const double sigma = fmin(fmax(oms_ * oms_ * oms_, SIGMAMIN), SIGMAMAX);
         const double mu = wi.mu;
@@ -764,7 +876,7 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
             t1[i] = lpw[i] * q_;
         }
         if (P.nc > 0) {
-            for_cones<T>(P, [&](int c, auto G, int ln) {
+            for_cones<T>(ps, [&](int c, auto G, int ln) {
                 constexpr int g = decltype(G)::value;
                 const int o = P.cone_off[c], d = P.cq[c];
                 // conic products (ref :1357-1378): ds1 = lam o lam + dsw o wdz - sigmamu e
@@ -788,10 +900,10 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
                 if (ln == 0) dsw[o] = (l0 * p0 - zeta) / rho;
             });
             __syncthreads();
-            for_cones<T>(P, [&](int c, auto G, int ln) { // t1 = W * (lam \ ds) on the cone part
+            for_cones<T>(ps, [&](int c, auto G, int ln) { // t1 = W * (lam \ ds) on the cone part
                 constexpr int g = decltype(G)::value;
                 const int o = P.cone_off[c], d = P.cq[c];
-                const double *cs = csc + c * CSC_STRIDE;
+                gcdbl_p cs = csc + c * CSC_STRIDE;
                 double zeta = 0.;
                 for (int k = 1 + ln; k < d; k += g) zeta += qv[o + k] * dsw[o + k];
                 zeta = grp_sum<g>(zeta);
@@ -820,10 +932,10 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
         FOR_T(r, p) dy2[r] += dtau * dy1[r];
         FOR_T(i, m) dz2[i] += dtau * dz1[i];
         __syncthreads();
-        dev_scale<T>(P, W, dz2, wdz);
+        dev_scale<T>(ps, W, dz2, wdz);
         FOR_T(i, m) dsw[i] = -(dsw[i] + wdz[i]);
-        const double st = GAMMA * dev_line_search<T>(P, W, tau, dtau, kap, dkap);
-        dev_scale<T>(P, W, dsw, dsa);
+        const double st = GAMMA * dev_line_search<T>(ps, W, tau, dtau, kap, dkap);
+        dev_scale<T>(ps, W, dsw, dsa);
         FOR_T(j, n) wx[j] += st * dx2[j];
         FOR_T(r, p) wy[r] += st * dy2[r];
         FOR_T(i, m) { wz[i] += st * dz2[i]; wsl[i] += st * dsa[i]; }
@@ -833,34 +945,37 @@ __device__ __noinline__ int stage_kkt(const DevPat &P, double *__restrict__ I, d
             wi.tau = tau + st * dtau;
         }
         __syncthreads();
-        iter++;
         stage = ST_RESID;
     }
+    TICK_END(TK_KPOST);
     return stage;
 }
 
-template <int T, bool WS_LDS>
-__device__ __forceinline__ void solve_instance(const DevPat &P, double *__restrict__ I, double *__restrict__ W) {
+template <int T, int NLDS>
+__device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
+    const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
     const int tid = threadIdx.x;
     DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
     DevInfo &wi = g_S.wi;
     {
-        double *cv = I + P.i_c, *hv = I + P.i_h, *bv = I + P.i_b, *Vv = I + P.i_Vv;
-        double *rhs1 = W + P.w_rhs1, *rhs2 = W + P.w_rhs2;
+        gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
+        gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;
         int phase = 0;
     __syncthreads();
         if (tid == 0) { // sticky across solve() calls like the reference's w.i
             wi = *ginfo; g_S.bi = wi;
             wi.n_factor = 0; wi.n_ldlsolve = 0;
             g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7;
+        for (int q = 0; q < 8; q++) g_S.tick[q] = 0;
+        g_S.tick[7] = wall_clock64();
         }
         // resetKKTScalings (ref :807-846)
         FOR_T(i, l) Vv[i] = -1.;
-        for_cones<T>(P, [&](int c, auto G, int ln) {
+        for_cones<T>(ps, [&](int c, auto G, int ln) {
             constexpr int g = decltype(G)::value;
             const int d = P.cq[c];
-            double *v = Vv + P.cone_vbase[c];
+            gdbl_p v = Vv + P.cone_vbase[c];
             for (int k = ln; k < d; k += g) { v[k] = -1.; v[2 * d + 1 + k] = 0.; if (k >= 1) v[d + k] = 0.; }
             if (ln == 0) { v[d] = -1.; v[2 * d] = 1.; }
         });
@@ -882,27 +997,43 @@ __device__ __forceinline__ void solve_instance(const DevPat &P, double *__restri
     int stage = ST_FACTOR;
     int iter = -1; // -1 while initialising
     while (stage != ST_DONE) {
-        if (stage == ST_FACTOR) stage = stage_factor<T>(P, I, W, iter);
-        else if (stage == ST_RESID) stage = stage_resid<T>(P, I, W, iter);
-        else stage = stage_kkt<T, WS_LDS>(P, I, W, stage, iter);
+        if (stage == ST_FACTOR) stage = stage_factor<T>(ps, I, W, iter);
+        else if (stage == ST_RESID) stage = stage_resid<T>(ps, I, W, iter);
+        else {
+            const int prev = stage;
+            stage = stage_kkt<T, NLDS>(ps, I, W, stage);
+            if (stage == ST_RESID) iter = (prev == ST_KKT_INIT2) ? 0 : iter + 1; // a pass of the main loop completed
+        }
     }
     __syncthreads();
     if (tid == 0) {
         wi.exitcode = g_S.fl[FL_FATAL] ? -7 : g_S.fl[FL_CODE];
         *ginfo = wi;
+        // phase timers (microseconds) into the last row of the trace buffer: factor, LDL solves, refinement
+        // residuals, KKT post-processing, residual/statistics/scalings stage, [5] unused, [6] total
+        gdbl_p tr = W + P.w_trace + (size_t)(TRACE_ROWS - 1) * TRACE_COLS;
+        for (int q = 0; q < TK_COUNT; q++) tr[q] = (double)g_S.tick[q] * 0.01;
+        tr[6] = (double)(wall_clock64() - g_S.tick[7]) * 0.01;
     }
 }
 
-template <int T, bool WS_LDS>
-__global__ __launch_bounds__(T, (EICOS_WAVES_PER_EU * T) / 256 > 8 ? 8 : (EICOS_WAVES_PER_EU * T) / 256) void k_solve(const DevPat *__restrict__ Pp, double *inst, double *work, int B) {
-    const DevPat &P = *Pp;
-    double *W = work + (size_t)blockIdx.x * P.work_stride;
+template <int T, int NLDS>
+__global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
+    int ps, double *inst, double *work, int B) {
+    const DevPat &P = c_pat[ps];
+    gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
+    if constexpr (NLDS >= 1) { // slice tables of both sweeps -> LDS, once per workgroup (same plan for every instance)
+        int *dst = reinterpret_cast<int *>(g_dyn + (size_t)NLDS * P.Npad);
+        const int *srcf = reinterpret_cast<const int *>(P.fsl), *srcb = reinterpret_cast<const int *>(P.bsl);
+        for (int q = threadIdx.x; q < P.nfs * 8; q += T) dst[q] = srcf[q];
+        for (int q = threadIdx.x; q < P.nbs * 8; q += T) dst[P.nfs * 8 + q] = srcb[q];
+        __syncthreads();
+    }
     for (int i = blockIdx.x; i < B; i += gridDim.x) {
-        solve_instance<T, WS_LDS>(P, inst + (size_t)i * P.inst_stride, W);
+        solve_instance<T, NLDS>(ps, (gdbl_p)inst + (size_t)i * P.inst_stride, W);
         __syncthreads();
     }
 }
-
 // ============================================================================================
 // updateData for a range of instances: reference updateData(double*...) src/eicos.cpp:2053-2082
 // = unsetEquilibration (:389-404) -> copy-in -> setEquilibration (:302-374) -> transposes.
@@ -910,16 +1041,16 @@ __global__ __launch_bounds__(T, (EICOS_WAVES_PER_EU * T) / 256 > 8 ? 8 : (EICOS_
 //  equilibrated A/G values in place through DevPat::Lsrc.)
 // ============================================================================================
 template <int T>
-__global__ __launch_bounds__(T) void k_update(const DevPat *__restrict__ Pp, double *inst, int first, int count,
+__global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, int count,
                                               const double *Gpr, const double *Apr, const double *cin,
                                               const double *hin, const double *bin, double *scratch) {
-    const DevPat &P = *Pp;
+    const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l;
-    double *xt = scratch + (size_t)blockIdx.x * (size_t)(n + p + m), *at = xt + n, *gt = at + p;
+    gdbl_p xt = (gdbl_p)scratch + (size_t)blockIdx.x * (size_t)(n + p + m), at = xt + n, gt = at + p;
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        double *I = inst + (size_t)(first + q) * P.inst_stride;
-        double *Av = I + P.i_Av, *Gv = I + P.i_Gv, *Atv = I + P.i_Atv, *Gtv = I + P.i_Gtv;
-        double *cv = I + P.i_c, *hv = I + P.i_h, *bv = I + P.i_b, *xe = I + P.i_xe, *ae = I + P.i_ae, *ge = I + P.i_ge;
+        gdbl_p I = (gdbl_p)inst + (size_t)(first + q) * P.inst_stride;
+        gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, Atv = I + P.i_Atv, Gtv = I + P.i_Gtv;
+        gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
         DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
         const bool was_eq = ginfo->equilibrated != 0;
         __syncthreads();
@@ -984,7 +1115,7 @@ __global__ __launch_bounds__(T) void k_update(const DevPat *__restrict__ Pp, dou
         FOR_T(k, P.nnzG) Gtv[k] = Gv[P.Gt_pos[k]];
         // static-regularisation constants read by the factor program
         if (threadIdx.x == 0) {
-            double *cst = I + P.i_cst;
+            gdbl_p cst = I + P.i_cst;
             cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 0.;
             ginfo->equilibrated = 1;
         }
@@ -994,59 +1125,72 @@ __global__ __launch_bounds__(T) void k_update(const DevPat *__restrict__ Pp, dou
 
 // Debug: factorise instance `i` with the KKT scaling block as it stands in memory.
 template <int T>
-__global__ __launch_bounds__(T) void k_debug_factor(const DevPat *__restrict__ Pp, double *inst, double *work, int i) {
-    const DevPat &P = *Pp;
+__global__ __launch_bounds__(T) void k_debug_factor(int ps, double *inst, double *work, int i) {
+    const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x;
-    double *I = inst + (size_t)i * P.inst_stride, *W = work;
-    double *U = W + P.w_U, *Ur = W + P.w_Ur, *D = W + P.w_D, *invD = W + P.w_invD;
+    gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, W = (gdbl_p)work;
+    gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD;
     for (int v = 0; v < P.nlev; v++) {
         for (int q = P.ftask_ptr[v] + tid; q < P.ftask_ptr[v + 1]; q += T) {
             const int tgt = P.ftask[q];
             double s = 0.;
             for (int k = P.tp[tgt]; k < P.tp[tgt + 1]; k++) s += U[P.pa[k]] * U[P.pb[k]] * invD[P.pk[k]];
             if (tgt < P.N) { const double d = I[P.Dsrc[tgt]] - s; D[tgt] = d; invD[tgt] = 1. / d; }
-            else { const int e = tgt - P.N; const double u = I[P.Lsrc[e]] - s; U[e] = u; Ur[P.Cpos[e]] = u; }
+            else { const int e = tgt - P.N; const double u = I[P.Lsrc[e]] - s; U[P.posB[e]] = u; UF[P.posF[e]] = u; }
         }
         __syncthreads();
     }
 }
 
 // ---- launchers (called from api.cpp) ----
-template <int T, bool WS>
-static hipError_t launch_solve_t(const DevPat *dP, double *inst, double *work, int B, int grid, size_t dyn, hipStream_t st) {
-    hipLaunchKernelGGL((k_solve<T, WS>), dim3(grid), dim3(T), dyn, st, dP, inst, work, B);
-    return hipGetLastError();
+template <class F> static auto dispatch_solve(int threads, int nlds, F &&f) {
+    auto byT = [&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        switch (nlds) {
+        case 0: return f((const void *)k_solve<T, 0>);
+        case 1: return f((const void *)k_solve<T, 1>);
+        case 2: return f((const void *)k_solve<T, 2>);
+        default: return f((const void *)k_solve<T, 3>);
+        }
+    };
+    if (threads == 1024) return byT(std::integral_constant<int, 1024>{});
+    if (threads == 512) return byT(std::integral_constant<int, 512>{});
+    return byT(std::integral_constant<int, 256>{});
 }
-hipError_t launch_solve(const DevPat *dP, double *inst, double *work, int B, int grid, int threads, size_t dyn_lds,
-                        hipStream_t st) {
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int grid, int threads, int nlds,
+                        size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    if (dyn_lds > 0) return threads == 512 ? launch_solve_t<512, true>(dP, inst, work, B, grid, dyn_lds, st)
-                                           : launch_solve_t<256, true>(dP, inst, work, B, grid, dyn_lds, st);
-    return threads == 512 ? launch_solve_t<512, false>(dP, inst, work, B, grid, 0, st)
-                          : launch_solve_t<256, false>(dP, inst, work, B, grid, 0, st);
+    return dispatch_solve(threads, nlds, [&](const void *fn) {
+        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B};
+        return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
+    });
 }
-hipError_t launch_update(const DevPat *dP, double *inst, int first, int count, const double *Gpr, const double *Apr,
+hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,
                          const double *c, const double *h, const double *b, double *scratch, int grid, hipStream_t st) {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, dP, inst, first, count, Gpr, Apr, c, h, b, scratch);
+    hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
     return hipGetLastError();
 }
-hipError_t launch_debug_factor(const DevPat *dP, double *inst, double *work, int i, hipStream_t st) {
-    hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), 0, st, dP, inst, work, i);
+hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), 0, st, ps, inst, work, i);
     return hipGetLastError();
 }
-hipError_t solve_occupancy(int threads, size_t dyn_lds, int *blocks_per_cu) {
-    if (dyn_lds > 0) {
-        if (threads == 512) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_solve<512, true>, 512, dyn_lds);
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_solve<256, true>, 256, dyn_lds);
-    }
-    if (threads == 512) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_solve<512, false>, 512, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_solve<256, false>, 256, 0);
+hipError_t solve_occupancy(int threads, int nlds, size_t dyn_lds, int *blocks_per_cu) {
+    return dispatch_solve(threads, nlds, [&](const void *fn) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, threads, dyn_lds);
+    });
 }
-hipError_t solve_set_max_lds(int threads, size_t dyn_lds) {
+hipError_t solve_set_max_lds(int threads, int nlds, size_t dyn_lds) {
     if (dyn_lds == 0) return hipSuccess;
-    if (threads == 512) return hipFuncSetAttribute((const void *)k_solve<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
-    return hipFuncSetAttribute((const void *)k_solve<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+    return dispatch_solve(threads, nlds, [&](const void *fn) {
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+    });
 }
+
+hipError_t upload_pattern(int ps, const DevPat &P) {
+    if (ps < 0 || ps >= MAX_PATTERNS) return hipErrorInvalidValue;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_pat), &P, sizeof(DevPat), (size_t)ps * sizeof(DevPat), hipMemcpyHostToDevice);
+}
+int max_patterns() { return MAX_PATTERNS; }
 
 } // namespace eicos

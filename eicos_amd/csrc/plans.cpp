@@ -1,0 +1,53 @@
+// Host-side construction of the sliced-ELL triangular-solve plans.
+#include "plans.hpp"
+
+#include <algorithm>
+
+namespace eicos {
+
+TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
+    TriPlan pl;
+    pl.pos.assign(S.nnzL, 0);
+    const std::vector<int> &ptr = forward ? S.Rp : S.Lp;
+    const std::vector<int> &ind = forward ? S.Rj : S.Li;
+    auto len = [&](int r) { return ptr[r + 1] - ptr[r]; };
+    auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
+    auto emit_level = [&](int v) {
+        int r = S.lev_ptr[v];
+        const int end = S.lev_ptr[v + 1];
+        bool first = true;
+        while (r < end) {
+            // lanes per row from the longest row among the next T candidates (rows of a level are
+            // sorted by decreasing row length, so for the forward plan this is row r itself)
+            int mx = 0;
+            for (int i = r; i < std::min(end, r + T); i++) mx = std::max(mx, len(i));
+            const int g = std::max(1, std::min(64, pow2ceil((mx + ELL_KMAX - 1) / ELL_KMAX)));
+            const int cnt = std::min(T / g, end - r);
+            mx = 0;
+            for (int i = r; i < r + cnt; i++) mx = std::max(mx, len(i));
+            const int K = (mx + g - 1) / g;
+            int lg = 0;
+            while ((1 << lg) < g) lg++;
+            const int lanes = cnt * g;
+            pl.sl.push_back(SliceMeta{r, cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
+            pl.idx.resize((size_t)pl.slots + (size_t)K * lanes, S.N); // padding gathers the zero slot N
+            for (int i = r; i < r + cnt; i++)
+                for (int e = ptr[i]; e < ptr[i + 1]; e++) {
+                    const int j = e - ptr[i], q = j % g, kk = j / g;
+                    const int slot = pl.slots + kk * lanes + (i - r) * g + q;
+                    pl.idx[slot] = ind[e];
+                    pl.pos[forward ? S.Rpos[e] : e] = slot; // indexed by the CSC entry of L
+                }
+            pl.slots += K * lanes;
+            r += cnt;
+            first = false;
+        }
+    };
+    if (forward) for (int v = 0; v < S.nlev; v++) emit_level(v);
+    else for (int v = S.nlev - 1; v >= 0; v--) emit_level(v);
+    pl.idx.push_back(S.N); // slot `slots`: the dummy (index N, value 0) read by inactive lanes
+    while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // empty slices: no loop tail
+    return pl;
+}
+
+} // namespace eicos

@@ -1,0 +1,20 @@
+// Sliced-ELL plans of the level-scheduled triangular sweeps (see SliceMeta in device_types.hpp).
+#pragma once
+#include <vector>
+
+#include "device_types.hpp"
+#include "symbolic.hpp"
+
+namespace eicos {
+
+struct TriPlan {
+    std::vector<SliceMeta> sl; // slices in sweep order (forward: levels up, backward: levels down)
+    std::vector<int> idx;      // per slot: index of the gathered solve-vector entry (padding -> N)
+    std::vector<int> pos;      // per CSC entry of L: its slot
+    int slots = 0;
+};
+
+// T = workgroup size the plan is laid out for.
+TriPlan build_tri_plan(const Symbolic &S, int T, bool forward);
+
+} // namespace eicos

@@ -185,10 +185,23 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
     }
 
     // ---- L pattern under the final ordering ----
+    // Inside a level the numbering is free (any topological order of the tree gives the same
+    // fill): sort each level by decreasing row length of L so that the sliced-ELL structures of
+    // the GPU triangular solves (rows of one slice share a lanes-per-row factor) pad little.
     std::vector<ivec> rows;
     {
         auto up = permuted_upper(N, S.K_row, S.K_col, S.iperm);
         etree_rows(N, up, S.parent, &rows);
+        ivec idx(N); std::iota(idx.begin(), idx.end(), 0);
+        for (int v = 0; v < S.nlev; v++)
+            std::stable_sort(idx.begin() + S.lev_ptr[v], idx.begin() + S.lev_ptr[v + 1],
+                             [&](int a, int b) { return rows[a].size() > rows[b].size(); });
+        ivec perm2(N);
+        for (int k = 0; k < N; k++) perm2[k] = S.perm[idx[k]];
+        S.perm = perm2;
+        for (int k = 0; k < N; k++) S.iperm[S.perm[k]] = k;
+        auto up2 = permuted_upper(N, S.K_row, S.K_col, S.iperm);
+        etree_rows(N, up2, S.parent, &rows);
     }
     S.Rp.assign(N + 1, 0);
     for (int i = 0; i < N; i++) { std::sort(rows[i].begin(), rows[i].end()); S.Rp[i + 1] = S.Rp[i] + (int)rows[i].size(); }

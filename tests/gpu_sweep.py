@@ -18,3 +18,7 @@ for r in range(reps):
 ia = g.info_arrays(); dm = g.dims()
 tag = f"lib={os.path.basename(os.environ.get('EICOS_AMD_LIB','default'))} T={dm['threads_per_block']} lds={dm['lds_bytes']} resident={dm['resident_blocks']}"
 print(f"{name} B={B} {tag}: ms={min(ms):.2f} (all {['%.1f'%m for m in ms]}) iters={ia['iter'].sum()} ok={(codes==0).sum()} -> {ia['iter'].sum()/min(ms)*1e3:.0f} iter/s  pcost0={ia['pcost'][0]:.10e}", flush=True)
+
+if B <= dm['resident_blocks']:
+    tr = g.debug_trace(0)[-1]
+    print("   phase us (inst 0): factor %.0f ldl %.0f kkt-resid %.0f kkt-post %.0f resid-stage %.0f total %.0f" % (tr[0], tr[1], tr[2], tr[3], tr[4], tr[6]), " per iter:", ["%.0f" % (v / max(1, ia['iter'][0])) for v in (tr[0], tr[1], tr[2], tr[3], tr[4], tr[6])])
