@@ -27,6 +27,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
 
 
+def usable_cores():
+    """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def algorithmic_bytes(dims, ia):
     """Algorithmic HBM bytes of ONE solve launch (fp64 values only; shared index arrays excluded),
     SURVEY.md 8(d) formula with the measured counters of every instance."""
@@ -143,7 +155,7 @@ def main():
         if not args.no_cpu_baseline:
             # CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload
             from oracle import oracle as orc
-            cores = len(os.sched_getaffinity(0))
+            cores = usable_cores()
             ns = int(min(B, max(64, 24 * cores)))
             r = orc.batch_solve(pat, data["Gpr"][:ns], data["Apr"][:ns], data["c"][:ns], data["h"][:ns], data["b"][:ns], cores)
             wall = r["seconds"] + r["update_seconds"]

@@ -129,12 +129,37 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     }
     // ---- slab layouts ----
     SlabLayout L;
-    D.i_Av = L.add(S.nnzA); D.i_Gv = L.add(S.nnzG); D.i_Atv = L.add(S.nnzA); D.i_Gtv = L.add(S.nnzG);
+    D.i_Av = L.add(S.nnzA); D.i_Gv = L.add(S.nnzG);
+    // sliced-ELL plans of the matrix-vector products
+    std::vector<int> cag_ptr(S.n + 1, 0), cag_val, cag_k, cag_yz; // stacked columns of [A; G]
+    std::vector<int> zexp0(S.m);
+    { for (int i = 0; i < S.l; i++) zexp0[i] = i; for (int c = 0; c < S.nc; c++) for (int k = 0; k < S.q[c]; k++) zexp0[S.cone_off[c] + k] = S.cone_off[c] + k + 2 * c; }
+    const int gv_rel = D.i_Gv - D.i_Av;
+    for (int j = 0; j < S.n; j++) {
+        for (int k = P.Ajc[j]; k < P.Ajc[j + 1]; k++) { cag_val.push_back(k); cag_k.push_back(S.n + P.Air[k]); cag_yz.push_back(P.Air[k]); }
+        for (int k = P.Gjc[j]; k < P.Gjc[j + 1]; k++) { cag_val.push_back(gv_rel + k); cag_k.push_back(S.n + S.p + zexp0[P.Gir[k]]); cag_yz.push_back(-1 - P.Gir[k]); }
+        cag_ptr[j + 1] = (int)cag_val.size();
+    }
+    EllPlan pcag = build_ell_plan(cag_ptr, S.n, h->threads), prA = build_ell_plan(S.At_ptr, S.p, h->threads),
+            prG = build_ell_plan(S.Gt_ptr, S.m, h->threads);
+    D.cag_ns = (int)pcag.sl.size(); D.rA_ns = (int)prA.sl.size(); D.rG_ns = (int)prG.sl.size();
+    D.cag_slots = pcag.slots; D.rA_slots = prA.slots; D.rG_slots = prG.slots;
+    D.i_cag = L.add((size_t)pcag.slots + 8); D.i_rA = L.add((size_t)prA.slots + 8); D.i_rG = L.add((size_t)prG.slots + 8);
     D.i_c = L.add(S.n); D.i_h = L.add(S.m); D.i_b = L.add(S.p);
     D.i_xe = L.add(S.n); D.i_ae = L.add(S.p); D.i_ge = L.add(S.m);
     D.i_Vv = L.add(S.nV); D.i_cst = L.add(4);
     D.i_x = L.add(S.n); D.i_y = L.add(S.p); D.i_z = L.add(S.m); D.i_s = L.add(S.m);
     D.i_info = L.add(DEVINFO_DOUBLES);
+    std::vector<int> cag_idx_k(pcag.src.size()), cag_idx_yz(pcag.src.size()), cag_src(pcag.src.size());
+    for (size_t sl = 0; sl < pcag.src.size(); sl++) {
+        const int e = pcag.src[sl];
+        cag_src[sl] = e < 0 ? -1 : cag_val[e];
+        cag_idx_k[sl] = e < 0 ? S.N : cag_k[e];                                  // padding gathers the zero slot N of x
+        cag_idx_yz[sl] = e < 0 ? 0 : (cag_yz[e] >= 0 ? cag_yz[e] : (D.i_z - D.i_y) + (-1 - cag_yz[e])); // offset from y
+    }
+    std::vector<int> rA_idx(prA.src.size()), rA_src(prA.src.size()), rG_idx(prG.src.size()), rG_src(prG.src.size());
+    for (size_t sl = 0; sl < prA.src.size(); sl++) { const int e = prA.src[sl]; rA_src[sl] = e < 0 ? -1 : S.At_pos[e]; rA_idx[sl] = e < 0 ? 0 : S.At_col[e]; }
+    for (size_t sl = 0; sl < prG.src.size(); sl++) { const int e = prG.src[sl]; rG_src[sl] = e < 0 ? -1 : gv_rel + S.Gt_pos[e]; rG_idx[sl] = e < 0 ? 0 : S.Gt_col[e]; }
     D.inst_stride = L.size;
     SlabLayout Wl;
     D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m); D.w_blam = Wl.add(S.m);
@@ -142,7 +167,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
-    D.w_xk = Wl.add(S.N); D.w_ek = Wl.add(S.N); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
+    D.w_xk = Wl.add((size_t)S.N + 16); D.w_ek = Wl.add(S.N); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
     D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N); // w_UF / w_UB are added once the slice plans are known
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
 
@@ -204,6 +229,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         return o;
     };
     std::vector<int> fsl_i = meta_ints(planF.sl), bsl_i = meta_ints(planB.sl);
+    std::vector<int> cag_sl_i = meta_ints(pcag.sl), rA_sl_i = meta_ints(prA.sl), rG_sl_i = meta_ints(prG.sl);
 
     struct Slot { const int **dst; size_t off; };
     std::vector<Slot> slots;
@@ -218,8 +244,10 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(D.zexp, zexp); put(D.zdsign, zdsign);
     put(D.perm, S.perm); put(D.lev_ptr, S.lev_ptr);
     put(D.f_idx, planF.idx); put(D.b_idx, planB.idx); put(D.posF, planF.pos); put(D.posB, planB.pos);
-    const int *fsl_p = nullptr, *bsl_p = nullptr;
-    put(fsl_p, fsl_i); put(bsl_p, bsl_i);
+    const int *fsl_p = nullptr, *bsl_p = nullptr, *cag_sl_p = nullptr, *rA_sl_p = nullptr, *rG_sl_p = nullptr;
+    put(fsl_p, fsl_i); put(bsl_p, bsl_i); put(cag_sl_p, cag_sl_i); put(rA_sl_p, rA_sl_i); put(rG_sl_p, rG_sl_i);
+    put(D.cag_idx_k, cag_idx_k); put(D.cag_idx_yz, cag_idx_yz); put(D.cag_src, cag_src);
+    put(D.rA_idx, rA_idx); put(D.rA_src, rA_src); put(D.rG_idx, rG_idx); put(D.rG_src, rG_src);
     put(D.ftask_ptr, S.ftask_ptr); put(D.ftask, S.ftask); put(D.ftask_nlong, ftask_nlong); put(D.tp, tp32);
     put(D.pa, pa2); put(D.pb, pb2); put(D.pk, S.pk); put(D.Lsrc, Lsrc); put(D.Dsrc, Dsrc);
 
@@ -244,7 +272,12 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         // all-global variant (NLDS = 0, plain __syncthreads between levels) is used
         int fit = (meta + vec <= avail) ? (int)std::min<size_t>(3, (avail - meta) / vec) : 0;
         if (S.N == 0) fit = 0;
-        h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", fit)));
+        // More than one instance per CU: keep only the solve vector in LDS so that two 512-thread workgroups
+        // share a CU (measured on MI355X, MPC02 pattern: 2 x NLDS=1 beats 1 x NLDS=3 once the batch exceeds
+        // the CU count); a batch that fits one-per-CU takes every vector it can into LDS.
+        int want = fit;
+        if (batch > prop.multiProcessorCount && fit >= 1 && 2 * (vec + meta) + 8192 <= 160 * 1024) want = 1;
+        h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want)));
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
         h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : 0;
     }
@@ -261,6 +294,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
     for (auto &s : slots) *s.dst = h->d_pattern + s.off;
     D.fsl = reinterpret_cast<const SliceMeta *>(fsl_p); D.bsl = reinterpret_cast<const SliceMeta *>(bsl_p);
+    D.cag_sl = reinterpret_cast<const SliceMeta *>(cag_sl_p); D.rA_sl = reinterpret_cast<const SliceMeta *>(rA_sl_p);
+    D.rG_sl = reinterpret_cast<const SliceMeta *>(rG_sl_p);
     {
         std::lock_guard<std::mutex> lk(g_slot_mu);
         for (int q = 0; q < max_patterns() && q < 64; q++) if (!g_slot_used[device % 16][q]) { h->pslot = q; g_slot_used[device % 16][q] = true; break; }

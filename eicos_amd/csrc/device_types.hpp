@@ -49,6 +49,13 @@ struct DevPat {
     gint_p Gjc, Gir, Gir_k, Gt_ptr, Gt_col, Gt_pos;
     gint_p A_long, At_long, G_long, Gt_long; // columns / rows longer than LONG_SEG
     int nA_long, nAt_long, nG_long, nGt_long;
+    // sliced-ELL plans of the matrix-vector products (plans.hpp: EllPlan): stacked columns of [A;G]
+    // (cag: x-space results), rows of A (rA), rows of G (rG).  *_src: slot -> offset of the CSC value
+    // relative to Av (-1 = padding); cag has two gather-index sets: KKT indices (refinement) and
+    // offsets into the contiguous (y, z) block of the instance slab (residuals).
+    const SliceMeta EICOS_GLOBAL *cag_sl; const SliceMeta EICOS_GLOBAL *rA_sl; const SliceMeta EICOS_GLOBAL *rG_sl;
+    int cag_ns, rA_ns, rG_ns, cag_slots, rA_slots, rG_slots;
+    gint_p cag_idx_k, cag_idx_yz, cag_src, rA_idx, rA_src, rG_idx, rG_src;
     // cones
     gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;
@@ -64,7 +71,7 @@ struct DevPat {
     gint_p f_idx, b_idx, posF, posB;
     gint_p ftask_ptr, ftask, ftask_nlong, tp, pa, pb, pk, Lsrc, Dsrc;
     // instance slab offsets
-    int i_Av, i_Gv, i_Atv, i_Gtv, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
+    int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets
     int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;

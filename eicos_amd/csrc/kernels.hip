@@ -191,6 +191,32 @@ __device__ __forceinline__ void for_cones(int ps, Body &&body) {
 
 #define FOR_T(i, cnt) for (int i = threadIdx.x; i < (cnt); i += T)
 
+// Row products over a sliced-ELL plan (no levels): sum_r = sum_k val[r,k] * x[idx[r,k]], unit-stride
+// index/value loads, g lanes per row, epi(row, sum) on one lane per row.
+template <int T, class V, class X, class Epi>
+__device__ __forceinline__ void ell_dots(const SliceMeta EICOS_GLOBAL *sm, int ns, gint_p eidx, V eval, X x, int dummy_slot,
+                                         Epi &&epi) {
+    const int t = threadIdx.x;
+    for (int s = 0; s < ns; s++) {
+        SliceMeta m = sm[s];
+        m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off);
+        const int lanes = m.cnt << m.lg;
+        const bool act = t < lanes;
+        double acc = 0.;
+        int kk = 0;
+        for (; kk + ELL_KMAX <= m.K; kk += ELL_KMAX) { // batches of ELL_KMAX independent loads
+            int ii[ELL_KMAX]; double vv[ELL_KMAX];
+#pragma unroll
+            for (int u = 0; u < ELL_KMAX; u++) { const int slot = act ? m.off + (kk + u) * lanes + t : dummy_slot; ii[u] = eidx[slot]; vv[u] = eval[slot]; }
+#pragma unroll
+            for (int u = 0; u < ELL_KMAX; u++) acc += vv[u] * x[ii[u]];
+        }
+        for (; kk < m.K; kk++) { const int slot = act ? m.off + kk * lanes + t : dummy_slot; acc += eval[slot] * x[eidx[slot]]; }
+        for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc);
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  On gfx9-family parts loads and stores share
 // the vmcnt counter, so __syncthreads() (release fence) drains every outstanding global LOAD as
 // well -- which would serialise the software prefetch below behind each level barrier.  The
@@ -494,7 +520,7 @@ template <int T>
 __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
-    gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, Atv = I + P.i_Atv, Gtv = I + P.i_Gtv;
+    gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
     gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
     gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
     gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
@@ -504,13 +530,13 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     // ---- computeResiduals (ref :643-689) + updateStatistics (ref :691-754) ----
     const double tau = wi.tau;
     double r8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hresx2 rx2 cx nx2 | hresy2 ry2 by ny2
-    col_dots_AG<T>(ps, Av, Gv, P.Air, P.Gir, wy, wz, [&](int j, double s) {
+    ell_dots<T>(P.cag_sl, P.cag_ns, P.cag_idx_yz, cagv, wy, P.cag_slots, [&](int j, double s) { // -G'z - A'y: (y,z) contiguous
         const double hr = -s, c_ = cv[j], xj = wx[j];
         const double r = hr - tau * c_;
         rx[j] = r;
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
-    seg_dots<T>(0, p, P.At_ptr, P.At_col, Atv, wx, P.At_long, P.nAt_long, [&](int r, double s) {
+    ell_dots<T>(P.rA_sl, P.rA_ns, P.rA_idx, rAv, wx, P.rA_slots, [&](int r, double s) {
         const double b_ = bv[r], yr = wy[r];
         const double rr = s - tau * b_;
         ry[r] = rr;
@@ -518,7 +544,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
     double q6[6] = {0, 0, 0, 0, 0, 0}; // hresz2 rz2 hz nz2 ns2 gap
-    seg_dots<T>(0, m, P.Gt_ptr, P.Gt_col, Gtv, wx, P.Gt_long, P.nGt_long, [&](int i, double s) {
+    ell_dots<T>(P.rG_sl, P.rG_ns, P.rG_idx, rGv, wx, P.rG_slots, [&](int i, double s) {
         const double si = wsl[i], zi = wz[i], h_ = hv[i];
         const double hr = si + s, r = hr - tau * h_;
         rz[i] = r;
@@ -687,7 +713,7 @@ template <int T, int NLDS>
 __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     STAGE_PROLOGUE
     stage = uni(stage);
-    gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, Atv = I + P.i_Atv, Gtv = I + P.i_Gtv;
+    gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
     gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b;
     gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
     gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz, rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;
@@ -713,6 +739,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         gcdbl_p bx = rhs, by = rhs + n, bz = rhs + np;
         auto ex = ek, ey = ek + n, ez = ek + np;
         auto xz = xk + np; // expanded dz ("dz_true")
+        if (tid == 0) xk[N] = 0.; // slot N: gather target of ELL padding
         double nr = 0.;
         FOR_T(i, N) nr = fmax(nr, fabs(rhs[i]));
         nr = blk_reduce1<OpMax, T>(phase, nr);
@@ -752,17 +779,17 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             k++;
             // ex = bx - G'dz - A'dy - delta dx   (ref :1515-1521); dz, dy read straight from xk
             double nex = 0., ney = 0., nez = 0.;
-            col_dots_AG<T>(ps, Av, Gv, P.Air_k, P.Gir_k, xk, xk, [&](int j, double s) {
+            ell_dots<T>(P.cag_sl, P.cag_ns, P.cag_idx_k, cagv, xk, P.cag_slots, [&](int j, double s) {
                 const double e = bx[j] - s - DELTASTAT * xk[j];
                 ex[j] = e; nex = fmax(nex, fabs(e));
             });
             // ey = by - A dx + delta dy   (ref :1525-1531)
-            seg_dots<T>(0, p, P.At_ptr, P.At_col, Atv, xk, P.At_long, P.nAt_long, [&](int r, double s) {
+            ell_dots<T>(P.rA_sl, P.rA_ns, P.rA_idx, rAv, xk, P.rA_slots, [&](int r, double s) {
                 const double e = by[r] - s + DELTASTAT * xk[n + r];
                 ey[r] = e; ney = fmax(ney, fabs(e));
             });
             // ez (rows of G) = bz - G dx +/- delta dz  (ref :1535-1555), then + V dz_true
-            seg_dots<T>(0, m, P.Gt_ptr, P.Gt_col, Gtv, xk, P.Gt_long, P.nGt_long, [&](int i, double s) {
+            ell_dots<T>(P.rG_sl, P.rG_ns, P.rG_idx, rGv, xk, P.rG_slots, [&](int i, double s) {
                 const int e = P.zexp[i];
                 double v = bz[e] - s + (double)P.zdsign[i] * DELTASTAT * xz[e];
                 if (i < l) { v += init ? xz[e] : lpv[i] * xz[e]; nez = fmax(nez, fabs(v)); }
@@ -1049,7 +1076,7 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
     gdbl_p xt = (gdbl_p)scratch + (size_t)blockIdx.x * (size_t)(n + p + m), at = xt + n, gt = at + p;
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         gdbl_p I = (gdbl_p)inst + (size_t)(first + q) * P.inst_stride;
-        gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, Atv = I + P.i_Atv, Gtv = I + P.i_Gtv;
+        gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
         gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
         DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
         const bool was_eq = ginfo->equilibrated != 0;
@@ -1110,9 +1137,12 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
         FOR_T(j, n) cv[j] /= xe[j];
         FOR_T(r, p) bv[r] /= ae[r];
         FOR_T(i, m) hv[i] /= ge[i];
-        // transposed value copies (reference Gt/At, :2078-2079)
-        FOR_T(k, P.nnzA) Atv[k] = Av[P.At_pos[k]];
-        FOR_T(k, P.nnzG) Gtv[k] = Gv[P.Gt_pos[k]];
+        // sliced-ELL value copies for the products (stand in for the reference's Gt/At, :2078-2079);
+        // *_src is relative to Av (G values follow at i_Gv - i_Av); padding and the dummy slot get 0
+        __syncthreads();
+        FOR_T(k, P.cag_slots + 1) { const int e = P.cag_src[k]; cagv[k] = e < 0 ? 0. : Av[e]; }
+        FOR_T(k, P.rA_slots + 1) { const int e = P.rA_src[k]; rAv[k] = e < 0 ? 0. : Av[e]; }
+        FOR_T(k, P.rG_slots + 1) { const int e = P.rG_src[k]; rGv[k] = e < 0 ? 0. : Av[e]; }
         // static-regularisation constants read by the factor program
         if (threadIdx.x == 0) {
             gdbl_p cst = I + P.i_cst;

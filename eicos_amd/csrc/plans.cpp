@@ -50,4 +50,37 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
     return pl;
 }
 
+EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T) {
+    EllPlan pl;
+    auto len = [&](int r) { return ptr[r + 1] - ptr[r]; };
+    auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
+    int r = 0;
+    while (r < nrows) {
+        // grow the slice while the lanes-per-row factor of its longest row still lets it fit in T lanes
+        int mx = len(r), cnt = 1;
+        auto gof = [&](int m) { return std::max(1, std::min(64, pow2ceil((m + ELL_KMAX - 1) / ELL_KMAX))); };
+        while (r + cnt < nrows) {
+            const int m2 = std::max(mx, len(r + cnt));
+            if ((cnt + 1) * gof(m2) > T) break;
+            // do not let one very long row force many lanes on a run of short rows
+            if (gof(m2) > gof(mx) && cnt >= 32) break;
+            mx = m2; cnt++;
+        }
+        const int g = gof(mx), K = (mx + g - 1) / g, lanes = cnt * g;
+        int lg = 0;
+        while ((1 << lg) < g) lg++;
+        pl.sl.push_back(SliceMeta{r, cnt, lg, K, pl.slots, 0, 0, 0});
+        pl.src.resize((size_t)pl.slots + (size_t)K * lanes, -1);
+        for (int i = r; i < r + cnt; i++)
+            for (int e = ptr[i]; e < ptr[i + 1]; e++) {
+                const int j = e - ptr[i], q = j % g, kk = j / g;
+                pl.src[pl.slots + kk * lanes + (i - r) * g + q] = e;
+            }
+        pl.slots += K * lanes;
+        r += cnt;
+    }
+    pl.src.push_back(-1); // dummy slot (index `slots`)
+    return pl;
+}
+
 } // namespace eicos

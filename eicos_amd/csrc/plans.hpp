@@ -17,4 +17,13 @@ struct TriPlan {
 // T = workgroup size the plan is laid out for.
 TriPlan build_tri_plan(const Symbolic &S, int T, bool forward);
 
+// Sliced-ELL plan of a plain row-wise sparse product (no levels): rows [0,nrows) of a CSR-like
+// pattern `ptr`, consecutive rows per slice.  src[slot] = CSR entry stored in that slot, -1 = padding.
+struct EllPlan {
+    std::vector<SliceMeta> sl;
+    std::vector<int> src;
+    int slots = 0;
+};
+EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T);
+
 } // namespace eicos

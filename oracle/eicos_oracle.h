@@ -49,9 +49,10 @@ int oracle_get_trace(void *s, double *out, int max_rows);
 void oracle_destroy(void *s);
 
 /* CPU-baseline driver: solve `batch` instances that share one pattern, one instance at a
- * time per thread (first instance via the constructor, the rest via oracle_update --
- * the reference's updateData path, src/run.cpp:34-50).  Arrays are [batch][...].
- * Returns wall seconds of the solve phase only (update time returned via *update_s). */
+ * time per thread.  Each thread constructs its solver once (pattern setup, untimed), then all
+ * threads start together and every instance goes through oracle_update + oracle_solve (the
+ * reference's updateData path, src/run.cpp:34-50).  Arrays are [batch][...].  Returns the wall
+ * seconds attributed to solve; the updateData share of the same wall time goes to *update_s. */
 double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,
                           const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                           int batch, const double *Gpr, const double *Apr,
