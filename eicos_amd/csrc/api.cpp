@@ -154,20 +154,27 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     for (size_t sl = 0; sl < pcag.src.size(); sl++) {
         const int e = pcag.src[sl];
         cag_src[sl] = e < 0 ? -1 : cag_val[e];
-        cag_idx_k[sl] = e < 0 ? S.N : cag_k[e];                                  // padding gathers the zero slot N of x
+        cag_idx_k[sl] = e < 0 ? S.N : S.iperm[cag_k[e]];                         // elimination order; padding -> zero slot N
         cag_idx_yz[sl] = e < 0 ? 0 : (cag_yz[e] >= 0 ? cag_yz[e] : (D.i_z - D.i_y) + (-1 - cag_yz[e])); // offset from y
     }
     std::vector<int> rA_idx(prA.src.size()), rA_src(prA.src.size()), rG_idx(prG.src.size()), rG_src(prG.src.size());
-    for (size_t sl = 0; sl < prA.src.size(); sl++) { const int e = prA.src[sl]; rA_src[sl] = e < 0 ? -1 : S.At_pos[e]; rA_idx[sl] = e < 0 ? 0 : S.At_col[e]; }
-    for (size_t sl = 0; sl < prG.src.size(); sl++) { const int e = prG.src[sl]; rG_src[sl] = e < 0 ? -1 : gv_rel + S.Gt_pos[e]; rG_idx[sl] = e < 0 ? 0 : S.Gt_col[e]; }
+    std::vector<int> rA_idx_k(prA.src.size()), rG_idx_k(prG.src.size());
+    for (size_t sl = 0; sl < prA.src.size(); sl++) { const int e = prA.src[sl]; rA_src[sl] = e < 0 ? -1 : S.At_pos[e]; rA_idx[sl] = e < 0 ? 0 : S.At_col[e]; rA_idx_k[sl] = e < 0 ? S.N : S.iperm[S.At_col[e]]; }
+    for (size_t sl = 0; sl < prG.src.size(); sl++) { const int e = prG.src[sl]; rG_src[sl] = e < 0 ? -1 : gv_rel + S.Gt_pos[e]; rG_idx[sl] = e < 0 ? 0 : S.Gt_col[e]; rG_idx_k[sl] = e < 0 ? S.N : S.iperm[S.Gt_col[e]]; }
+    std::vector<int> ipx(S.n), ipy(S.p), ipz(S.m), ipv(S.nc), ipu(S.nc);
+    for (int j = 0; j < S.n; j++) ipx[j] = S.iperm[j];
+    for (int r = 0; r < S.p; r++) ipy[r] = S.iperm[S.n + r];
+    for (int i = 0; i < S.m; i++) ipz[i] = S.iperm[S.n + S.p + zexp0[i]];
+    for (int c = 0; c < S.nc; c++) { const int e0 = S.n + S.p + S.cone_off[c] + 2 * c + S.q[c]; ipv[c] = S.iperm[e0]; ipu[c] = S.iperm[e0 + 1]; }
     D.inst_stride = L.size;
     SlabLayout Wl;
     D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m); D.w_blam = Wl.add(S.m);
-    D.w_rx = Wl.add(S.n); D.w_ry = Wl.add(S.p); D.w_rz = Wl.add(S.m); D.w_rhs1 = Wl.add(S.N); D.w_rhs2 = Wl.add(S.N);
+    D.w_rx = Wl.add(S.n); D.w_ry = Wl.add(S.p); D.w_rz = Wl.add(S.m); D.w_rhs1 = Wl.add((size_t)S.N + 16); D.w_rhs2 = Wl.add((size_t)S.N + 16); // elimination order
+    D.w_rhs1k = Wl.add((size_t)S.n + S.p + S.m); D.w_rhs2k = Wl.add((size_t)S.n + S.p + S.m);       // [x | y | z] order
     D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
-    D.w_xk = Wl.add((size_t)S.N + 16); D.w_ek = Wl.add(S.N); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
+    D.w_xk = Wl.add((size_t)S.N + 16); D.w_ek = Wl.add((size_t)S.N + 16); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
     D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N); // w_UF / w_UB are added once the slice plans are known
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
 
@@ -248,6 +255,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(fsl_p, fsl_i); put(bsl_p, bsl_i); put(cag_sl_p, cag_sl_i); put(rA_sl_p, rA_sl_i); put(rG_sl_p, rG_sl_i);
     put(D.cag_idx_k, cag_idx_k); put(D.cag_idx_yz, cag_idx_yz); put(D.cag_src, cag_src);
     put(D.rA_idx, rA_idx); put(D.rA_src, rA_src); put(D.rG_idx, rG_idx); put(D.rG_src, rG_src);
+    put(D.rA_idx_k, rA_idx_k); put(D.rG_idx_k, rG_idx_k);
+    put(D.ipx, ipx); put(D.ipy, ipy); put(D.ipz, ipz); put(D.ipv, ipv); put(D.ipu, ipu);
     put(D.ftask_ptr, S.ftask_ptr); put(D.ftask, S.ftask); put(D.ftask_nlong, ftask_nlong); put(D.tp, tp32);
     put(D.pa, pa2); put(D.pb, pb2); put(D.pk, S.pk); put(D.Lsrc, Lsrc); put(D.Dsrc, Dsrc);
 
@@ -270,13 +279,12 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
         // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
         // all-global variant (NLDS = 0, plain __syncthreads between levels) is used
-        int fit = (meta + vec <= avail) ? (int)std::min<size_t>(3, (avail - meta) / vec) : 0;
-        if (S.N == 0) fit = 0;
-        // More than one instance per CU: keep only the solve vector in LDS so that two 512-thread workgroups
-        // share a CU (measured on MI355X, MPC02 pattern: 2 x NLDS=1 beats 1 x NLDS=3 once the batch exceeds
-        // the CU count); a batch that fits one-per-CU takes every vector it can into LDS.
+        // KKT-space vectors in LDS: E (rhs / residual / solve vector) and X (current solution), + both slice tables
+        int fit = 0;
+        if (S.N > 0 && meta + vec <= avail) fit = (meta + 2 * vec <= avail) ? 2 : 1;
+        // more instances than CUs: keep only E in LDS so that several workgroups share a CU (measured)
         int want = fit;
-        if (batch > prop.multiProcessorCount && fit >= 1 && 2 * (vec + meta) + 8192 <= 160 * 1024) want = 1;
+        if (batch > prop.multiProcessorCount && fit == 2 && 2 * (vec + meta + 4096) <= 160 * 1024) want = 1;
         h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want)));
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
         h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : 0;

@@ -55,7 +55,10 @@ struct DevPat {
     // offsets into the contiguous (y, z) block of the instance slab (residuals).
     const SliceMeta EICOS_GLOBAL *cag_sl; const SliceMeta EICOS_GLOBAL *rA_sl; const SliceMeta EICOS_GLOBAL *rG_sl;
     int cag_ns, rA_ns, rG_ns, cag_slots, rA_slots, rG_slots;
-    gint_p cag_idx_k, cag_idx_yz, cag_src, rA_idx, rA_src, rG_idx, rG_src;
+    gint_p cag_idx_k, cag_idx_yz, cag_src, rA_idx, rA_idx_k, rA_src, rG_idx, rG_idx_k, rG_src;
+    // KKT-space vectors live in the (level-ordered) elimination order on the device: position of
+    // variable j / equality row r / cone-block row i / the v- and u-expansion slot of cone c
+    gint_p ipx, ipy, ipz, ipv, ipu;
     // cones
     gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;
@@ -73,7 +76,7 @@ struct DevPat {
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets
-    int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2;
+    int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2, w_rhs1k, w_rhs2k;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
     int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_ws, w_UF, w_UB, w_D, w_invD, w_trace;
     size_t inst_stride, work_stride; // in doubles

@@ -72,7 +72,7 @@ enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_INIT, TK_COUNT };
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
 __shared__ Sh g_S;
-extern __shared__ double g_dyn[]; // NLDS KKT-space vectors of P.Npad doubles: ws [, xk [, ek]]
+extern __shared__ double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | slice tables of both sweeps
 
 // Arguments of non-inlined device functions arrive in VGPRs; the values below are workgroup-uniform,
 // so move them to SGPRs: address math and branches on them become scalar (s_load, s_cbranch) instead
@@ -716,112 +716,112 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
     gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b;
     gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
-    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz, rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;
+    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
+    gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;     // elimination order (what the triangular sweeps consume)
+    gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k; // same values as [x | y | z] (what the residual reads)
     gdbl_p dx1 = W + P.w_dx1, dy1 = W + P.w_dy1, dz1 = W + P.w_dz1, dx2 = W + P.w_dx2, dy2 = W + P.w_dy2, dz2 = W + P.w_dz2;
     gdbl_p dsw = W + P.w_dsw, wdz = W + P.w_wdz, dsa = W + P.w_dsa, t1 = W + P.w_t1, t2 = W + P.w_t2;
     gdbl_p lpw = W + P.w_lpw, lpv = W + P.w_lpv, csc = W + P.w_csc, qv = W + P.w_qv;
-    // KKT-space vectors: in LDS when they fit (NLDS of them), else in the workspace slab
-    // KKT-space vectors: LDS when they fit (NLDS of them), else the workspace slab (typed per instantiation)
-    auto xk = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else return W + P.w_xk; }();
-    auto ek = [&] { if constexpr (NLDS >= 3) return g_dyn + 2 * P.Npad; else return W + P.w_ek; }();
+    // KKT-space vectors, in elimination order: X = current solution, E = rhs / residual / solve vector.
+    // Both in LDS (NLDS = 2) or both in the workspace slab (NLDS = 0, patterns too large for LDS).
+    // Roles: SV = vector the triangular sweeps run on; X = solution the residual gathers from; E = where the
+    // residual is written.  NLDS = 2: SV = E and X both in LDS.  NLDS = 1 (one LDS vector, several workgroups
+    // per CU): the LDS vector alternates between the sweep vector and X -- the ~25k gathers of a residual hit
+    // LDS, its ~N scattered stores go to E in the workspace slab, X's master copy (Xg) is updated with
+    // unit-stride read-modify-writes.  NLDS = 0: everything in the workspace slab.
+    auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return W + P.w_ek; }();
+    auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return W + P.w_xk; }();
+    auto E = [&] { if constexpr (NLDS == 1) return W + P.w_ek; else return SV; }();
+    gdbl_p Xg = W + P.w_xk;
     gdbl_p dxr = W + P.w_dxr;
     gdbl_p UF = W + P.w_UF, UB = W + P.w_UB, invD = W + P.w_invD;
     __syncthreads();
     TICK_BEGIN;
     const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
-    auto rhs = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? rhs1 : rhs2;
-    auto dx = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dx1 : dx2;
-    auto dy = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dy1 : dy2;
-    auto dz = (stage == ST_KKT_INIT1 || stage == ST_KKT1) ? dz1 : dz2;
+    const bool first = (stage == ST_KKT_INIT1 || stage == ST_KKT1);
+    gcdbl_p rhsp = first ? rhs1 : rhs2, rhsk = first ? rhs1k : rhs2k;
+    gdbl_p dx = first ? dx1 : dx2, dy = first ? dy1 : dy2, dz = first ? dz1 : dz2;
     int kref;
     {
         // ---------------- solveKKT (ref :1471-1620) ----------------
-        gcdbl_p bx = rhs, by = rhs + n, bz = rhs + np;
-        auto ex = ek, ey = ek + n, ez = ek + np;
-        auto xz = xk + np; // expanded dz ("dz_true")
-        if (tid == 0) xk[N] = 0.; // slot N: gather target of ELL padding
+        gcdbl_p bx = rhsk, by = rhsk + n, bz = rhsk + np;
         double nr = 0.;
-        FOR_T(i, N) nr = fmax(nr, fabs(rhs[i]));
+        FOR_T(i, P.Npad) { const double v = (i < N) ? rhsp[i] : 0.; SV[i] = v; nr = fmax(nr, fabs(v)); } // slots >= N stay 0
         nr = blk_reduce1<OpMax, T>(phase, nr);
         const double thr = (1. + nr) * LINSYSACC;
         double nerr_prev = DBL_MAX;
         int k = -1;
         for (;;) {
-            // -------- x = P' L^-T D^-1 L^-1 P rhs (replaces ldlt.solve, ref :1477,1599) --------
-            {
-                auto run = [&](auto ws) {
-                    // permute in (first solve: rhs, refinement: the residual e); slots >= N stay 0 (ELL padding)
-                    if (k < 0) { FOR_T(i, P.Npad) ws[i] = (i < N) ? rhs[P.perm[i]] : 0.; }
-                    else { FOR_T(i, P.Npad) ws[i] = (i < N) ? ek[P.perm[i]] : 0.; }
-                    // slice tables: staged in LDS behind the vectors when they fit (P.meta_lds), else read from L2
-                    __syncthreads();
-                    if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-                        const SliceMeta *fsl = reinterpret_cast<const SliceMeta *>(g_dyn + (size_t)NLDS * P.Npad);
-                        tri_sweep<T, true, true>(fsl, P.nfs, P.f_idx, UF, invD, ws, P.nUF); // barriers at level starts + end
-                        tri_sweep<T, false, true>(fsl + P.nfs, P.nbs, P.b_idx, UB, invD, ws, P.nUB);
-                    } else {
-                        tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, ws, P.nUF);
-                        tri_sweep<T, false, false>(P.bsl, P.nbs, P.b_idx, UB, invD, ws, P.nUB);
-                    }
-                    FOR_T(jn, N) { // permute out; a refinement solve also adds its correction to x (ref :1602)
-                        const double xj = ws[jn];
-                        const int o = P.perm[jn];
-                        if (k < 0) xk[o] = xj;
-                        else { dxr[o] = xj; xk[o] += xj; }
-                    }
-                    __syncthreads();
-                };
-                TICK_END(TK_KRES);
-                if constexpr (NLDS >= 1) run(g_dyn); else run(W + P.w_ws);
-                if (tid == 0) wi.n_ldlsolve++;
-                TICK_END(TK_LDL);
+            // -------- SV <- L^-T D^-1 L^-1 SV in elimination order (replaces ldlt.solve, ref :1477,1599) --------
+            TICK_END(TK_KRES);
+            __syncthreads();
+            if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
+                const SliceMeta *fsl = reinterpret_cast<const SliceMeta *>(g_dyn + (size_t)NLDS * P.Npad);
+                tri_sweep<T, true, true>(fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
+                tri_sweep<T, false, true>(fsl + P.nfs, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
+            } else {
+                tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, false>(P.bsl, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
             }
+            if constexpr (NLDS == 1) { // the LDS vector becomes X again; master copy in the slab
+                if (k < 0) { FOR_T(i, N) Xg[i] = SV[i]; }
+                else { FOR_T(i, N) { const double dv = SV[i]; const double xv = Xg[i] + dv; dxr[i] = dv; Xg[i] = xv; SV[i] = xv; } }
+            } else {
+                if (k < 0) { FOR_T(i, P.Npad) X[i] = SV[i]; }                               // x = first solve (slot N.. = 0)
+                else { FOR_T(i, N) { const double dv = SV[i]; dxr[i] = dv; X[i] += dv; } } // x += dx_ref (ref :1602)
+            }
+            if (tid == 0) wi.n_ldlsolve++;
+            __syncthreads();
+            TICK_END(TK_LDL);
             k++;
-            // ex = bx - G'dz - A'dy - delta dx   (ref :1515-1521); dz, dy read straight from xk
+            // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
             double nex = 0., ney = 0., nez = 0.;
-            ell_dots<T>(P.cag_sl, P.cag_ns, P.cag_idx_k, cagv, xk, P.cag_slots, [&](int j, double s) {
-                const double e = bx[j] - s - DELTASTAT * xk[j];
-                ex[j] = e; nex = fmax(nex, fabs(e));
+            ell_dots<T>(P.cag_sl, P.cag_ns, P.cag_idx_k, cagv, X, P.cag_slots, [&](int j, double s) {
+                const int o = P.ipx[j];
+                const double e = bx[j] - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
+                E[o] = e; nex = fmax(nex, fabs(e));
             });
-            // ey = by - A dx + delta dy   (ref :1525-1531)
-            ell_dots<T>(P.rA_sl, P.rA_ns, P.rA_idx, rAv, xk, P.rA_slots, [&](int r, double s) {
-                const double e = by[r] - s + DELTASTAT * xk[n + r];
-                ey[r] = e; ney = fmax(ney, fabs(e));
+            ell_dots<T>(P.rA_sl, P.rA_ns, P.rA_idx_k, rAv, X, P.rA_slots, [&](int r, double s) {
+                const int o = P.ipy[r];
+                const double e = by[r] - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
+                E[o] = e; ney = fmax(ney, fabs(e));
             });
-            // ez (rows of G) = bz - G dx +/- delta dz  (ref :1535-1555), then + V dz_true
-            ell_dots<T>(P.rG_sl, P.rG_ns, P.rG_idx, rGv, xk, P.rG_slots, [&](int i, double s) {
-                const int e = P.zexp[i];
-                double v = bz[e] - s + (double)P.zdsign[i] * DELTASTAT * xz[e];
-                if (i < l) { v += init ? xz[e] : lpv[i] * xz[e]; nez = fmax(nez, fabs(v)); }
-                ez[e] = v;
+            ell_dots<T>(P.rG_sl, P.rG_ns, P.rG_idx_k, rGv, X, P.rG_slots, [&](int i, double s) {
+                const int o = P.ipz[i];
+                const double xo = X[o];
+                double v = bz[i] - s + (double)P.zdsign[i] * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
+                if (i < l) { v += init ? xo : lpv[i] * xo; nez = fmax(nez, fabs(v)); } // ... + V dz (LP part)
+                E[o] = v;
             });
             if (P.nc > 0) {
                 __syncthreads();
                 // cone blocks (expanded): ez += dz_true (init) or scale2add (ref :1629-1662)
                 for_cones<T>(ps, [&](int c, auto G, int ln) {
                     constexpr int g = decltype(G)::value;
-                    const int d = P.cq[c], o = P.cone_off[c], i1 = o + 2 * c, i3 = i1 + d, i4 = i3 + 1;
+                    const int d = P.cq[c], o = P.cone_off[c];
+                    const int p1 = P.ipz[o], p3 = P.ipv[c], p4 = P.ipu[c];
                     double mx = 0.;
                     if (init) {
-                        for (int q = ln; q < d; q += g) { const double v = ez[i1 + q] + xz[i1 + q]; ez[i1 + q] = v; mx = fmax(mx, fabs(v)); }
-                        if (ln == 0) { ez[i3] = xz[i3]; ez[i4] = xz[i4]; mx = fmax(mx, fmax(fabs(xz[i3]), fabs(xz[i4]))); }
+                        for (int q = ln; q < d; q += g) { const int pq = P.ipz[o + q]; const double v = E[pq] + X[pq]; E[pq] = v; mx = fmax(mx, fabs(v)); }
+                        if (ln == 0) { const double x3 = X[p3], x4 = X[p4]; E[p3] = x3; E[p4] = x4; mx = fmax(mx, fmax(fabs(x3), fabs(x4))); }
                     } else {
                         gcdbl_p cs = csc + c * CSC_STRIDE;
-                        const double eta2 = cs[CS_ETA2], x1 = xz[i1], x3 = xz[i3], x4 = xz[i4];
+                        const double eta2 = cs[CS_ETA2], x1 = X[p1], x3 = X[p3], x4 = X[p4];
                         const double tt = cs[CS_V1] * x3 + cs[CS_U1] * x4;
                         double qtx = 0.;
                         for (int q = 1 + ln; q < d; q += g) {
-                            const double qq = qv[o + q], xq = xz[i1 + q];
-                            const double v = ez[i1 + q] + eta2 * (xq + tt * qq);
-                            ez[i1 + q] = v; mx = fmax(mx, fabs(v));
+                            const int pq = P.ipz[o + q];
+                            const double qq = qv[o + q], xq = X[pq];
+                            const double v = E[pq] + eta2 * (xq + tt * qq);
+                            E[pq] = v; mx = fmax(mx, fabs(v));
                             qtx += qq * xq;
                         }
                         qtx = grp_sum<g>(qtx);
                         if (ln == 0) {
-                            const double v1 = ez[i1] + eta2 * (cs[CS_D1] * x1 + cs[CS_U0] * x4);
+                            const double v1 = E[p1] + eta2 * (cs[CS_D1] * x1 + cs[CS_U0] * x4);
                             const double v3 = eta2 * (cs[CS_V1] * qtx + x3);
                             const double v4 = eta2 * (cs[CS_U0] * x1 + cs[CS_U1] * qtx - x4);
-                            ez[i1] = v1; ez[i3] = v3; ez[i4] = v4;
+                            E[p1] = v1; E[p3] = v3; E[p4] = v4;
                             mx = fmax(mx, fmax(fabs(v1), fmax(fabs(v3), fabs(v4))));
                         }
                     }
@@ -833,17 +833,19 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             double nerr = fmax(nv[0], nv[2]);
             if (p > 0) nerr = fmax(nerr, nv[1]);
             if (k > 0 && nerr > nerr_prev) { // got worse: undo and quit (ref :1579-1585)
-                FOR_T(i, N) xk[i] -= dxr[i];
+                if constexpr (NLDS == 1) { FOR_T(i, N) { const double xv = Xg[i] - dxr[i]; Xg[i] = xv; X[i] = xv; } }
+                else { FOR_T(i, N) X[i] -= dxr[i]; }
                 k--;
                 break;
             }
             if (k == NITREF || nerr < thr || (k > 0 && nerr_prev < IRERRFACT * nerr)) break;
             nerr_prev = nerr;
+            if constexpr (NLDS == 1) { __syncthreads(); FOR_T(i, N) SV[i] = E[i]; } // residual -> sweep vector (unit stride)
         }
         __syncthreads();
-        FOR_T(j, n) dx[j] = xk[j];
-        FOR_T(j, p) dy[j] = xk[n + j];
-        FOR_T(i, m) dz[i] = xz[P.zexp[i]];
+        FOR_T(j, n) dx[j] = X[P.ipx[j]];
+        FOR_T(r, p) dy[r] = X[P.ipy[r]];
+        FOR_T(i, m) dz[i] = X[P.ipz[i]];
         __syncthreads();
         kref = k;
         TICK_END(TK_KRES);
@@ -858,7 +860,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     } else if (stage == ST_KKT_INIT2) { // ref :966-992
         FOR_T(j, p) wy[j] = dy2[j];
         dev_bring_to_cone<T>(ps, dz2, 1., wz);
-        FOR_T(j, n) rhs1[j] = -cv[j];
+        FOR_T(j, n) { const double v = -cv[j]; rhs1[P.ipx[j]] = v; rhs1k[j] = v; }
         if (tid == 0) {
             wi.nitref2 = kref;
             wi.kap = 1.; wi.tau = 1.; wi.step = 0.; wi.step_aff = 0.; wi.pinf = 0; wi.dinf = 0;
@@ -867,9 +869,9 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         __syncthreads();
         stage = ST_RESID;
     } else if (stage == ST_KKT1) { // RHSaffine (ref :1670-1689)
-        FOR_T(j, n) rhs2[j] = rx[j];
-        FOR_T(r, p) rhs2[n + r] = -ry[r];
-        FOR_T(i, m) rhs2[np + P.zexp[i]] = wsl[i] - rz[i];
+        FOR_T(j, n) { const double v = rx[j]; rhs2[P.ipx[j]] = v; rhs2k[j] = v; }
+        FOR_T(r, p) { const double v = -ry[r]; rhs2[P.ipy[r]] = v; rhs2k[n + r] = v; }
+        FOR_T(i, m) { const double v = wsl[i] - rz[i]; rhs2[P.ipz[i]] = v; rhs2k[np + i] = v; } // expansion slots stay 0
         __syncthreads();
         stage = ST_KKT_AFF;
     } else if (stage == ST_KKT_AFF) { // ref :1181-1210
@@ -940,8 +942,9 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             });
         }
         __syncthreads();
-        FOR_T(j, np) rhs2[j] *= oms;
-        FOR_T(i, m) rhs2[np + P.zexp[i]] = -oms * rz[i] + t1[i];
+        FOR_T(j, n) { const double v = rhs2k[j] * oms; rhs2k[j] = v; rhs2[P.ipx[j]] = v; }
+        FOR_T(r, p) { const double v = rhs2k[n + r] * oms; rhs2k[n + r] = v; rhs2[P.ipy[r]] = v; }
+        FOR_T(i, m) { const double v = -oms * rz[i] + t1[i]; rhs2k[np + i] = v; rhs2[P.ipz[i]] = v; }
         __syncthreads();
         stage = ST_KKT_COMB;
     } else { // ST_KKT_COMB, ref :1212-1252
@@ -987,7 +990,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     DevInfo &wi = g_S.wi;
     {
         gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
-        gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;
+        gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2, rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k;
         int phase = 0;
     __syncthreads();
         if (tid == 0) { // sticky across solve() calls like the reference's w.i
@@ -1008,12 +1011,13 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
         });
         // rhs1 = [0; b; h expanded], rhs2 = [-c; 0; 0]   (ref :865-886)
         FOR_T(i, N) { rhs1[i] = 0.; rhs2[i] = 0.; }
+        FOR_T(i, np + m) { rhs1k[i] = 0.; rhs2k[i] = 0.; }
         __syncthreads();
         {
             double nr3[3] = {0., 0., 0.};
-            FOR_T(j, n) { const double c_ = cv[j]; rhs2[j] = -c_; nr3[0] += c_ * c_; }
-            FOR_T(r, p) { const double b_ = bv[r]; rhs1[n + r] = b_; nr3[1] += b_ * b_; }
-            FOR_T(i, m) { const double h_ = hv[i]; rhs1[np + P.zexp[i]] = h_; nr3[2] += h_ * h_; }
+            FOR_T(j, n) { const double c_ = cv[j]; rhs2[P.ipx[j]] = -c_; rhs2k[j] = -c_; nr3[0] += c_ * c_; }
+            FOR_T(r, p) { const double b_ = bv[r]; rhs1[P.ipy[r]] = b_; rhs1k[n + r] = b_; nr3[1] += b_ * b_; }
+            FOR_T(i, m) { const double h_ = hv[i]; rhs1[P.ipz[i]] = h_; rhs1k[np + i] = h_; nr3[2] += h_ * h_; }
             blk_reduce<OpSum, T, 3>(phase, nr3);
             if (tid == 0) {
                 g_S.sv[SV_RESX0] = fmax(1., sqrt(nr3[0])); g_S.sv[SV_RESY0] = fmax(1., sqrt(nr3[1])); g_S.sv[SV_RESZ0] = fmax(1., sqrt(nr3[2]));
@@ -1176,12 +1180,9 @@ __global__ __launch_bounds__(T) void k_debug_factor(int ps, double *inst, double
 template <class F> static auto dispatch_solve(int threads, int nlds, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        switch (nlds) {
-        case 0: return f((const void *)k_solve<T, 0>);
-        case 1: return f((const void *)k_solve<T, 1>);
-        case 2: return f((const void *)k_solve<T, 2>);
-        default: return f((const void *)k_solve<T, 3>);
-        }
+        if (nlds >= 2) return f((const void *)k_solve<T, 2>);
+        if (nlds == 1) return f((const void *)k_solve<T, 1>);
+        return f((const void *)k_solve<T, 0>);
     };
     if (threads == 1024) return byT(std::integral_constant<int, 1024>{});
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
