@@ -200,12 +200,6 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         if ((P.Ajc[j + 1] - P.Ajc[j]) + (P.Gjc[j + 1] - P.Gjc[j]) > LONG_SEG) AG_long.push_back(j);
     for (int r = 0; r < S.p; r++) if (S.At_ptr[r + 1] - S.At_ptr[r] > LONG_SEG) At_long.push_back(r);
     for (int r = 0; r < S.m; r++) if (S.Gt_ptr[r + 1] - S.Gt_ptr[r] > LONG_SEG) Gt_long.push_back(r);
-    std::vector<int> ftask_nlong(S.nlev, 0);
-    for (int v = 0; v < S.nlev; v++)
-        for (int t = S.ftask_ptr[v]; t < S.ftask_ptr[v + 1]; t++)
-            if (S.tp[S.ftask[t] + 1] - S.tp[S.ftask[t]] > LONG_SEG) ftask_nlong[v]++;
-    std::vector<int> tp32(S.tp.size());
-    for (size_t i = 0; i < S.tp.size(); i++) tp32[i] = (int)S.tp[i];
     auto srcoff = [&](int kind, int src) {
         switch (kind) {
         case SRC_A: return D.i_Av + src;
@@ -216,9 +210,6 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         default: return D.i_cst + 2;
         }
     };
-    std::vector<int> Lsrc(S.nnzL), Dsrc(S.N);
-    for (int e = 0; e < S.nnzL; e++) Lsrc[e] = srcoff(S.Lkind[e], S.Lsrc[e]);
-    for (int j = 0; j < S.N; j++) Dsrc[j] = srcoff(S.Dkind[j], S.Dsrc[j]);
 
 
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
@@ -227,15 +218,16 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     D.work_stride = Wl.size;
     h->posB = planB.pos;
-    // the factor program reads L.*D through the backward (column) slots
-    std::vector<int> pa2(S.pa.size()), pb2(S.pb.size());
-    for (size_t i = 0; i < S.pa.size(); i++) { pa2[i] = planB.pos[S.pa[i]]; pb2[i] = planB.pos[S.pb[i]]; }
+    // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
+    FactorPlan planX = build_factor_plan(S, h->threads, planB.pos, planB.slots);
+    D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots;
+    std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size());
     auto meta_ints = [](const std::vector<SliceMeta> &v) {
         std::vector<int> o(v.size() * 8);
         if (!v.empty()) std::memcpy(o.data(), v.data(), o.size() * sizeof(int));
         return o;
     };
-    std::vector<int> fsl_i = meta_ints(planF.sl), bsl_i = meta_ints(planB.sl);
+    std::vector<int> fsl_i = meta_ints(planF.sl), bsl_i = meta_ints(planB.sl), fac_sl_i = meta_ints(planX.sl);
     std::vector<int> cag_sl_i = meta_ints(pcag.sl), rA_sl_i = meta_ints(prA.sl), rG_sl_i = meta_ints(prG.sl);
 
     struct Slot { const int **dst; size_t off; };
@@ -257,8 +249,15 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(D.rA_idx, rA_idx); put(D.rA_src, rA_src); put(D.rG_idx, rG_idx); put(D.rG_src, rG_src);
     put(D.rA_idx_k, rA_idx_k); put(D.rG_idx_k, rG_idx_k);
     put(D.ipx, ipx); put(D.ipy, ipy); put(D.ipz, ipz); put(D.ipv, ipv); put(D.ipu, ipu);
-    put(D.ftask_ptr, S.ftask_ptr); put(D.ftask, S.ftask); put(D.ftask_nlong, ftask_nlong); put(D.tp, tp32);
-    put(D.pa, pa2); put(D.pb, pb2); put(D.pk, S.pk); put(D.Lsrc, Lsrc); put(D.Dsrc, Dsrc);
+    for (size_t t = 0; t < planX.target.size(); t++) {
+        const int tgt = planX.target[t];
+        if (tgt < S.N) { fac_src[t] = srcoff(S.Dkind[tgt], S.Dsrc[tgt]); fac_dst[t] = -tgt - 1; fac_dstF[t] = 0; }
+        else { const int e = tgt - S.N; fac_src[t] = srcoff(S.Lkind[e], S.Lsrc[e]); fac_dst[t] = planB.pos[e]; fac_dstF[t] = planF.pos[e]; }
+    }
+    const int *fac_sl_p = nullptr;
+    put(fac_sl_p, fac_sl_i);
+    put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb); put(D.fac_pk, planX.pk);
+    put(D.fac_src, fac_src); put(D.fac_dst, fac_dst); put(D.fac_dstF, fac_dstF);
 
     // ---- device resources ----
     auto bail = [&](int code, const std::string &msg) { eicos_batch_destroy(h); return fail(code, msg); };
@@ -304,6 +303,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.fsl = reinterpret_cast<const SliceMeta *>(fsl_p); D.bsl = reinterpret_cast<const SliceMeta *>(bsl_p);
     D.cag_sl = reinterpret_cast<const SliceMeta *>(cag_sl_p); D.rA_sl = reinterpret_cast<const SliceMeta *>(rA_sl_p);
     D.rG_sl = reinterpret_cast<const SliceMeta *>(rG_sl_p);
+    D.fac_sl = reinterpret_cast<const SliceMeta *>(fac_sl_p);
     {
         std::lock_guard<std::mutex> lk(g_slot_mu);
         for (int q = 0; q < max_patterns() && q < 64; q++) if (!g_slot_used[device % 16][q]) { h->pslot = q; g_slot_used[device % 16][q] = true; break; }
@@ -581,8 +581,25 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
         double plan_err = 0;
         for (int T : {256, 512, 1024}) {
             TriPlan pf = build_tri_plan(S, T, true), pb = build_tri_plan(S, T, false);
-            std::vector<double> UF(pf.slots, 0.0), UB(pb.slots, 0.0), ws(N + 1, 0.0);
-            for (int e = 0; e < S.nnzL; e++) { UF[pf.pos[e]] = U[e]; UB[pb.pos[e]] = U[e]; }
+            std::vector<double> UF(pf.slots + 1, 0.0), UB(pb.slots + 1, 0.0), ws(N + 1, 0.0);
+            { // numeric factorisation through the sliced-ELL factor plan, lane by lane as the kernel does it
+                FactorPlan px = build_factor_plan(S, T, pb.pos, pb.slots);
+                std::vector<double> D2(N, 0.0), iD2(N, 0.0);
+                for (const SliceMeta &m : px.sl) {
+                    const int g = 1 << m.lg, lanes = m.cnt * g;
+                    if (lanes > T) throw std::logic_error("factor slice wider than the workgroup");
+                    for (int r = 0; r < m.cnt; r++) {
+                        double acc = 0;
+                        for (int q = 0; q < g; q++)
+                            for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + r * g + q; acc += UB[px.pa[slot]] * UB[px.pb[slot]] * iD2[px.pk[slot]]; }
+                        const int tgt = px.target[m.row0 + r];
+                        if (tgt < N) { D2[tgt] = Dv[tgt] - acc; iD2[tgt] = 1.0 / D2[tgt]; }
+                        else { const int e = tgt - N; UB[pb.pos[e]] = Lv[e] - acc; UF[pf.pos[e]] = Lv[e] - acc; }
+                    }
+                }
+                for (int e = 0; e < S.nnzL; e++) plan_err = std::max(plan_err, std::fabs(UB[pb.pos[e]] - U[e]) / (1.0 + std::fabs(U[e])));
+                for (int jn = 0; jn < N; jn++) plan_err = std::max(plan_err, std::fabs(D2[jn] - D[jn]) / (1.0 + std::fabs(D[jn])));
+            }
             for (int i = 0; i < N; i++) ws[i] = rhs[S.perm[i]];
             auto sweep = [&](const TriPlan &pl, const std::vector<double> &val, bool fwd) {
                 for (const SliceMeta &m : pl.sl) {

@@ -72,7 +72,11 @@ struct DevPat {
     int nfs, nbs, nUF, nUB;
     int meta_lds; // 1: both slice tables are staged in LDS behind the NLDS vectors
     gint_p f_idx, b_idx, posF, posB;
-    gint_p ftask_ptr, ftask, ftask_nlong, tp, pa, pb, pk, Lsrc, Dsrc;
+    // numeric factorisation: sliced-ELL program (plans.hpp: FactorPlan); per target: source offset of its
+    // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot
+    const SliceMeta EICOS_GLOBAL *fac_sl;
+    int fac_ns, fac_slots;
+    gint_p fac_pa, fac_pb, fac_pk, fac_src, fac_dst, fac_dstF;
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets

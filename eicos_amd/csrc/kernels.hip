@@ -478,36 +478,42 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD; // pa/pb index UB slots
     __syncthreads();
     TICK_BEGIN;
-    for (int v = 0; v < P.nlev; v++) {
-        const int q0 = P.ftask_ptr[v], q1 = P.ftask_ptr[v + 1], nl = P.ftask_nlong[v];
-        auto store = [&](int tgt, double s) {
-            if (tgt < N) {
-                const double d = I[P.Dsrc[tgt]] - s;
-                D[tgt] = d; invD[tgt] = 1. / d;
-                if (d == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
-            } else {
-                const int e = tgt - N;
-                const double u = I[P.Lsrc[e]] - s;
-                U[P.posB[e]] = u; UF[P.posF[e]] = u;
+    // target value = K entry - sum over pairs UB[pa]*UB[pb]/D[pk]; slices of one level are independent,
+    // levels are separated by a full barrier (the values travel through the workspace slab)
+    for (int sl = 0; sl < P.fac_ns; sl++) {
+        SliceMeta m = P.fac_sl[sl];
+        m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off); m.newlev = uni(m.newlev);
+        if (m.newlev && sl > 0) __syncthreads();
+        const int lanes = m.cnt << m.lg;
+        const bool act = tid < lanes;
+        double acc = 0.;
+        int kk = 0;
+        for (; kk + ELL_KMAX <= m.K; kk += ELL_KMAX) {
+            int ia[ELL_KMAX], ib[ELL_KMAX], ik[ELL_KMAX];
+#pragma unroll
+            for (int u = 0; u < ELL_KMAX; u++) {
+                const int slot = act ? m.off + (kk + u) * lanes + tid : P.fac_slots;
+                ia[u] = P.fac_pa[slot]; ib[u] = P.fac_pb[slot]; ik[u] = P.fac_pk[slot];
             }
-        };
-        for (int q = q0 + wave; q < q0 + nl; q += T / 64) {
-            const int tgt = P.ftask[q];
-            const int k0 = P.tp[tgt], k1 = P.tp[tgt + 1];
-            double s = 0.;
-            for (int k = k0 + lane; k < k1; k += 64) s += U[P.pa[k]] * U[P.pb[k]] * invD[P.pk[k]];
-            s = wave_reduce<OpSum>(s);
-            if (lane == 0) store(tgt, s);
+#pragma unroll
+            for (int u = 0; u < ELL_KMAX; u++) acc += U[ia[u]] * U[ib[u]] * invD[ik[u]];
         }
-        for (int q = q0 + nl + tid; q < q1; q += T) {
-            const int tgt = P.ftask[q];
-            const int k0 = P.tp[tgt], k1 = P.tp[tgt + 1];
-            double s = 0.;
-            for (int k = k0; k < k1; k++) s += U[P.pa[k]] * U[P.pb[k]] * invD[P.pk[k]];
-            store(tgt, s);
+        for (; kk < m.K; kk++) {
+            const int slot = act ? m.off + kk * lanes + tid : P.fac_slots;
+            acc += U[P.fac_pa[slot]] * U[P.fac_pb[slot]] * invD[P.fac_pk[slot]];
         }
-        __syncthreads();
+        for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (act && (tid & ((1 << m.lg) - 1)) == 0) {
+            const int t = m.row0 + (tid >> m.lg);
+            const double val = I[P.fac_src[t]] - acc;
+            const int dst = P.fac_dst[t];
+            if (dst < 0) {
+                D[-dst - 1] = val; invD[-dst - 1] = 1. / val;
+                if (val == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
+            } else { U[dst] = val; UF[P.fac_dstF[t]] = val; }
+        }
     }
+    __syncthreads();
     if (tid == 0) wi.n_factor++;
     __syncthreads();
     TICK_END(TK_FACTOR);
@@ -1164,16 +1170,23 @@ __global__ __launch_bounds__(T) void k_debug_factor(int ps, double *inst, double
     const int tid = threadIdx.x;
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, W = (gdbl_p)work;
     gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD;
-    for (int v = 0; v < P.nlev; v++) {
-        for (int q = P.ftask_ptr[v] + tid; q < P.ftask_ptr[v + 1]; q += T) {
-            const int tgt = P.ftask[q];
-            double s = 0.;
-            for (int k = P.tp[tgt]; k < P.tp[tgt + 1]; k++) s += U[P.pa[k]] * U[P.pb[k]] * invD[P.pk[k]];
-            if (tgt < P.N) { const double d = I[P.Dsrc[tgt]] - s; D[tgt] = d; invD[tgt] = 1. / d; }
-            else { const int e = tgt - P.N; const double u = I[P.Lsrc[e]] - s; U[P.posB[e]] = u; UF[P.posF[e]] = u; }
+    for (int sl = 0; sl < P.fac_ns; sl++) {
+        const SliceMeta m = P.fac_sl[sl];
+        if (m.newlev && sl > 0) __syncthreads();
+        const int lanes = m.cnt << m.lg;
+        double acc = 0.;
+        if (tid < lanes)
+            for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + tid; acc += U[P.fac_pa[slot]] * U[P.fac_pb[slot]] * invD[P.fac_pk[slot]]; }
+        for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (tid < lanes && (tid & ((1 << m.lg) - 1)) == 0) {
+            const int t = m.row0 + (tid >> m.lg);
+            const double val = I[P.fac_src[t]] - acc;
+            const int dst = P.fac_dst[t];
+            if (dst < 0) { D[-dst - 1] = val; invD[-dst - 1] = 1. / val; }
+            else { U[dst] = val; UF[P.fac_dstF[t]] = val; }
         }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // ---- launchers (called from api.cpp) ----

@@ -50,6 +50,43 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
     return pl;
 }
 
+FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &posB, int dummy_val_slot) {
+    FactorPlan pl;
+    auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
+    auto gof = [&](int64_t m) { return std::max(1, std::min(64, pow2ceil((int)((m + ELL_KMAX - 1) / ELL_KMAX)))); };
+    for (int v = 0; v < S.nlev; v++) {
+        int r = S.ftask_ptr[v];
+        const int end = S.ftask_ptr[v + 1];
+        bool first = true;
+        while (r < end) {
+            auto len = [&](int q) { return S.tp[S.ftask[q] + 1] - S.tp[S.ftask[q]]; };
+            const int g = gof(len(r)); // tasks are sorted by decreasing pair count: task r is the longest
+            const int cnt = std::min(T / g, end - r);
+            const int K = (int)((len(r) + g - 1) / g), lanes = cnt * g;
+            int lg = 0;
+            while ((1 << lg) < g) lg++;
+            pl.sl.push_back(SliceMeta{(int)pl.target.size(), cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
+            pl.pa.resize((size_t)pl.slots + (size_t)K * lanes, dummy_val_slot);
+            pl.pb.resize(pl.pa.size(), dummy_val_slot);
+            pl.pk.resize(pl.pa.size(), 0);
+            for (int i = r; i < r + cnt; i++) {
+                const int tgt = S.ftask[i];
+                pl.target.push_back(tgt);
+                for (int64_t e = S.tp[tgt]; e < S.tp[tgt + 1]; e++) {
+                    const int j = (int)(e - S.tp[tgt]), q = j % g, kk = j / g;
+                    const int slot = pl.slots + kk * lanes + (i - r) * g + q;
+                    pl.pa[slot] = posB[S.pa[e]]; pl.pb[slot] = posB[S.pb[e]]; pl.pk[slot] = S.pk[e];
+                }
+            }
+            pl.slots += K * lanes;
+            r += cnt;
+            first = false;
+        }
+    }
+    pl.pa.push_back(dummy_val_slot); pl.pb.push_back(dummy_val_slot); pl.pk.push_back(0); // dummy slot `slots`
+    return pl;
+}
+
 EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T) {
     EllPlan pl;
     auto len = [&](int r) { return ptr[r + 1] - ptr[r]; };

@@ -26,4 +26,16 @@ struct EllPlan {
 };
 EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T);
 
+// Sliced-ELL form of the numeric factorisation program.  Per elimination-tree level the targets
+// (diagonal j or strictly-lower entry e of L, Symbolic::ftask order = decreasing pair count) are cut
+// into slices; lane t of a slice owns pairs q, q+g, ... of target row0 + t/g.  Padding pairs read the
+// dummy value slot (value 0).
+struct FactorPlan {
+    std::vector<SliceMeta> sl;       // row0 = index of the slice's first target in the per-target arrays
+    std::vector<int> pa, pb, pk;     // per slot: two value slots (backward/column order) and the pivot column
+    std::vector<int> target;         // per target: Symbolic target id (j < N: diagonal, N + e: entry e)
+    int slots = 0;
+};
+FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &posB, int dummy_val_slot);
+
 } // namespace eicos
