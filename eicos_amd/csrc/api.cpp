@@ -274,7 +274,9 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     // 160 KiB per CU minus the static block (reductions + scalar state)
     D.Npad = (S.N + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding
     {
-        const size_t meta = (size_t)(D.nfs + D.nbs) * sizeof(SliceMeta);
+        D.lm_f = 0; D.lm_b = D.lm_f + D.nfs; D.lm_cag = D.lm_b + D.nbs; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
+        D.lm_total = D.lm_rG + D.rG_ns;
+        const size_t meta = (size_t)D.lm_total * sizeof(SliceMeta);
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
         // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
         // all-global variant (NLDS = 0, plain __syncthreads between levels) is used

@@ -192,28 +192,53 @@ __device__ __forceinline__ void for_cones(int ps, Body &&body) {
 #define FOR_T(i, cnt) for (int i = threadIdx.x; i < (cnt); i += T)
 
 // Row products over a sliced-ELL plan (no levels): sum_r = sum_k val[r,k] * x[idx[r,k]], unit-stride
-// index/value loads, g lanes per row, epi(row, sum) on one lane per row.
-template <int T, class V, class X, class Epi>
-__device__ __forceinline__ void ell_dots(const SliceMeta EICOS_GLOBAL *sm, int ns, gint_p eidx, V eval, X x, int dummy_slot,
-                                         Epi &&epi) {
+// index/value loads, g lanes per row, epi(row, sum) on one lane per row.  Loads run ELL_DEPTH slices
+// ahead of the arithmetic (same register queue as tri_sweep, no barriers); plans are padded to a
+// multiple of ELL_DEPTH slices.  `sm` may live in LDS (staged by k_solve) or in global memory.
+constexpr int ELL_DEPTH = 2;
+template <int T, class SM, class V, class X, class Epi>
+__device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V eval, X x, int dummy_slot, Epi &&epi) {
     const int t = threadIdx.x;
-    for (int s = 0; s < ns; s++) {
+    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX];
+    auto meta = [&](int s) {
         SliceMeta m = sm[s];
         m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off);
-        const int lanes = m.cnt << m.lg;
+        return m;
+    };
+    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX]) {
+        const SliceMeta nm = meta(s);
+        const int lanes = nm.cnt << nm.lg;
         const bool act = t < lanes;
-        double acc = 0.;
-        int kk = 0;
-        for (; kk + ELL_KMAX <= m.K; kk += ELL_KMAX) { // batches of ELL_KMAX independent loads
-            int ii[ELL_KMAX]; double vv[ELL_KMAX];
 #pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) { const int slot = act ? m.off + (kk + u) * lanes + t : dummy_slot; ii[u] = eidx[slot]; vv[u] = eval[slot]; }
-#pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) acc += vv[u] * x[ii[u]];
+        for (int kk = 0; kk < ELL_KMAX; kk++) {
+            const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
+            ni[kk] = eidx[slot];
+            nv[kk] = eval[slot];
         }
-        for (; kk < m.K; kk++) { const int slot = act ? m.off + kk * lanes + t : dummy_slot; acc += eval[slot] * x[eidx[slot]]; }
-        for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc);
+    };
+#pragma unroll
+    for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d]);
+    for (int s0 = 0; s0 < ns; s0 += ELL_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < ELL_DEPTH; d++) {
+            const int s = s0 + d;
+            const SliceMeta m = meta(s);
+            int ci[ELL_KMAX]; double cv[ELL_KMAX];
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
+            load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d]);
+            const int lanes = m.cnt << m.lg;
+            const bool act = t < lanes;
+            double acc = 0.;
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk] * x[ci[kk]];
+            for (int kk = ELL_KMAX; kk < m.K; kk++) { // long rows: the tail is not prefetched
+                const int slot = act ? m.off + kk * lanes + t : dummy_slot;
+                acc += eval[slot] * x[eidx[slot]];
+            }
+            for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc);
+        }
     }
 }
 
@@ -452,6 +477,9 @@ __device__ __forceinline__ void restore_scalars() { // w = w_best (scalars), cou
     g_S.wi = g_S.bi; g_S.wi.n_factor = nf; g_S.wi.n_ldlsolve = ns;
 }
 
+// Slice table `which` of the current pattern: the LDS copy (NLDS >= 1) or the one in global memory.
+#define LDS_TABLE(at) (reinterpret_cast<const SliceMeta *>(g_dyn + (size_t)NLDS * P.Npad) + (at))
+
 // states of the solve program
 enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KKT_AFF, ST_KKT_COMB, ST_DONE };
 
@@ -522,7 +550,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
-template <int T>
+template <int T, int NLDS>
 __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
@@ -536,13 +564,16 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     // ---- computeResiduals (ref :643-689) + updateStatistics (ref :691-754) ----
     const double tau = wi.tau;
     double r8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hresx2 rx2 cx nx2 | hresy2 ry2 by ny2
-    ell_dots<T>(P.cag_sl, P.cag_ns, P.cag_idx_yz, cagv, wy, P.cag_slots, [&](int j, double s) { // -G'z - A'y: (y,z) contiguous
+    auto tab_cag = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_cag); else return P.cag_sl; }();
+    auto tab_rA = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rA); else return P.rA_sl; }();
+    auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
+    ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_yz, cagv, wy, P.cag_slots, [&](int j, double s) { // -G'z - A'y: (y,z) contiguous
         const double hr = -s, c_ = cv[j], xj = wx[j];
         const double r = hr - tau * c_;
         rx[j] = r;
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
-    ell_dots<T>(P.rA_sl, P.rA_ns, P.rA_idx, rAv, wx, P.rA_slots, [&](int r, double s) {
+    ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx, rAv, wx, P.rA_slots, [&](int r, double s) {
         const double b_ = bv[r], yr = wy[r];
         const double rr = s - tau * b_;
         ry[r] = rr;
@@ -550,7 +581,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
     double q6[6] = {0, 0, 0, 0, 0, 0}; // hresz2 rz2 hz nz2 ns2 gap
-    ell_dots<T>(P.rG_sl, P.rG_ns, P.rG_idx, rGv, wx, P.rG_slots, [&](int i, double s) {
+    ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx, rGv, wx, P.rG_slots, [&](int i, double s) {
         const double si = wsl[i], zi = wz[i], h_ = hv[i];
         const double hr = si + s, r = hr - tau * h_;
         rz[i] = r;
@@ -739,6 +770,9 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return W + P.w_xk; }();
     auto E = [&] { if constexpr (NLDS == 1) return W + P.w_ek; else return SV; }();
     gdbl_p Xg = W + P.w_xk;
+    auto tab_cag = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_cag); else return P.cag_sl; }();
+    auto tab_rA = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rA); else return P.rA_sl; }();
+    auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
     gdbl_p dxr = W + P.w_dxr;
     gdbl_p UF = W + P.w_UF, UB = W + P.w_UB, invD = W + P.w_invD;
     __syncthreads();
@@ -762,9 +796,8 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             TICK_END(TK_KRES);
             __syncthreads();
             if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-                const SliceMeta *fsl = reinterpret_cast<const SliceMeta *>(g_dyn + (size_t)NLDS * P.Npad);
-                tri_sweep<T, true, true>(fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
-                tri_sweep<T, false, true>(fsl + P.nfs, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, true>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
+                tri_sweep<T, false, true>(LDS_TABLE(P.lm_b), P.nbs, P.b_idx, UB, invD, SV, P.nUB);
             } else {
                 tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
                 tri_sweep<T, false, false>(P.bsl, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
@@ -782,17 +815,17 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             k++;
             // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
             double nex = 0., ney = 0., nez = 0.;
-            ell_dots<T>(P.cag_sl, P.cag_ns, P.cag_idx_k, cagv, X, P.cag_slots, [&](int j, double s) {
+            ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_k, cagv, X, P.cag_slots, [&](int j, double s) {
                 const int o = P.ipx[j];
                 const double e = bx[j] - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
                 E[o] = e; nex = fmax(nex, fabs(e));
             });
-            ell_dots<T>(P.rA_sl, P.rA_ns, P.rA_idx_k, rAv, X, P.rA_slots, [&](int r, double s) {
+            ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx_k, rAv, X, P.rA_slots, [&](int r, double s) {
                 const int o = P.ipy[r];
                 const double e = by[r] - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
                 E[o] = e; ney = fmax(ney, fabs(e));
             });
-            ell_dots<T>(P.rG_sl, P.rG_ns, P.rG_idx_k, rGv, X, P.rG_slots, [&](int i, double s) {
+            ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx_k, rGv, X, P.rG_slots, [&](int i, double s) {
                 const int o = P.ipz[i];
                 const double xo = X[o];
                 double v = bz[i] - s + (double)P.zdsign[i] * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
@@ -1035,7 +1068,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     int iter = -1; // -1 while initialising
     while (stage != ST_DONE) {
         if (stage == ST_FACTOR) stage = stage_factor<T>(ps, I, W, iter);
-        else if (stage == ST_RESID) stage = stage_resid<T>(ps, I, W, iter);
+        else if (stage == ST_RESID) stage = stage_resid<T, NLDS>(ps, I, W, iter);
         else {
             const int prev = stage;
             stage = stage_kkt<T, NLDS>(ps, I, W, stage);
@@ -1059,11 +1092,14 @@ __global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
     int ps, double *inst, double *work, int B) {
     const DevPat &P = c_pat[ps];
     gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
-    if constexpr (NLDS >= 1) { // slice tables of both sweeps -> LDS, once per workgroup (same plan for every instance)
+    if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
         int *dst = reinterpret_cast<int *>(g_dyn + (size_t)NLDS * P.Npad);
-        const int *srcf = reinterpret_cast<const int *>(P.fsl), *srcb = reinterpret_cast<const int *>(P.bsl);
-        for (int q = threadIdx.x; q < P.nfs * 8; q += T) dst[q] = srcf[q];
-        for (int q = threadIdx.x; q < P.nbs * 8; q += T) dst[P.nfs * 8 + q] = srcb[q];
+        auto stage = [&](const SliceMeta EICOS_GLOBAL *src, int cnt, int at) {
+            gint_p si = reinterpret_cast<gint_p>(src);
+            for (int q = threadIdx.x; q < cnt * 8; q += T) dst[at * 8 + q] = si[q];
+        };
+        stage(P.fsl, P.nfs, P.lm_f); stage(P.bsl, P.nbs, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
+        stage(P.rA_sl, P.rA_ns, P.lm_rA); stage(P.rG_sl, P.rG_ns, P.lm_rG);
         __syncthreads();
     }
     for (int i = blockIdx.x; i < B; i += gridDim.x) {
