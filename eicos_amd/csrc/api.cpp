@@ -192,14 +192,6 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
             (d >= CONE_BIG ? cone_big : cone_small).push_back(c);
         }
     }
-    std::vector<int> Air_k(S.nnzA), Gir_k(S.nnzG);
-    for (int k = 0; k < S.nnzA; k++) Air_k[k] = S.n + P.Air[k];
-    for (int k = 0; k < S.nnzG; k++) Gir_k[k] = S.n + S.p + zexp[P.Gir[k]];
-    std::vector<int> AG_long, At_long, Gt_long;
-    for (int j = 0; j < S.n; j++)
-        if ((P.Ajc[j + 1] - P.Ajc[j]) + (P.Gjc[j + 1] - P.Gjc[j]) > LONG_SEG) AG_long.push_back(j);
-    for (int r = 0; r < S.p; r++) if (S.At_ptr[r + 1] - S.At_ptr[r] > LONG_SEG) At_long.push_back(r);
-    for (int r = 0; r < S.m; r++) if (S.Gt_ptr[r + 1] - S.Gt_ptr[r] > LONG_SEG) Gt_long.push_back(r);
     auto srcoff = [&](int kind, int src) {
         switch (kind) {
         case SRC_A: return D.i_Av + src;
@@ -215,6 +207,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     TriPlan planF = build_tri_plan(S, h->threads, true), planB = build_tri_plan(S, h->threads, false);
     D.nfs = (int)planF.sl.size(); D.nbs = (int)planB.sl.size(); D.nUF = planF.slots; D.nUB = planB.slots;
+    D.n_leaf = S.nlev > 0 ? S.lev_ptr[1] : 0;
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     D.work_stride = Wl.size;
     h->posB = planB.pos;
@@ -233,15 +226,11 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     struct Slot { const int **dst; size_t off; };
     std::vector<Slot> slots;
     auto put = [&](const int *&field, const std::vector<int> &v) { slots.push_back({&field, pool.add(v)}); };
-    put(D.Ajc, P.Ajc); put(D.Air, P.Air); put(D.Air_k, Air_k); put(D.At_ptr, S.At_ptr); put(D.At_col, S.At_col); put(D.At_pos, S.At_pos);
-    put(D.Gjc, P.Gjc); put(D.Gir, P.Gir); put(D.Gir_k, Gir_k); put(D.Gt_ptr, S.Gt_ptr); put(D.Gt_col, S.Gt_col); put(D.Gt_pos, S.Gt_pos);
-    put(D.A_long, AG_long); put(D.At_long, At_long); put(D.Gt_long, Gt_long);
-    D.G_long = nullptr; D.nG_long = 0;
-    D.nA_long = (int)AG_long.size(); D.nAt_long = (int)At_long.size(); D.nGt_long = (int)Gt_long.size();
+    put(D.Ajc, P.Ajc); put(D.Air, P.Air); put(D.At_ptr, S.At_ptr); put(D.At_pos, S.At_pos);
+    put(D.Gjc, P.Gjc); put(D.Gir, P.Gir); put(D.Gt_ptr, S.Gt_ptr); put(D.Gt_pos, S.Gt_pos);
     put(D.cq, S.q); put(D.cone_off, S.cone_off); put(D.cone_vbase, cone_vbase); put(D.cone_small, cone_small); put(D.cone_big, cone_big);
     D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
-    put(D.zexp, zexp); put(D.zdsign, zdsign);
-    put(D.perm, S.perm); put(D.lev_ptr, S.lev_ptr);
+    put(D.zdsign, zdsign);
     put(D.f_idx, planF.idx); put(D.b_idx, planB.idx); put(D.posF, planF.pos); put(D.posB, planB.pos);
     const int *fsl_p = nullptr, *bsl_p = nullptr, *cag_sl_p = nullptr, *rA_sl_p = nullptr, *rG_sl_p = nullptr;
     put(fsl_p, fsl_i); put(bsl_p, bsl_i); put(cag_sl_p, cag_sl_i); put(rA_sl_p, rA_sl_i); put(rG_sl_p, rG_sl_i);
@@ -602,7 +591,8 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                 for (int e = 0; e < S.nnzL; e++) plan_err = std::max(plan_err, std::fabs(UB[pb.pos[e]] - U[e]) / (1.0 + std::fabs(U[e])));
                 for (int jn = 0; jn < N; jn++) plan_err = std::max(plan_err, std::fabs(D2[jn] - D[jn]) / (1.0 + std::fabs(D[jn])));
             }
-            for (int i = 0; i < N; i++) ws[i] = rhs[S.perm[i]];
+            const int n_leaf = S.nlev > 0 ? S.lev_ptr[1] : 0;
+            for (int i = 0; i < N; i++) ws[i] = rhs[S.perm[i]] * (i < n_leaf ? invD[i] : 1.0);
             auto sweep = [&](const TriPlan &pl, const std::vector<double> &val, bool fwd) {
                 for (const SliceMeta &m : pl.sl) {
                     const int g = 1 << m.lg, lanes = m.cnt * g;

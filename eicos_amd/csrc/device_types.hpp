@@ -44,11 +44,9 @@ constexpr int TRI_DEPTH = 3; // ... this many slices ahead of their use (plans a
 struct DevPat {
     int n, p, m, l, nc, N, mt, nV, nnzA, nnzG, nnzL, nlev;
     int Npad; // N rounded up to 16 doubles: stride of the LDS-resident KKT-space vectors
-    // A, G in CSC (column) and transposed (row) form; *_k = row index as KKT index
-    gint_p Ajc, Air, Air_k, At_ptr, At_col, At_pos;
-    gint_p Gjc, Gir, Gir_k, Gt_ptr, Gt_col, Gt_pos;
-    gint_p A_long, At_long, G_long, Gt_long; // columns / rows longer than LONG_SEG
-    int nA_long, nAt_long, nG_long, nGt_long;
+    // A, G in CSC (column) form and row pointers + CSC positions of the transposed form (updateData)
+    gint_p Ajc, Air, At_ptr, At_pos;
+    gint_p Gjc, Gir, Gt_ptr, Gt_pos;
     // sliced-ELL plans of the matrix-vector products (plans.hpp: EllPlan): stacked columns of [A;G]
     // (cag: x-space results), rows of A (rA), rows of G (rG).  *_src: slot -> offset of the CSC value
     // relative to Av (-1 = padding); cag has two gather-index sets: KKT indices (refinement) and
@@ -62,14 +60,13 @@ struct DevPat {
     // cones
     gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;
-    gint_p zexp;    // [m] expanded (rhs / KKT cone block) position of z row i
     gint_p zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
     // LDL' pattern, level ordered
-    gint_p perm, lev_ptr;
     // triangular solves: sliced-ELL plans (see SliceMeta); UF/UB hold the values of L.*D in the
     // forward (row) and backward (column) slot order, posF/posB map a CSC entry of L to its slots
     const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;
+    int n_leaf; // nodes [0, n_leaf) are level 0: no row entries, forward update = scaling by 1/D (done at load)
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_total;
     gint_p f_idx, b_idx, posF, posB;
@@ -88,7 +85,6 @@ struct DevPat {
 };
 
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
-constexpr int LONG_SEG = 48;       // segments longer than this are reduced by a whole wavefront
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each
 constexpr int CSC_STRIDE = 20;     // doubles of scaling state per cone
 // per-cone scaling scalars (reference struct SOCone, include/eicos.hpp:81-95): CS_* committed,

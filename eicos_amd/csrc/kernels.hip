@@ -68,7 +68,7 @@ struct Sh {
     int fl[FL_COUNT];
     unsigned long long tick[8]; // per-phase time of the current solve (100 MHz ticks), thread 0
 };
-enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_INIT, TK_COUNT };
+enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT };
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
 __shared__ Sh g_S;
@@ -82,6 +82,25 @@ template <class Ptr> __device__ __forceinline__ Ptr uni_ptr(Ptr p) {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return (Ptr)(((unsigned long long)hi << 32) | lo);
+}
+
+// Sum over an aligned group of g = 1<<lg adjacent lanes, result valid in the group's lane 0.
+// Steps of 1..8 lanes stay inside a DPP row (row_shl: lane i reads lane i+n of its 16-lane row, 0 past
+// the end) and run at VALU speed; only g = 32/64 needs the LDS-crossbar shuffles for its last steps.
+template <int CTRL> __device__ __forceinline__ double dpp_shl_add(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double grp_reduce_to_lane0(double v, int lg) { // lg is wavefront-uniform
+    if (lg >= 6) v += __shfl_xor(v, 32, 64);
+    if (lg >= 5) v += __shfl_xor(v, 16, 64);
+    if (lg >= 4) v = dpp_shl_add<0x108>(v); // row_shl:8
+    if (lg >= 3) v = dpp_shl_add<0x104>(v); // row_shl:4
+    if (lg >= 2) v = dpp_shl_add<0x102>(v); // row_shl:2
+    if (lg >= 1) v = dpp_shl_add<0x101>(v); // row_shl:1
+    return v;
 }
 
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
@@ -124,54 +143,6 @@ __device__ __forceinline__ double blk_reduce1(int &phase, double x) {
     double v[1] = {x};
     blk_reduce<Op, T, 1>(phase, v);
     return v[0];
-}
-
-// Segmented sparse dot products over rows/columns [r0,r1): short segments one thread each,
-// long ones (listed in longlist) one wavefront each.  epi(r, sum) runs on exactly one thread.
-template <int T, class V, class X, class Epi>
-__device__ __forceinline__ void seg_dots(int r0, int r1, gint_p ptr, gint_p idx, V val, X x, gint_p longlist, int nlong,
-                                         Epi &&epi) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int r = r0 + tid; r < r1; r += T) {
-        const int k0 = ptr[r], k1 = ptr[r + 1];
-        if (k1 - k0 > LONG_SEG) continue;
-        double s = 0.;
-        for (int k = k0; k < k1; k++) s += val[k] * x[idx[k]];
-        epi(r, s);
-    }
-    for (int q = wave; q < nlong; q += T / 64) {
-        const int r = longlist[q];
-        const int k0 = ptr[r], k1 = ptr[r + 1];
-        double s = 0.;
-        for (int k = k0 + lane; k < k1; k += 64) s += val[k] * x[idx[k]];
-        s = wave_reduce<OpSum>(s);
-        if (lane == 0) epi(r, s);
-    }
-}
-
-// Column products with the stacked matrix [A; G]: s_j = sum_k A[k,j] xa[ia[k]] + sum_k G[k,j] xg[ig[k]]
-template <int T, class XA, class XG, class Epi>
-__device__ __forceinline__ void col_dots_AG(int ps, gcdbl_p Av, gcdbl_p Gv, gint_p ia, gint_p ig, XA xa, XG xg,
-                                            Epi &&epi) {
-    const DevPat &P = c_pat[ps];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < P.n; j += T) {
-        const int a0 = P.Ajc[j], a1 = P.Ajc[j + 1], g0 = P.Gjc[j], g1 = P.Gjc[j + 1];
-        if ((a1 - a0) + (g1 - g0) > LONG_SEG) continue;
-        double s = 0.;
-        for (int k = a0; k < a1; k++) s += Av[k] * xa[ia[k]];
-        for (int k = g0; k < g1; k++) s += Gv[k] * xg[ig[k]];
-        epi(j, s);
-    }
-    for (int q = wave; q < P.nA_long; q += T / 64) { // A_long lists the long columns of [A;G]
-        const int j = P.A_long[q];
-        const int a0 = P.Ajc[j], a1 = P.Ajc[j + 1], g0 = P.Gjc[j], g1 = P.Gjc[j + 1];
-        double s = 0.;
-        for (int k = a0 + lane; k < a1; k += 64) s += Av[k] * xa[ia[k]];
-        for (int k = g0 + lane; k < g1; k += 64) s += Gv[k] * xg[ig[k]];
-        s = wave_reduce<OpSum>(s);
-        if (lane == 0) epi(j, s);
-    }
 }
 
 template <int G> __device__ __forceinline__ double grp_sum(double v) {
@@ -236,7 +207,7 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V ev
                 const int slot = act ? m.off + kk * lanes + t : dummy_slot;
                 acc += eval[slot] * x[eidx[slot]];
             }
-            for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            acc = grp_reduce_to_lane0(acc, m.lg);
             if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc);
         }
     }
@@ -263,53 +234,49 @@ template <int T, bool FORWARD, bool LDSBAR, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
     const int t = threadIdx.x;
-    int qi[TRI_DEPTH][ELL_KMAX]; double qv[TRI_DEPTH][ELL_KMAX]; double qd[TRI_DEPTH];
-    // every slice issues exactly 2*ELL_KMAX+1 loads per lane (inactive lanes / padding read the
+    struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
+        int row0, lg, K, off, lanes, newlev;
+        int idx[ELL_KMAX]; double val[ELL_KMAX]; double d, own;
+    } q[TRI_DEPTH];
+    // every slice issues exactly 2*ELL_KMAX+1 global loads per lane (inactive lanes / padding read the
     // plan's dummy slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
-    auto meta = [&](int s) { // slice descriptors are workgroup-uniform: keep them in SGPRs
-        SliceMeta m = sm[s];
-        m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off); m.newlev = uni(m.newlev);
-        return m;
-    };
-    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX], double &nd) {
-        const SliceMeta nm = meta(s);
-        const int lanes = nm.cnt << nm.lg;
-        const bool act = t < lanes;
+    auto load = [&](int s, Slot &o) {
+        const SliceMeta nm = sm[s];
+        o.row0 = uni(nm.row0); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off); o.newlev = uni(nm.newlev);
+        o.lanes = uni(nm.cnt) << o.lg;
+        const bool act = t < o.lanes;
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
-            const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
-            ni[kk] = eidx[slot];
-            nv[kk] = eval[slot];
+            const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
+            o.idx[kk] = eidx[slot];
+            o.val[kk] = eval[slot];
         }
-        nd = invD[act ? nm.row0 + (t >> nm.lg) : 0];
+        const int r = act ? o.row0 + (t >> o.lg) : 0;
+        o.d = invD[r];
+        o.own = ws[r]; // rows of later slices are not written before their own slice runs
     };
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
 #pragma unroll
-    for (int d = 0; d < TRI_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qd[d]);
+    for (int d = 0; d < TRI_DEPTH; d++) load(d < ns ? d : 0, q[d]);
     for (int s0 = 0; s0 < ns; s0 += TRI_DEPTH) {
 #pragma unroll
         for (int d = 0; d < TRI_DEPTH; d++) {
             const int s = s0 + d;
-            const SliceMeta cm = meta(s);
-            int ci[ELL_KMAX]; double cv[ELL_KMAX];
-#pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
-            const double cd = qd[d];
-            load(min(s + TRI_DEPTH, ns - 1), qi[d], qv[d], qd[d]);
-            if (cm.newlev) { if (LDSBAR) lds_barrier(); else __syncthreads(); }
-            const int lanes = cm.cnt << cm.lg;
+            const Slot c = q[d];
+            load(min(s + TRI_DEPTH, ns - 1), q[d]);
+            if (c.newlev) { if (LDSBAR) lds_barrier(); else __syncthreads(); }
             double acc = 0.;
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk] * ws[ci[kk]];
-            for (int kk = ELL_KMAX; kk < cm.K; kk++) { // very long rows: the tail is not prefetched
-                if (t < lanes) { const int slot = cm.off + kk * lanes + t; acc += eval[slot] * ws[eidx[slot]]; }
+            for (int kk = 0; kk < ELL_KMAX; kk++) acc += c.val[kk] * ws[c.idx[kk]];
+            for (int kk = ELL_KMAX; kk < c.K; kk++) { // very long rows: the tail is not prefetched
+                if (t < c.lanes) { const int slot = c.off + kk * c.lanes + t; acc += eval[slot] * ws[eidx[slot]]; }
             }
-            for (int o = (1 << cm.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (t < lanes && (t & ((1 << cm.lg) - 1)) == 0) {
-                const int r = cm.row0 + (t >> cm.lg);
-                if (FORWARD) ws[r] = (ws[r] - acc) * cd;
-                else ws[r] = ws[r] - cd * acc;
+            acc = grp_reduce_to_lane0(acc, c.lg);
+            if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
+                const int r = c.row0 + (t >> c.lg);
+                if (FORWARD) ws[r] = (c.own - acc) * c.d;
+                else ws[r] = c.own - c.d * acc;
             }
         }
     }
@@ -530,7 +497,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             const int slot = act ? m.off + kk * lanes + tid : P.fac_slots;
             acc += U[P.fac_pa[slot]] * U[P.fac_pb[slot]] * invD[P.fac_pk[slot]];
         }
-        for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        acc = grp_reduce_to_lane0(acc, m.lg);
         if (act && (tid & ((1 << m.lg) - 1)) == 0) {
             const int t = m.row0 + (tid >> m.lg);
             const double val = I[P.fac_src[t]] - acc;
@@ -786,7 +753,8 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         // ---------------- solveKKT (ref :1471-1620) ----------------
         gcdbl_p bx = rhsk, by = rhsk + n, bz = rhsk + np;
         double nr = 0.;
-        FOR_T(i, P.Npad) { const double v = (i < N) ? rhsp[i] : 0.; SV[i] = v; nr = fmax(nr, fabs(v)); } // slots >= N stay 0
+        // load the right-hand side; leaves of the tree (nodes < n_leaf) get their forward update t = b/D here
+        FOR_T(i, P.Npad) { const double v = (i < N) ? rhsp[i] : 0.; SV[i] = (i < P.n_leaf) ? v * invD[i] : v; nr = fmax(nr, fabs(v)); } // slots >= N stay 0
         nr = blk_reduce1<OpMax, T>(phase, nr);
         const double thr = (1. + nr) * LINSYSACC;
         double nerr_prev = DBL_MAX;
@@ -797,6 +765,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             __syncthreads();
             if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
                 tri_sweep<T, true, true>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
+                TICK_END(TK_FWD);
                 tri_sweep<T, false, true>(LDS_TABLE(P.lm_b), P.nbs, P.b_idx, UB, invD, SV, P.nUB);
             } else {
                 tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
@@ -879,7 +848,8 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             }
             if (k == NITREF || nerr < thr || (k > 0 && nerr_prev < IRERRFACT * nerr)) break;
             nerr_prev = nerr;
-            if constexpr (NLDS == 1) { __syncthreads(); FOR_T(i, N) SV[i] = E[i]; } // residual -> sweep vector (unit stride)
+            if constexpr (NLDS == 1) { __syncthreads(); FOR_T(i, N) SV[i] = (i < P.n_leaf) ? E[i] * invD[i] : E[i]; } // residual -> sweep vector
+            else { __syncthreads(); FOR_T(i, P.n_leaf) SV[i] *= invD[i]; }                                         // leaves: t = e/D
         }
         __syncthreads();
         FOR_T(j, n) dx[j] = X[P.ipx[j]];

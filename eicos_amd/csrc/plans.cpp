@@ -43,7 +43,9 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
             first = false;
         }
     };
-    if (forward) for (int v = 0; v < S.nlev; v++) emit_level(v);
+    // forward: level-0 rows (leaves of the elimination tree) have no entries -- their update is the plain
+    // scaling t_i = b_i / D_i, which the kernel folds into the pass that loads the right-hand side
+    if (forward) for (int v = 1; v < S.nlev; v++) emit_level(v);
     else for (int v = S.nlev - 1; v >= 0; v--) emit_level(v);
     pl.idx.push_back(S.N); // slot `slots`: the dummy (index N, value 0) read by inactive lanes
     while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // empty slices: no loop tail
