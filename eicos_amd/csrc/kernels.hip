@@ -11,17 +11,18 @@
 // Per-instance control flow (exit tests, refinement counts, safeguards) therefore needs no
 // inter-workgroup communication and no active-mask compaction.
 //
-// Data: per-instance values live in a slab in HBM (consecutive lanes walk consecutive
-// entries of one instance's CSC/CSR value arrays); the index arrays are shared by all
-// instances and stay L2-resident.  The sparse LDL' is level scheduled: nodes are renumbered
-// on the host so each elimination-tree level is a contiguous range; factorisation is a
-// left-looking "one thread (or one wavefront) per target entry" program, triangular solves
-// are gather-form segmented dot products per level with the solve vector staged in LDS.
+// Data: per-instance values live in slabs in HBM; the index arrays are shared by all instances.
+// Every sparse operation -- the three matrix-vector products, the numeric LDL' program and the two
+// level-scheduled triangular sweeps -- walks a "sliced ELL" plan (SliceMeta, device_types.hpp): g lanes
+// per row, unit-stride index/value loads with no row pointers, DPP row reductions, and the loads of
+// the next slices are issued before the current one is consumed (register queue; across the LDS-only
+// level barriers of the sweeps).  KKT-space vectors live in elimination order, the solve vector (and
+// the current solution when one workgroup owns a CU) in LDS.
 //
 // Code shape: the solve is a small state machine so that the three big pieces -- numeric
-// factorisation, LDL' solve, KKT solve with iterative refinement -- each have exactly ONE
-// inlined call site (the straight-line form of the reference calls solveKKT at five places;
-// inlining that blows the instruction cache and the register budget).
+// factorisation, LDL' solve, KKT solve with iterative refinement -- each have exactly ONE call site,
+// and every stage is a non-inlined function (the straight-line form of the reference calls solveKKT
+// at five places; inlining that blows the instruction cache and the register budget).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>

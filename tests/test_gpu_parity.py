@@ -127,6 +127,51 @@ def test_big_cone_wavefront_path():
     _check_batch(pat, feasible_batch(pat, base, 0, 8), 8, 8, x_rtol=1e-7)
 
 
+def dense_front_pattern(n, k, d, seed=3):
+    """SURVEY.md 8d config 5 in small: k cones of dim d, each a dense d x d block of G on d consecutive
+    variables, neighbouring blocks overlapping so that G has full column rank."""
+    from scipy.sparse import csc_matrix
+    from eicos_amd.problem_io import Pattern
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for i in range(k):
+        c0 = (i * (n - d)) // max(1, k - 1)
+        B = rng.standard_normal((d, d)) / 8
+        for r in range(d):
+            for c in range(d):
+                rows.append(i * d + r); cols.append(c0 + c); vals.append(B[r, c])
+    G = csc_matrix((vals, (rows, cols)), shape=(k * d, n)); G.sum_duplicates(); G.sort_indices()
+    pat = Pattern(n, k * d, 0, 0, np.full(k, d, np.int32), G.indptr.astype(np.int32), G.indices.astype(np.int32),
+                  np.zeros(n + 1, np.int32), np.zeros(0, np.int32))
+    return pat, Values(G.data.copy(), np.zeros(0), np.zeros(n), np.zeros(k * d), np.zeros(0))
+
+
+def test_dense_front_socp():
+    # BASELINE.json config 4 shape (dense cone blocks, big cones -> wavefront-per-cone path, deep tree)
+    pat, base = dense_front_pattern(n=150, k=4, d=40)
+    assert pat.n <= (pat.ncones - 1) * 40 + 40  # blocks cover every column
+    _check_batch(pat, feasible_batch(pat, base, 0, 6), 6, 6, x_rtol=1e-6)
+
+
+@pytest.mark.parametrize("env", [{"EICOS_NLDS": "0"}, {"EICOS_NLDS": "1"}, {"EICOS_NLDS": "2"},
+                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "1024"}])
+def test_every_kernel_variant_matches_oracle(env, monkeypatch):
+    # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
+    # or in the workspace slab, 256/512/1024 threads) through an LP, an SOC and an infeasible fixture
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("lp_bandm", "issue98", "infeasible1", "update_data"):
+        pat, sets = load_fixture(name)
+        o = OracleSolver(pat, sets[0]); oc = o.solve(); oi = o.info()
+        g = eicos_amd.BatchSolver(pat, 2); g.update(*rep(sets[0], 2))
+        codes = g.solve(); gi = g.info()
+        assert list(codes) == [oc, oc], (env, name, codes, oc)
+        assert abs(gi[0]["iter"] - oi["iter"]) <= 1
+        if oc == 0:
+            assert abs(gi[0]["pcost"] - oi["pcost"]) <= PCOST_RTOL * max(1.0, abs(oi["pcost"]))
+        g.close(); o.close()
+
+
 def test_lpnetlib_perturbed_batch():
     pat, sets = load_fixture("lp_blend")
     d = perturbed_batch(pat, sets[0], 0, 32)
