@@ -39,6 +39,19 @@ def test_cpp_header_compiles_against_c_header():
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
 
 
+def test_ecos_shim_and_demo_compile():
+    # include/ecos.h (drop-in for the reference's test/ecos.h) and examples/run_demo.cpp (counterpart of
+    # the reference's src/run.cpp) must build against the C ABI with a plain host compiler
+    import subprocess, tempfile
+    inc = os.path.join(ROOT, "include")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        open(src, "w").write('#include "ecos.h"\nint main(){ pwork *w = nullptr; (void)w; return ECOS_OPTIMAL; }\n')
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", inc, src])
+        subprocess.check_call(["g++", "-std=c++17", "-I", inc, os.path.join(ROOT, "examples", "run_demo.cpp"),
+                               "-L", os.path.join(ROOT, "eicos_amd"), "-leicos_amd", "-o", os.path.join(d, "run_demo")])
+
+
 @pytest.mark.skipif(eicos_amd.device_count() > 0, reason="GPU present")
 def test_no_cpu_fallback_without_gpu():
     pat, _ = load_fixture("lp_afiro")

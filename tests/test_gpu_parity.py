@@ -243,3 +243,17 @@ def test_full_size_batch_properties():
     x1 = x.copy(); g.solve()
     assert np.array_equal(g.solution(), x1)
     g.close()
+
+
+def test_cpp_solver_surface_demo(tmp_path):
+    # examples/run_demo.cpp = the reference's src/run.cpp flow (ctor -> solve -> updateData -> solve) through
+    # include/eicos.hpp; built with the host compiler and run on the GPU
+    import os, subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "run_demo")
+    lib = os.path.join(ROOT, "eicos_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "run_demo.cpp"),
+                           "-L", lib, "-leicos_amd", "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "MPC02.epb")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("exit 0") == 2 and "pcost 0.16" in out.stdout, out.stdout
