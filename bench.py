@@ -61,8 +61,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
-    ap.add_argument("--pattern", default="MPC02", help="fixture name under tests/golden")
+    ap.add_argument("--pattern", default="MPC02", help="fixture name under tests/golden (BASELINE config 3: lp_*), "
+                    "or 'dense-front' (BASELINE config 4: n=2000, 32 cones x 64, generated)")
     ap.add_argument("--soc", action="store_true", help="MPC-SOC variant (332 cones of dim 3)")
+    ap.add_argument("--perturb", action="store_true", help="LPnetlib-style batch: perturb c,h of the fixture "
+                    "(SURVEY.md 8d config 4) instead of generating strictly feasible (c,h,b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,12 +88,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    pat, sets = eicos_amd.read_epb(os.path.join(ROOT, "tests", "golden", args.pattern + ".epb"))
+    if args.pattern == "dense-front":
+        from eicos_amd.generate import dense_front_pattern
+        pat, base = dense_front_pattern(2000, 32, 64)
+        sets = [base]
+    else:
+        pat, sets = eicos_amd.read_epb(os.path.join(ROOT, "tests", "golden", args.pattern + ".epb"))
     if args.soc:
         pat = mpc_soc_variant(pat)
     B = args.batch
     first = rank * B  # weak scaling: every rank owns instances [rank*B, (rank+1)*B)
-    data = feasible_batch(pat, sets[0], first, B, SEED)
+    if args.perturb:
+        from eicos_amd.generate import perturbed_batch
+        data = perturbed_batch(pat, sets[0], first, B, SEED)
+    else:
+        data = feasible_batch(pat, sets[0], first, B, SEED)
     dev = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in data.items()}
     ptr = lambda k: dev[k].data_ptr() if dev[k].numel() else 0
 
@@ -146,7 +158,7 @@ def main():
                        "batch_per_gpu": B, "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"],
                        "levels": dims["nlevels"], "mean_iter": float(ia["iter"].mean()),
                        "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
-                       "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B,
+                       "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B, "generator": "perturbed" if args.perturb else "feasible",
                        "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

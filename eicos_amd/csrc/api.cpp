@@ -124,8 +124,11 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
 
     auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
     {
-        const int t = env_int("EICOS_THREADS", 512);
-        h->threads = (t == 256 || t == 1024) ? t : 512;
+        // workgroup size by problem size (measured, batch 256: dim_K 129 -> 128, 1249 -> 256, >= 3815 -> 512 threads)
+        const int dimK = n + p + m + 2 * ncones;
+        const int dflt = dimK < 400 ? 128 : (dimK < 2000 ? 256 : 512);
+        const int t = env_int("EICOS_THREADS", dflt);
+        h->threads = (t == 128 || t == 256 || t == 512 || t == 1024) ? t : dflt;
     }
     // ---- slab layouts ----
     SlabLayout L;

@@ -1206,6 +1206,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, F &&f) {
     };
     if (threads == 1024) return byT(std::integral_constant<int, 1024>{});
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
+    if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
 }
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int grid, int threads, int nlds,

@@ -72,6 +72,24 @@ def mpc_soc_variant(pat: Pattern, base: Values = None, rows_from: int = 3000, di
     return Pattern(pat.n, pat.m, pat.p, rows_from, q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)
 
 
+def dense_front_pattern(n: int = 2000, k: int = 32, d: int = 64, seed: int = SEED):
+    """Dense-front SOCP: k cones of dimension d, p = 0, l = 0; cone i's d rows of G
+    form a dense d x d N(0,1)/8 block on the d consecutive variables starting at floor(i (n-d)/(k-1))
+    (neighbouring blocks overlap, together they cover all n columns).  Returns (Pattern, base Values)."""
+    rng = np.random.Generator(np.random.Philox(key=[seed, 0xD5E]))
+    rows, cols, vals = [], [], []
+    for i in range(k):
+        c0 = (i * (n - d)) // max(1, k - 1)
+        blk = rng.standard_normal((d, d)) / 8
+        rr, cc = np.meshgrid(np.arange(d), np.arange(d), indexing="ij")
+        rows.append((i * d + rr).ravel()); cols.append((c0 + cc).ravel()); vals.append(blk.ravel())
+    G = csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(k * d, n))
+    G.sum_duplicates(); G.sort_indices()
+    pat = Pattern(n, k * d, 0, 0, np.full(k, d, np.int32), G.indptr.astype(np.int32), G.indices.astype(np.int32),
+                  np.zeros(n + 1, np.int32), np.zeros(0, np.int32))
+    return pat, Values(G.data.copy(), np.zeros(0), np.zeros(n), np.zeros(k * d), np.zeros(0))
+
+
 def shard_range(total: int, rank: int, world: int):
     """Contiguous shard [first, first+count) of `total` instances for `rank` of `world`."""
     base, rem = divmod(total, world)

@@ -153,8 +153,8 @@ def test_dense_front_socp():
     _check_batch(pat, feasible_batch(pat, base, 0, 6), 6, 6, x_rtol=1e-6)
 
 
-@pytest.mark.parametrize("env", [{"EICOS_NLDS": "0"}, {"EICOS_NLDS": "1"}, {"EICOS_NLDS": "2"},
-                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "1024"}])
+@pytest.mark.parametrize("env", [{"EICOS_NLDS": "0"}, {"EICOS_NLDS": "1"}, {"EICOS_NLDS": "2"}, {"EICOS_THREADS": "128"},
+                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_THREADS": "1024"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
     # or in the workspace slab, 256/512/1024 threads) through an LP, an SOC and an infeasible fixture
@@ -183,6 +183,26 @@ def test_lpnetlib_perturbed_batch():
         o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
         assert o.solve() == 0
         assert abs(ia["pcost"][i] - o.info()["pcost"]) <= PCOST_RTOL * max(1.0, abs(o.info()["pcost"]))
+    g.close()
+
+
+def test_lpnetlib_perturbed_ill_posed_instances_match_oracle():
+    # perturbing c and h of a Netlib LP makes part of the batch hard (close-to-optimal, unbounded, maxit exits):
+    # the GPU must take the same exit as the oracle on every instance, not just on the easy ones
+    pat, sets = load_fixture("lp_agg2")
+    B = 12
+    d = perturbed_batch(pat, sets[0], 0, B)
+    g = eicos_amd.BatchSolver(pat, B)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve(); ia = g.info_arrays()
+    for i in range(B):
+        o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+        oc = o.solve(); oi = o.info()
+        assert codes[i] == oc, (i, codes[i], oc)
+        assert abs(ia["iter"][i] - oi["iter"]) <= 1
+        if oc == 0:  # badly scaled LP (|pcost| ~ 2e7): objective agreement at the solver's own relgap tolerance
+            assert abs(ia["pcost"][i] - oi["pcost"]) <= 5e-8 * max(1.0, abs(oi["pcost"]))
+        o.close()
     g.close()
 
 
