@@ -1,6 +1,6 @@
 """Dev script: oracle (CPU baseline) thread scaling on this host."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from eicos_amd import read_epb
 from eicos_amd.generate import feasible_batch
 from oracle import oracle as orc

@@ -1,7 +1,7 @@
 """Dev script: perturbed LPnetlib batch, GPU vs oracle exit codes / iterations per instance."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from eicos_amd import read_epb, BatchSolver
 from eicos_amd.generate import perturbed_batch
 from eicos_amd.problem_io import Values

@@ -1,7 +1,7 @@
 """Dev script (not a pytest file): GPU vs oracle on every fixture, prints a table."""
 import json, sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from eicos_amd import read_epb, BatchSolver
 from eicos_amd.generate import feasible_batch
 from oracle.oracle import OracleSolver

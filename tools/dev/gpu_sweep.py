@@ -1,7 +1,7 @@
 """Dev script (not a pytest file): time the batched solve for the current library / env knobs."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from eicos_amd import read_epb, BatchSolver
 from eicos_amd.generate import feasible_batch
 name = sys.argv[1] if len(sys.argv) > 1 else "MPC02"

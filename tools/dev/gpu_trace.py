@@ -1,7 +1,7 @@
 """Dev script: per-iteration trace, oracle vs GPU (needs a -DEICOS_TRACE build via EICOS_AMD_LIB)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from eicos_amd import read_epb, BatchSolver
 from oracle.oracle import OracleSolver
 name = sys.argv[1]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 output of tests/profile_r1.sh into profiles/<tag>_*.{csv,md}.
+"""Summarise rocprofv3 output of tools/dev/profile_r1.sh into profiles/<tag>_*.{csv,md}.
 
 usage: python tools/summarize_profile.py gpurun_out/prof_r1 profiles/r01
 Per-launch averages of the PMC counters for the solve kernel; FETCH_SIZE/WRITE_SIZE are reported in
