@@ -164,7 +164,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (host cores are shared by all ranks)
             # CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload
             from oracle import oracle as orc
             cores = usable_cores()

@@ -185,7 +185,7 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V ev
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
             ni[kk] = eidx[slot];
-            nv[kk] = eval[slot];
+            nv[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per pass: keep the shared index arrays in L2
         }
     };
 #pragma unroll
@@ -250,7 +250,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
             o.idx[kk] = eidx[slot];
-            o.val[kk] = eval[slot];
+            o.val[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per sweep: do not displace the index arrays in L2
         }
         const int r = act ? o.row0 + (t >> o.lg) : 0;
         o.d = invD[r];
