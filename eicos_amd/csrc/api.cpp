@@ -210,14 +210,15 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     TriPlan planF = build_tri_plan(S, h->threads, true), planB = build_tri_plan(S, h->threads, false);
     D.nfs = (int)planF.sl.size(); D.nbs = (int)planB.sl.size(); D.nUF = planF.slots; D.nUB = planB.slots;
-    D.n_leaf = S.nlev > 0 ? S.lev_ptr[1] : 0;
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     D.work_stride = Wl.size;
     h->posB = planB.pos;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
-    FactorPlan planX = build_factor_plan(S, h->threads, planB.pos, planB.slots);
+    FactorPlan planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots;
-    std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size());
+    std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
+    std::vector<int> col_of(S.nnzL);
+    for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) col_of[e] = j;
     auto meta_ints = [](const std::vector<SliceMeta> &v) {
         std::vector<int> o(v.size() * 8);
         if (!v.empty()) std::memcpy(o.data(), v.data(), o.size() * sizeof(int));
@@ -244,12 +245,12 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     for (size_t t = 0; t < planX.target.size(); t++) {
         const int tgt = planX.target[t];
         if (tgt < S.N) { fac_src[t] = srcoff(S.Dkind[tgt], S.Dsrc[tgt]); fac_dst[t] = -tgt - 1; fac_dstF[t] = 0; }
-        else { const int e = tgt - S.N; fac_src[t] = srcoff(S.Lkind[e], S.Lsrc[e]); fac_dst[t] = planB.pos[e]; fac_dstF[t] = planF.pos[e]; }
+        else { const int e = tgt - S.N; fac_src[t] = srcoff(S.Lkind[e], S.Lsrc[e]); fac_dst[t] = planB.pos[e]; fac_dstF[t] = planF.pos[e]; fac_col[t] = col_of[e]; }
     }
     const int *fac_sl_p = nullptr;
     put(fac_sl_p, fac_sl_i);
-    put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb); put(D.fac_pk, planX.pk);
-    put(D.fac_src, fac_src); put(D.fac_dst, fac_dst); put(D.fac_dstF, fac_dstF);
+    put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb);
+    put(D.fac_src, fac_src); put(D.fac_dst, fac_dst); put(D.fac_dstF, fac_dstF); put(D.fac_col, fac_col);
 
     // ---- device resources ----
     auto bail = [&](int code, const std::string &msg) { eicos_batch_destroy(h); return fail(code, msg); };
@@ -577,25 +578,38 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
             TriPlan pf = build_tri_plan(S, T, true), pb = build_tri_plan(S, T, false);
             std::vector<double> UF(pf.slots + 1, 0.0), UB(pb.slots + 1, 0.0), ws(N + 1, 0.0);
             { // numeric factorisation through the sliced-ELL factor plan, lane by lane as the kernel does it
-                FactorPlan px = build_factor_plan(S, T, pb.pos, pb.slots);
+                FactorPlan px = build_factor_plan(S, T, pb.pos, pb.slots, pf.pos, pf.slots);
                 std::vector<double> D2(N, 0.0), iD2(N, 0.0);
-                for (const SliceMeta &m : px.sl) {
-                    const int g = 1 << m.lg, lanes = m.cnt * g;
-                    if (lanes > T) throw std::logic_error("factor slice wider than the workgroup");
-                    for (int r = 0; r < m.cnt; r++) {
-                        double acc = 0;
-                        for (int q = 0; q < g; q++)
-                            for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + r * g + q; acc += UB[px.pa[slot]] * UB[px.pb[slot]] * iD2[px.pk[slot]]; }
-                        const int tgt = px.target[m.row0 + r];
-                        if (tgt < N) { D2[tgt] = Dv[tgt] - acc; iD2[tgt] = 1.0 / D2[tgt]; }
-                        else { const int e = tgt - N; UB[pb.pos[e]] = Lv[e] - acc; UF[pf.pos[e]] = Lv[e] - acc; }
+                std::vector<int> colof(S.nnzL);
+                for (int j = 0; j < N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colof[e] = j;
+                size_t s0 = 0;
+                while (s0 < px.sl.size()) { // one level at a time: phase A (U, D), then phase B (L = U / D[col])
+                    size_t s1 = s0 + 1;
+                    while (s1 < px.sl.size() && !px.sl[s1].newlev) s1++;
+                    for (size_t si = s0; si < s1; si++) {
+                        const SliceMeta &m = px.sl[si];
+                        const int g = 1 << m.lg, lanes = m.cnt * g;
+                        if (lanes > T) throw std::logic_error("factor slice wider than the workgroup");
+                        for (int r = 0; r < m.cnt; r++) {
+                            double acc = 0;
+                            for (int q = 0; q < g; q++)
+                                for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + r * g + q; acc += UB[px.pa[slot]] * UF[px.pb[slot]]; }
+                            const int tgt = px.target[m.row0 + r];
+                            if (tgt < N) { D2[tgt] = Dv[tgt] - acc; iD2[tgt] = 1.0 / D2[tgt]; }
+                            else { const int e = tgt - N; UB[pb.pos[e]] = Lv[e] - acc; }
+                        }
                     }
+                    for (size_t si = s0; si < s1; si++)
+                        for (int r = 0; r < px.sl[si].cnt; r++) {
+                            const int tgt = px.target[px.sl[si].row0 + r];
+                            if (tgt >= N) { const int e = tgt - N; UF[pf.pos[e]] = UB[pb.pos[e]] * iD2[colof[e]]; }
+                        }
+                    s0 = s1;
                 }
                 for (int e = 0; e < S.nnzL; e++) plan_err = std::max(plan_err, std::fabs(UB[pb.pos[e]] - U[e]) / (1.0 + std::fabs(U[e])));
                 for (int jn = 0; jn < N; jn++) plan_err = std::max(plan_err, std::fabs(D2[jn] - D[jn]) / (1.0 + std::fabs(D[jn])));
             }
-            const int n_leaf = S.nlev > 0 ? S.lev_ptr[1] : 0;
-            for (int i = 0; i < N; i++) ws[i] = rhs[S.perm[i]] * (i < n_leaf ? invD[i] : 1.0);
+            for (int i = 0; i < N; i++) ws[i] = rhs[S.perm[i]];
             auto sweep = [&](const TriPlan &pl, const std::vector<double> &val, bool fwd) {
                 for (const SliceMeta &m : pl.sl) {
                     const int g = 1 << m.lg, lanes = m.cnt * g;
@@ -605,7 +619,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                         for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + t; acc[t / g] += val[slot] * ws[pl.idx[slot]]; }
                     for (int r = 0; r < m.cnt; r++) {
                         const int i = m.row0 + r;
-                        ws[i] = fwd ? (ws[i] - acc[r]) * invD[i] : ws[i] - invD[i] * acc[r];
+                        ws[i] = fwd ? ws[i] - acc[r] : (ws[i] - acc[r]) * invD[i]; // L y = b ; x = (y - U' x) / D
                     }
                 }
             };

@@ -62,11 +62,10 @@ struct DevPat {
     int n_small, n_big;
     gint_p zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
     // LDL' pattern, level ordered
-    // triangular solves: sliced-ELL plans (see SliceMeta); UF/UB hold the values of L.*D in the
-    // forward (row) and backward (column) slot order, posF/posB map a CSC entry of L to its slots
+    // triangular solves: sliced-ELL plans (see SliceMeta).  UF = unit-lower L in the forward (row) slot order,
+    // UB = U = L.*D (column-scaled) in the backward (column) slot order; posF/posB map a CSC entry of L to its slots
     const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;
-    int n_leaf; // nodes [0, n_leaf) are level 0: no row entries, forward update = scaling by 1/D (done at load)
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_total;
     gint_p f_idx, b_idx, posF, posB;
@@ -74,7 +73,7 @@ struct DevPat {
     // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot
     const SliceMeta EICOS_GLOBAL *fac_sl;
     int fac_ns, fac_slots;
-    gint_p fac_pa, fac_pb, fac_pk, fac_src, fac_dst, fac_dstF;
+    gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets

@@ -226,8 +226,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // One triangular sweep of the level-scheduled LDL' solve over a sliced-ELL plan (SliceMeta):
-// forward:  ws[i] = (ws[i] - sum_k UF[i,k] ws[k]) * invD[i]   (t = D^-1 L^-1 b, rows by level)
-// backward: ws[j] =  ws[j] - invD[j] * sum_i UB[i,j] ws[i]    (x = L^-T t, columns by level, top down)
+// forward:  ws[i] =  ws[i] - sum_k L[i,k] ws[k]              (L y = b, unit-lower L in UF, rows by level)
+// backward: ws[j] = (ws[j] - sum_i U[i,j] ws[i]) / D[j]        (x = L^-T D^-1 y with U = L.*D in UB, columns by level, top down)
 // Index/value/invD loads run TRI_DEPTH slices ahead of their use: they do not depend on ws, so
 // their HBM/L2 latency overlaps earlier levels and the dependent part of a level is only LDS
 // gathers + one LDS store + the barrier.  `sm` points to the slice table (LDS copy when staged).
@@ -253,7 +253,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
             o.val[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per sweep: do not displace the index arrays in L2
         }
         const int r = act ? o.row0 + (t >> o.lg) : 0;
-        o.d = invD[r];
+        o.d = FORWARD ? 0. : invD[r]; // forward is L y = b with unit-lower L: no pivot needed
         o.own = ws[r]; // rows of later slices are not written before their own slice runs
     };
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
@@ -276,8 +276,8 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
             acc = grp_reduce_to_lane0(acc, c.lg);
             if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
                 const int r = c.row0 + (t >> c.lg);
-                if (FORWARD) ws[r] = (c.own - acc) * c.d;
-                else ws[r] = c.own - c.d * acc;
+                if (FORWARD) ws[r] = c.own - acc;             // y_i = b_i - sum_k L[i,k] y_k
+                else ws[r] = (c.own - acc) * c.d;             // x_j = (y_j - sum_i U[i,j] x_i) / D_j
             }
         }
     }
@@ -474,42 +474,55 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD; // pa/pb index UB slots
     __syncthreads();
     TICK_BEGIN;
-    // target value = K entry - sum over pairs UB[pa]*UB[pb]/D[pk]; slices of one level are independent,
-    // levels are separated by a full barrier (the values travel through the workspace slab)
-    for (int sl = 0; sl < P.fac_ns; sl++) {
-        SliceMeta m = P.fac_sl[sl];
-        m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off); m.newlev = uni(m.newlev);
-        if (m.newlev && sl > 0) __syncthreads();
-        const int lanes = m.cnt << m.lg;
-        const bool act = tid < lanes;
-        double acc = 0.;
-        int kk = 0;
-        for (; kk + ELL_KMAX <= m.K; kk += ELL_KMAX) {
-            int ia[ELL_KMAX], ib[ELL_KMAX], ik[ELL_KMAX];
+    // Phase A of a level: target value = K entry - sum over pairs U[i,k] * L[j,k]  (U = UB slots, L = UF slots);
+    // diagonal targets give D and 1/D, the others U[i,j].  Phase B (after a barrier, D of the level is known):
+    // L[i,j] = U[i,j] / D[j] into the forward slots.  Slices of one level are independent.
+    for (int lv0 = 0; lv0 < P.fac_ns;) {
+        int lv1 = lv0, lvl_t0 = 0, lvl_t1 = 0;
+        for (int sl = lv0; sl < P.fac_ns; sl++) {
+            SliceMeta m = P.fac_sl[sl];
+            m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off); m.newlev = uni(m.newlev);
+            if (m.newlev && sl > lv0) break;
+            lv1 = sl + 1;
+            if (sl == lv0) lvl_t0 = m.row0;
+            lvl_t1 = m.row0 + m.cnt;
+            const int lanes = m.cnt << m.lg;
+            const bool act = tid < lanes;
+            double acc = 0.;
+            int kk = 0;
+            for (; kk + ELL_KMAX <= m.K; kk += ELL_KMAX) {
+                int ia[ELL_KMAX], ib[ELL_KMAX];
 #pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) {
-                const int slot = act ? m.off + (kk + u) * lanes + tid : P.fac_slots;
-                ia[u] = P.fac_pa[slot]; ib[u] = P.fac_pb[slot]; ik[u] = P.fac_pk[slot];
+                for (int u = 0; u < ELL_KMAX; u++) {
+                    const int slot = act ? m.off + (kk + u) * lanes + tid : P.fac_slots;
+                    ia[u] = P.fac_pa[slot]; ib[u] = P.fac_pb[slot];
+                }
+#pragma unroll
+                for (int u = 0; u < ELL_KMAX; u++) acc += U[ia[u]] * UF[ib[u]];
             }
-#pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) acc += U[ia[u]] * U[ib[u]] * invD[ik[u]];
+            for (; kk < m.K; kk++) {
+                const int slot = act ? m.off + kk * lanes + tid : P.fac_slots;
+                acc += U[P.fac_pa[slot]] * UF[P.fac_pb[slot]];
+            }
+            acc = grp_reduce_to_lane0(acc, m.lg);
+            if (act && (tid & ((1 << m.lg) - 1)) == 0) {
+                const int t = m.row0 + (tid >> m.lg);
+                const double val = I[P.fac_src[t]] - acc;
+                const int dst = P.fac_dst[t];
+                if (dst < 0) {
+                    D[-dst - 1] = val; invD[-dst - 1] = 1. / val;
+                    if (val == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
+                } else U[dst] = val;
+            }
         }
-        for (; kk < m.K; kk++) {
-            const int slot = act ? m.off + kk * lanes + tid : P.fac_slots;
-            acc += U[P.fac_pa[slot]] * U[P.fac_pb[slot]] * invD[P.fac_pk[slot]];
-        }
-        acc = grp_reduce_to_lane0(acc, m.lg);
-        if (act && (tid & ((1 << m.lg) - 1)) == 0) {
-            const int t = m.row0 + (tid >> m.lg);
-            const double val = I[P.fac_src[t]] - acc;
+        __syncthreads();
+        for (int t = lvl_t0 + tid; t < lvl_t1; t += T) { // phase B: the level's targets are one contiguous range
             const int dst = P.fac_dst[t];
-            if (dst < 0) {
-                D[-dst - 1] = val; invD[-dst - 1] = 1. / val;
-                if (val == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
-            } else { U[dst] = val; UF[P.fac_dstF[t]] = val; }
+            if (dst >= 0) UF[P.fac_dstF[t]] = U[dst] * invD[P.fac_col[t]];
         }
+        __syncthreads();
+        lv0 = lv1;
     }
-    __syncthreads();
     if (tid == 0) wi.n_factor++;
     __syncthreads();
     TICK_END(TK_FACTOR);
@@ -754,8 +767,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         // ---------------- solveKKT (ref :1471-1620) ----------------
         gcdbl_p bx = rhsk, by = rhsk + n, bz = rhsk + np;
         double nr = 0.;
-        // load the right-hand side; leaves of the tree (nodes < n_leaf) get their forward update t = b/D here
-        FOR_T(i, P.Npad) { const double v = (i < N) ? rhsp[i] : 0.; SV[i] = (i < P.n_leaf) ? v * invD[i] : v; nr = fmax(nr, fabs(v)); } // slots >= N stay 0
+        FOR_T(i, P.Npad) { const double v = (i < N) ? rhsp[i] : 0.; SV[i] = v; nr = fmax(nr, fabs(v)); } // load the rhs; slots >= N stay 0
         nr = blk_reduce1<OpMax, T>(phase, nr);
         const double thr = (1. + nr) * LINSYSACC;
         double nerr_prev = DBL_MAX;
@@ -849,8 +861,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             }
             if (k == NITREF || nerr < thr || (k > 0 && nerr_prev < IRERRFACT * nerr)) break;
             nerr_prev = nerr;
-            if constexpr (NLDS == 1) { __syncthreads(); FOR_T(i, N) SV[i] = (i < P.n_leaf) ? E[i] * invD[i] : E[i]; } // residual -> sweep vector
-            else { __syncthreads(); FOR_T(i, P.n_leaf) SV[i] *= invD[i]; }                                         // leaves: t = e/D
+            if constexpr (NLDS == 1) { __syncthreads(); FOR_T(i, N) SV[i] = E[i]; } // residual -> sweep vector (unit stride)
         }
         __syncthreads();
         FOR_T(j, n) dx[j] = X[P.ipx[j]];
@@ -1177,23 +1188,34 @@ __global__ __launch_bounds__(T) void k_debug_factor(int ps, double *inst, double
     const int tid = threadIdx.x;
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, W = (gdbl_p)work;
     gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD;
-    for (int sl = 0; sl < P.fac_ns; sl++) {
-        const SliceMeta m = P.fac_sl[sl];
-        if (m.newlev && sl > 0) __syncthreads();
-        const int lanes = m.cnt << m.lg;
-        double acc = 0.;
-        if (tid < lanes)
-            for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + tid; acc += U[P.fac_pa[slot]] * U[P.fac_pb[slot]] * invD[P.fac_pk[slot]]; }
-        for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (tid < lanes && (tid & ((1 << m.lg) - 1)) == 0) {
-            const int t = m.row0 + (tid >> m.lg);
-            const double val = I[P.fac_src[t]] - acc;
-            const int dst = P.fac_dst[t];
-            if (dst < 0) { D[-dst - 1] = val; invD[-dst - 1] = 1. / val; }
-            else { U[dst] = val; UF[P.fac_dstF[t]] = val; }
+    for (int lv0 = 0; lv0 < P.fac_ns;) {
+        int lv1 = lv0;
+        for (int sl = lv0; sl < P.fac_ns; sl++) {
+            const SliceMeta m = P.fac_sl[sl];
+            if (m.newlev && sl > lv0) break;
+            lv1 = sl + 1;
+            const int lanes = m.cnt << m.lg;
+            double acc = 0.;
+            if (tid < lanes)
+                for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + tid; acc += U[P.fac_pa[slot]] * UF[P.fac_pb[slot]]; }
+            for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (tid < lanes && (tid & ((1 << m.lg) - 1)) == 0) {
+                const int t = m.row0 + (tid >> m.lg);
+                const double val = I[P.fac_src[t]] - acc;
+                const int dst = P.fac_dst[t];
+                if (dst < 0) { D[-dst - 1] = val; invD[-dst - 1] = 1. / val; }
+                else U[dst] = val;
+            }
         }
+        __syncthreads();
+        for (int sl = lv0; sl < lv1; sl++)
+            for (int r = tid; r < P.fac_sl[sl].cnt; r += T) {
+                const int t = P.fac_sl[sl].row0 + r, dst = P.fac_dst[t];
+                if (dst >= 0) UF[P.fac_dstF[t]] = U[dst] * invD[P.fac_col[t]];
+            }
+        __syncthreads();
+        lv0 = lv1;
     }
-    __syncthreads();
 }
 
 // ---- launchers (called from api.cpp) ----

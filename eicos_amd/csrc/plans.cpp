@@ -43,8 +43,7 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
             first = false;
         }
     };
-    // forward: level-0 rows (leaves of the elimination tree) have no entries -- their update is the plain
-    // scaling t_i = b_i / D_i, which the kernel folds into the pass that loads the right-hand side
+    // forward (L y = b, unit lower L): level-0 rows (leaves of the elimination tree) have no entries: y = b
     if (forward) for (int v = 1; v < S.nlev; v++) emit_level(v);
     else for (int v = S.nlev - 1; v >= 0; v--) emit_level(v);
     pl.idx.push_back(S.N); // slot `slots`: the dummy (index N, value 0) read by inactive lanes
@@ -52,7 +51,8 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
     return pl;
 }
 
-FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &posB, int dummy_val_slot) {
+FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &posB, int dummyB,
+                             const std::vector<int> &posF, int dummyF) {
     FactorPlan pl;
     auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
     auto gof = [&](int64_t m) { return std::max(1, std::min(64, pow2ceil((int)((m + ELL_KMAX - 1) / ELL_KMAX)))); };
@@ -68,16 +68,15 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
             int lg = 0;
             while ((1 << lg) < g) lg++;
             pl.sl.push_back(SliceMeta{(int)pl.target.size(), cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
-            pl.pa.resize((size_t)pl.slots + (size_t)K * lanes, dummy_val_slot);
-            pl.pb.resize(pl.pa.size(), dummy_val_slot);
-            pl.pk.resize(pl.pa.size(), 0);
+            pl.pa.resize((size_t)pl.slots + (size_t)K * lanes, dummyB);
+            pl.pb.resize(pl.pa.size(), dummyF);
             for (int i = r; i < r + cnt; i++) {
                 const int tgt = S.ftask[i];
                 pl.target.push_back(tgt);
                 for (int64_t e = S.tp[tgt]; e < S.tp[tgt + 1]; e++) {
                     const int j = (int)(e - S.tp[tgt]), q = j % g, kk = j / g;
                     const int slot = pl.slots + kk * lanes + (i - r) * g + q;
-                    pl.pa[slot] = posB[S.pa[e]]; pl.pb[slot] = posB[S.pb[e]]; pl.pk[slot] = S.pk[e];
+                    pl.pa[slot] = posB[S.pa[e]]; pl.pb[slot] = posF[S.pb[e]]; // term = U[i,k] * L[j,k]
                 }
             }
             pl.slots += K * lanes;
@@ -85,7 +84,7 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
             first = false;
         }
     }
-    pl.pa.push_back(dummy_val_slot); pl.pb.push_back(dummy_val_slot); pl.pk.push_back(0); // dummy slot `slots`
+    pl.pa.push_back(dummyB); pl.pb.push_back(dummyF); // dummy slot `slots`
     return pl;
 }
 

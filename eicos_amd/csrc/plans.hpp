@@ -32,10 +32,11 @@ EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T);
 // dummy value slot (value 0).
 struct FactorPlan {
     std::vector<SliceMeta> sl;       // row0 = index of the slice's first target in the per-target arrays
-    std::vector<int> pa, pb, pk;     // per slot: two value slots (backward/column order) and the pivot column
+    std::vector<int> pa, pb;         // per slot: U[i,k] in the backward (column) slot order, L[j,k] in the forward (row) slot order
     std::vector<int> target;         // per target: Symbolic target id (j < N: diagonal, N + e: entry e)
     int slots = 0;
 };
-FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &posB, int dummy_val_slot);
+FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &posB, int dummyB,
+                             const std::vector<int> &posF, int dummyF);
 
 } // namespace eicos
