@@ -90,6 +90,27 @@ def dense_front_pattern(n: int = 2000, k: int = 32, d: int = 64, seed: int = SEE
     return pat, Values(G.data.copy(), np.zeros(0), np.zeros(n), np.zeros(k * d), np.zeros(0))
 
 
+def random_socp_pattern(n: int, p: int, l: int, q, density: float = 0.3, seed: int = 0):
+    """Random sparse SOCP pattern + base values with equality rows, LP rows and cones of sizes q
+    (every variable appears in G so the problem is bounded in every direction of a feasible batch)."""
+    rng = np.random.default_rng(seed)
+    q = np.asarray(q, np.int32)
+    m = l + int(q.sum())
+    Gd = rng.standard_normal((m, n)) * (rng.random((m, n)) < density)
+    for j in range(n):  # no empty columns
+        if not Gd[:, j].any():
+            Gd[rng.integers(m), j] = rng.standard_normal() + 1.5
+    Ad = rng.standard_normal((p, n)) * (rng.random((p, n)) < max(density, 2.0 / max(n, 1)))
+    for r in range(p):
+        if not Ad[r].any():
+            Ad[r, rng.integers(n)] = 1.0
+    G, A = csc_matrix(Gd), csc_matrix(Ad)
+    G.sort_indices(); A.sort_indices()
+    pat = Pattern(n, m, p, l, q, G.indptr.astype(np.int32), G.indices.astype(np.int32),
+                  A.indptr.astype(np.int32), A.indices.astype(np.int32))
+    return pat, Values(G.data.copy(), A.data.copy(), np.zeros(n), np.zeros(m), np.zeros(p))
+
+
 def shard_range(total: int, rank: int, world: int):
     """Contiguous shard [first, first+count) of `total` instances for `rank` of `world`."""
     base, rem = divmod(total, world)

@@ -172,6 +172,15 @@ def test_every_kernel_variant_matches_oracle(env, monkeypatch):
         g.close(); o.close()
 
 
+@pytest.mark.parametrize("seed,n,p,l,q", [(1, 12, 3, 6, [4, 3]), (2, 20, 5, 0, [5, 5, 5]), (3, 9, 0, 4, [6]),
+                                          (4, 30, 8, 10, [3] * 6), (5, 16, 4, 5, [1, 2, 7]), (6, 60, 10, 20, [40, 33, 2])])
+def test_random_socp_with_equalities(seed, n, p, l, q):
+    # random sparse patterns with equality rows, LP rows and cones of mixed size (incl. dimension 1 and >= 32)
+    from eicos_amd.generate import random_socp_pattern
+    pat, base = random_socp_pattern(n, p, l, q, seed=seed)
+    _check_batch(pat, feasible_batch(pat, base, 0, 5, seed=100 + seed), 5, 5, x_rtol=1e-6)
+
+
 def test_lpnetlib_perturbed_batch():
     pat, sets = load_fixture("lp_blend")
     d = perturbed_batch(pat, sets[0], 0, 32)
