@@ -43,6 +43,7 @@ struct eicos_batch {
     int nlds = 0;
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
+    int *d_queue = nullptr; // instance queue of the solve kernel (reset per launch)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
     bool solve_timed = false, update_timed = false;
@@ -211,11 +212,12 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     TriPlan planF = build_tri_plan(S, h->threads, true), planB = build_tri_plan(S, h->threads, false);
     D.nfs = (int)planF.sl.size(); D.nbs = (int)planB.sl.size(); D.nUF = planF.slots; D.nUB = planB.slots;
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
-    D.work_stride = Wl.size;
     h->posB = planB.pos;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
     FactorPlan planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
-    D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots;
+    D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
+    D.w_Kt = Wl.add(planX.target.size() + 8); // KKT entries in target order: the factor's only per-target value stream
+    D.work_stride = Wl.size;
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
     std::vector<int> col_of(S.nnzL);
     for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) col_of[e] = j;
@@ -247,6 +249,10 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         if (tgt < S.N) { fac_src[t] = srcoff(S.Dkind[tgt], S.Dsrc[tgt]); fac_dst[t] = -tgt - 1; fac_dstF[t] = 0; }
         else { const int e = tgt - S.N; fac_src[t] = srcoff(S.Lkind[e], S.Lsrc[e]); fac_dst[t] = planB.pos[e]; fac_dstF[t] = planF.pos[e]; fac_col[t] = col_of[e]; }
     }
+    std::vector<int> v2t(std::max(S.nV, 1), D.fac_nt); // entries that are no target (none by construction) -> spare slot
+    for (size_t t = 0; t < planX.target.size(); t++)
+        if (fac_src[t] >= D.i_Vv && fac_src[t] < D.i_Vv + S.nV) v2t[fac_src[t] - D.i_Vv] = (int)t;
+    put(D.v2t, v2t);
     const int *fac_sl_p = nullptr;
     put(fac_sl_p, fac_sl_i);
     put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb);
@@ -309,6 +315,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_work, 0, (size_t)h->grid * D.work_stride * sizeof(double)));
+    HIP_TRY_H(hipMalloc(&h->d_queue, (16 + (size_t)batch) * sizeof(int))); // [0] queue head, [16..] longest-first order
     HIP_TRY_H(hipMalloc(&h->d_scratch, (size_t)h->upd_grid * (size_t)(S.n + S.p + S.m + 8) * sizeof(double)));
     HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
@@ -328,6 +335,7 @@ int eicos_batch_destroy(eicos_batch *h) {
     if (h->pslot >= 0) { std::lock_guard<std::mutex> lk(g_slot_mu); g_slot_used[h->device % 16][h->pslot] = false; }
     if (h->d_inst) (void)hipFree(h->d_inst);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     delete h;
     return EICOS_OK;
@@ -392,7 +400,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->grid, h->threads, h->nlds, h->dyn_lds, h->stream));
+    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;
@@ -496,7 +504,7 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(launch_debug_factor(h->pslot, h->d_inst, h->d_work, inst, h->stream));
+    HIP_TRY(launch_debug_factor(h->pslot, h->d_inst, h->d_work, inst, h->threads, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->dp.N * sizeof(double), hipMemcpyDeviceToHost));
     if (Uout) {
@@ -579,10 +587,21 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
             std::vector<double> UF(pf.slots + 1, 0.0), UB(pb.slots + 1, 0.0), ws(N + 1, 0.0);
             { // numeric factorisation through the sliced-ELL factor plan, lane by lane as the kernel does it
                 FactorPlan px = build_factor_plan(S, T, pb.pos, pb.slots, pf.pos, pf.slots);
+                if (getenv("EICOS_PLAN_STATS")) { // developer aid: shape of the three programs for this workgroup size
+                    auto stat = [&](const char *nm, const std::vector<SliceMeta> &sl, int slots) {
+                        int lev = 0, kmax = 0; long lanes = 0, kl = 0;
+                        for (const SliceMeta &m : sl) { lev += m.newlev; kmax = std::max(kmax, m.K); lanes += (long)m.cnt << m.lg; kl += (long)m.K; }
+                        fprintf(stderr, "[plan T=%d] %-8s slices %zu levels %d slots %d sum(K) %ld maxK %d active-lane slices %.2f\n", T, nm,
+                                sl.size(), lev, slots, kl, kmax, (double)lanes / T);
+                    };
+                    stat("forward", pf.sl, pf.slots); stat("backward", pb.sl, pb.slots); stat("factor", px.sl, px.slots);
+                    fprintf(stderr, "[plan T=%d] factor targets %zu pairs %lld\n", T, px.target.size(), (long long)S.tp.back());
+                }
                 std::vector<double> D2(N, 0.0), iD2(N, 0.0);
                 std::vector<int> colof(S.nnzL);
                 for (int j = 0; j < N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colof[e] = j;
                 size_t s0 = 0;
+                std::vector<double> carry;
                 while (s0 < px.sl.size()) { // one level at a time: phase A (U, D), then phase B (L = U / D[col])
                     size_t s1 = s0 + 1;
                     while (s1 < px.sl.size() && !px.sl[s1].newlev) s1++;
@@ -590,17 +609,20 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                         const SliceMeta &m = px.sl[si];
                         const int g = 1 << m.lg, lanes = m.cnt * g;
                         if (lanes > T) throw std::logic_error("factor slice wider than the workgroup");
+                        if (m.K > ELL_KMAX) throw std::logic_error("factor slice deeper than the prefetch depth");
+                        if (!m.cont) carry.assign(m.cnt, 0.0);
                         for (int r = 0; r < m.cnt; r++) {
-                            double acc = 0;
+                            double acc = carry[r];
                             for (int q = 0; q < g; q++)
                                 for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + r * g + q; acc += UB[px.pa[slot]] * UF[px.pb[slot]]; }
+                            if (m.more) { carry[r] = acc; continue; } // sub-slices of one set of targets accumulate
                             const int tgt = px.target[m.row0 + r];
                             if (tgt < N) { D2[tgt] = Dv[tgt] - acc; iD2[tgt] = 1.0 / D2[tgt]; }
                             else { const int e = tgt - N; UB[pb.pos[e]] = Lv[e] - acc; }
                         }
                     }
                     for (size_t si = s0; si < s1; si++)
-                        for (int r = 0; r < px.sl[si].cnt; r++) {
+                        for (int r = 0; r < px.sl[si].cnt && !px.sl[si].more; r++) {
                             const int tgt = px.target[px.sl[si].row0 + r];
                             if (tgt >= N) { const int e = tgt - N; UF[pf.pos[e]] = UB[pb.pos[e]] * iD2[colof[e]]; }
                         }
@@ -617,9 +639,10 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                     std::vector<double> acc(m.cnt, 0.0);
                     for (int t = 0; t < lanes; t++)
                         for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + t; acc[t / g] += val[slot] * ws[pl.idx[slot]]; }
+                    if (m.K > ELL_KMAX) throw std::logic_error("slice deeper than the prefetch depth");
                     for (int r = 0; r < m.cnt; r++) {
                         const int i = m.row0 + r;
-                        ws[i] = fwd ? ws[i] - acc[r] : (ws[i] - acc[r]) * invD[i]; // L y = b ; x = (y - U' x) / D
+                        ws[i] = (fwd || m.more) ? ws[i] - acc[r] : (ws[i] - acc[r]) * invD[i]; // L y = b ; x = (y - U' x) / D
                     }
                 }
             };

@@ -34,7 +34,10 @@ constexpr int DEVINFO_DOUBLES = 32;
 // off + kk*(cnt*g) + t, so every load is unit-stride across the workgroup and needs no row
 // pointer.  K = entries per lane (padding slots hold value 0 / index N).  newlev = 1 on the first
 // slice of an elimination-tree level: a workgroup barrier separates it from the previous level.
-struct SliceMeta { int row0, cnt, lg, K, off, newlev, pad0, pad1; };
+// One slice of a sliced-ELL program: rows/targets [row0, row0+cnt), 2^lg lanes per row, K entries per lane at
+// slot off + k*lanes + lane.  Rows longer than ELL_KMAX << lg are cut into consecutive sub-slices of K <= ELL_KMAX
+// over the same rows: `more` = another sub-slice of these rows follows, `cont` = this one continues the previous.
+struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; };
 constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
 constexpr int TRI_DEPTH = 3; // ... this many slices ahead of their use (plans are padded to a multiple)
 
@@ -72,7 +75,9 @@ struct DevPat {
     // numeric factorisation: sliced-ELL program (plans.hpp: FactorPlan); per target: source offset of its
     // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot
     const SliceMeta EICOS_GLOBAL *fac_sl;
-    int fac_ns, fac_slots;
+    int fac_ns, fac_slots, fac_nt; // slices, pair slots, targets
+    int w_Kt;                      // [fac_nt] KKT entry of every target, in target order (workspace slab)
+    gint_p v2t;                    // [nV] scaling-block entry -> its target
     gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;

@@ -67,9 +67,10 @@ struct Sh {
     DevInfo wi, bi;
     double sv[SV_COUNT];
     int fl[FL_COUNT];
-    unsigned long long tick[8]; // per-phase time of the current solve (100 MHz ticks), thread 0
+    int next; // next instance of this workgroup (k_solve's queue)
+    unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
 };
-enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT };
+enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT, TK_FA = 8, TK_FW1, TK_FB, TK_FW2 }; // 8..11: inside the factor
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
 __shared__ Sh g_S;
@@ -163,21 +164,49 @@ __device__ __forceinline__ void for_cones(int ps, Body &&body) {
 
 #define FOR_T(i, cnt) for (int i = threadIdx.x; i < (cnt); i += T)
 
+// Elementwise pass over [0, cnt) whose global loads are issued U iterations at a time: `ld(i)` returns what
+// iteration i reads (a small struct), `fn(i, loaded)` does the arithmetic and the stores.  A plain FOR_T loop is
+// not unrolled by the compiler (unknown trip count, possibly aliasing stores) and waits for every iteration's
+// loads before it issues the next ones: cnt/T serial memory round trips per pass.
+struct V1 { double a; };
+struct V2 { double a, b; };
+struct V3 { double a, b, c; };
+struct V4 { double a, b, c, d; };
+struct IV1 { int i; double a; };
+struct IV2 { int i; double a, b; };
+template <int T, int U = 4, class L, class F>
+__device__ __forceinline__ void for_t_pre(int cnt, L &&ld, F &&fn) {
+    for (int i0 = threadIdx.x; i0 < cnt; i0 += U * T) {
+        decltype(ld(0)) r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * T; r[u] = ld(i < cnt ? i : i0); } // clamped: unconditional loads
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * T; if (i < cnt) fn(i, r[u]); }
+    }
+}
+
 // Row products over a sliced-ELL plan (no levels): sum_r = sum_k val[r,k] * x[idx[r,k]], unit-stride
 // index/value loads, g lanes per row, epi(row, sum) on one lane per row.  Loads run ELL_DEPTH slices
 // ahead of the arithmetic (same register queue as tri_sweep, no barriers); plans are padded to a
-// multiple of ELL_DEPTH slices.  `sm` may live in LDS (staged by k_solve) or in global memory.
+// multiple of ELL_DEPTH slices and hold at most ELL_KMAX entries per lane and slice (longer rows are
+// cut into sub-slices whose partial sums are carried in a register).  `sm` may live in LDS (staged by k_solve) or in global memory.
 constexpr int ELL_DEPTH = 2;
-template <int T, class SM, class V, class X, class Epi>
-__device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V eval, X x, int dummy_slot, Epi &&epi) {
+// `pre(row)` loads whatever the epilogue needs per row (rhs entry, destination index, ...); it is issued with the
+// slice's index/value loads, ELL_DEPTH slices ahead, so that `epi(row, sum, pre(row))` starts no global load itself.
+template <int T, class SM, class V, class X, class Pre, class Epi>
+__device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V eval, X x, int dummy_slot, Pre &&pre, Epi &&epi) {
+    if (ns == 0) return; // no rows
     const int t = threadIdx.x;
-    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX];
+    using R = decltype(pre(0));
+    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX]; R qr[ELL_DEPTH];
     auto meta = [&](int s) {
         SliceMeta m = sm[s];
         m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off);
+        m.more = uni(m.more); m.cont = uni(m.cont);
         return m;
     };
-    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX]) {
+    double carry = 0.; // partial sum of rows cut into sub-slices (SliceMeta::more / cont)
+    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX], R &nr) {
         const SliceMeta nm = meta(s);
         const int lanes = nm.cnt << nm.lg;
         const bool act = t < lanes;
@@ -187,29 +216,29 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V ev
             ni[kk] = eidx[slot];
             nv[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per pass: keep the shared index arrays in L2
         }
+        nr = pre(act ? nm.row0 + (t >> nm.lg) : 0);
     };
 #pragma unroll
-    for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d]);
+    for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
     for (int s0 = 0; s0 < ns; s0 += ELL_DEPTH) {
 #pragma unroll
         for (int d = 0; d < ELL_DEPTH; d++) {
             const int s = s0 + d;
             const SliceMeta m = meta(s);
             int ci[ELL_KMAX]; double cv[ELL_KMAX];
+            const R cr = qr[d];
 #pragma unroll
             for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
-            load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d]);
+            load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
             const int lanes = m.cnt << m.lg;
             const bool act = t < lanes;
             double acc = 0.;
 #pragma unroll
             for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk] * x[ci[kk]];
-            for (int kk = ELL_KMAX; kk < m.K; kk++) { // long rows: the tail is not prefetched
-                const int slot = act ? m.off + kk * lanes + t : dummy_slot;
-                acc += eval[slot] * x[eidx[slot]];
-            }
             acc = grp_reduce_to_lane0(acc, m.lg);
-            if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc);
+            if (m.cont) acc += carry;
+            if (m.more) carry = acc;
+            else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc, cr);
         }
     }
 }
@@ -236,7 +265,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
                                           int dummy_slot) {
     const int t = threadIdx.x;
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
-        int row0, lg, K, off, lanes, newlev;
+        int row0, lg, K, off, lanes, newlev, more, cont;
         int idx[ELL_KMAX]; double val[ELL_KMAX]; double d, own;
     } q[TRI_DEPTH];
     // every slice issues exactly 2*ELL_KMAX+1 global loads per lane (inactive lanes / padding read the
@@ -244,6 +273,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
     auto load = [&](int s, Slot &o) {
         const SliceMeta nm = sm[s];
         o.row0 = uni(nm.row0); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off); o.newlev = uni(nm.newlev);
+        o.more = uni(nm.more); o.cont = uni(nm.cont);
         o.lanes = uni(nm.cnt) << o.lg;
         const bool act = t < o.lanes;
 #pragma unroll
@@ -270,14 +300,14 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
             double acc = 0.;
 #pragma unroll
             for (int kk = 0; kk < ELL_KMAX; kk++) acc += c.val[kk] * ws[c.idx[kk]];
-            for (int kk = ELL_KMAX; kk < c.K; kk++) { // very long rows: the tail is not prefetched
-                if (t < c.lanes) { const int slot = c.off + kk * c.lanes + t; acc += eval[slot] * ws[eidx[slot]]; }
-            }
             acc = grp_reduce_to_lane0(acc, c.lg);
             if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
                 const int r = c.row0 + (t >> c.lg);
-                if (FORWARD) ws[r] = c.own - acc;             // y_i = b_i - sum_k L[i,k] y_k
-                else ws[r] = (c.own - acc) * c.d;             // x_j = (y_j - sum_i U[i,j] x_i) / D_j
+                // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
+                // (same lane, program order), and only the last one applies the pivot
+                const double v = (c.cont ? ws[r] : c.own) - acc;
+                if (FORWARD || c.more) ws[r] = v;              // y_i = b_i - sum_k L[i,k] y_k
+                else ws[r] = v * c.d;                          // x_j = (y_j - sum_i U[i,j] x_i) / D_j
             }
         }
     }
@@ -290,7 +320,7 @@ __device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out
     ps = uni(ps); W = uni_ptr(W); zz = uni_ptr(zz); out = uni_ptr(out);
     const DevPat &P = c_pat[ps];
     gcdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
-    FOR_T(i, P.l) out[i] = lpw[i] * zz[i];
+    for_t_pre<T, 8>(P.l, [&](int i) { return V2{lpw[i], zz[i]}; }, [&](int i, const V2 &r) { out[i] = r.a * r.b; });
     for_cones<T>(ps, [&](int c, auto G, int lane) {
         constexpr int g = decltype(G)::value;
         const int o = P.cone_off[c], d = P.cq[c];
@@ -343,7 +373,8 @@ __device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, do
     int phase = 0;
     __syncthreads();
     double rmin = DBL_MAX, smin = DBL_MAX, cstep = 0., bad = 0.;
-    FOR_T(i, l) { const double li = lam[i]; rmin = fmin(rmin, ds[i] / li); smin = fmin(smin, dz[i] / li); }
+    for_t_pre<T, 4>(l, [&](int i) { return V3{lam[i], ds[i], dz[i]}; },
+                    [&](int i, const V3 &r) { rmin = fmin(rmin, r.b / r.a); smin = fmin(smin, r.c / r.a); });
     auto cone_step = [&](int o, int d, auto G, int lane, bool &skipped) -> double {
         constexpr int g = decltype(G)::value;
         double l1 = 0.;
@@ -472,56 +503,104 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
     gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD; // pa/pb index UB slots
+    gcdbl_p Kt = W + P.w_Kt; // KKT entries in target order (solve prologue + updateKKTScalings)
     __syncthreads();
     TICK_BEGIN;
     // Phase A of a level: target value = K entry - sum over pairs U[i,k] * L[j,k]  (U = UB slots, L = UF slots);
     // diagonal targets give D and 1/D, the others U[i,j].  Phase B (after a barrier, D of the level is known):
     // L[i,j] = U[i,j] / D[j] into the forward slots.  Slices of one level are independent.
-    for (int lv0 = 0; lv0 < P.fac_ns;) {
-        int lv1 = lv0, lvl_t0 = 0, lvl_t1 = 0;
-        for (int sl = lv0; sl < P.fac_ns; sl++) {
-            SliceMeta m = P.fac_sl[sl];
-            m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off); m.newlev = uni(m.newlev);
-            if (m.newlev && sl > lv0) break;
-            lv1 = sl + 1;
-            if (sl == lv0) lvl_t0 = m.row0;
-            lvl_t1 = m.row0 + m.cnt;
-            const int lanes = m.cnt << m.lg;
-            const bool act = tid < lanes;
-            double acc = 0.;
-            int kk = 0;
-            for (; kk + ELL_KMAX <= m.K; kk += ELL_KMAX) {
-                int ia[ELL_KMAX], ib[ELL_KMAX];
+    // Everything that does not depend on factor values (pair indices, the K entry, destinations) is loaded
+    // FAC_DEPTH slices ahead, across the level barriers, so a level costs one dependent gather round trip
+    // per phase instead of an index load + gather + source-index load + value load chain.
+    unsigned long long ft0 = (tid == 0) ? wall_clock64() : 0ull; // finer phase timers (thread 0's view)
+#define FTICK(slot) do { if (tid == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - ft0; ft0 = t1_; } } while (0)
+    constexpr int FAC_DEPTH = 2;
+    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
+    double carry = 0.; // partial sum of targets cut into sub-slices
+    const int ns = P.fac_ns;
+    auto fload = [&](int sidx, FSlot &o) {
+        const SliceMeta nm = P.fac_sl[sidx];
+        o.row0 = uni(nm.row0); o.cnt = uni(nm.cnt); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off); o.newlev = uni(nm.newlev);
+        o.more = uni(nm.more); o.cont = uni(nm.cont);
+        o.last = (sidx + 1 >= ns) ? 1 : uni(P.fac_sl[sidx + 1].newlev);
+        o.lanes = o.cnt << o.lg;
+        const bool act = tid < o.lanes;
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) {
-                    const int slot = act ? m.off + (kk + u) * lanes + tid : P.fac_slots;
-                    ia[u] = P.fac_pa[slot]; ib[u] = P.fac_pb[slot];
+        for (int u = 0; u < ELL_KMAX; u++) {
+            const int slot = (act && u < o.K) ? o.off + u * o.lanes + tid : P.fac_slots; // dummy pair: 0 * 0
+            o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot];
+        }
+        const int t = act ? o.row0 + (tid >> o.lg) : 0;
+        o.kv = Kt[t];
+        o.dst = P.fac_dst[t];
+    };
+#pragma unroll
+    for (int d = 0; d < FAC_DEPTH; d++) fload(min(d, ns - 1), q[d]);
+    int lvl_t0 = 0;
+    double gu[ELL_KMAX], gl[ELL_KMAX];
+    bool have = false;
+    for (int s0 = 0; s0 < ns; s0 += FAC_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < FAC_DEPTH; d++) {
+            const int sidx = s0 + d;
+            if (sidx >= ns) break;
+            const FSlot c = q[d];
+            fload(min(sidx + FAC_DEPTH, ns - 1), q[d]);
+            if (c.newlev) lvl_t0 = c.row0;
+            const int lvl_t1 = c.row0 + c.cnt; // targets of a level are one contiguous range
+            int bd[2] = {-1, -1}, bf[2] = {0, 0}, bc[2] = {0, 0};
+            if (c.last) { // phase B's destinations for this thread's first two targets, ahead of the barrier
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int t = min(lvl_t0 + tid + u * T, lvl_t1 - 1);
+                    bd[u] = P.fac_dst[t]; bf[u] = P.fac_dstF[t]; bc[u] = P.fac_col[t];
                 }
+            }
+            const bool act = tid < c.lanes;
+            // gathered factor values: slices of one level are independent, so the next slice's gathers are
+            // issued before this slice's arithmetic waits on its own (one L2 round trip per level, not per slice)
+            if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) acc += U[ia[u]] * UF[ib[u]];
+                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = U[c.ia[u]]; gl[u] = UF[c.ib[u]]; }
             }
-            for (; kk < m.K; kk++) {
-                const int slot = act ? m.off + kk * lanes + tid : P.fac_slots;
-                acc += U[P.fac_pa[slot]] * UF[P.fac_pb[slot]];
+            double cu[ELL_KMAX], cl[ELL_KMAX];
+#pragma unroll
+            for (int u = 0; u < ELL_KMAX; u++) { cu[u] = gu[u]; cl[u] = gl[u]; }
+            have = !c.last;
+            if (have) {
+                const FSlot &nx = q[(d + 1) % FAC_DEPTH];
+#pragma unroll
+                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = U[nx.ia[u]]; gl[u] = UF[nx.ib[u]]; }
             }
-            acc = grp_reduce_to_lane0(acc, m.lg);
-            if (act && (tid & ((1 << m.lg) - 1)) == 0) {
-                const int t = m.row0 + (tid >> m.lg);
-                const double val = I[P.fac_src[t]] - acc;
-                const int dst = P.fac_dst[t];
-                if (dst < 0) {
-                    D[-dst - 1] = val; invD[-dst - 1] = 1. / val;
+            double acc = 0.;
+#pragma unroll
+            for (int u = 0; u < ELL_KMAX; u++) acc += cu[u] * cl[u];
+            acc = grp_reduce_to_lane0(acc, c.lg);
+            if (c.cont) acc += carry;
+            if (c.more) carry = acc;
+            else if (act && (tid & ((1 << c.lg) - 1)) == 0) {
+                const double val = c.kv - acc;
+                if (c.dst < 0) {
+                    D[-c.dst - 1] = val; invD[-c.dst - 1] = 1. / val;
                     if (val == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
-                } else U[dst] = val;
+                } else U[c.dst] = val;
+            }
+            if (c.last) {
+                FTICK(TK_FA);
+                __syncthreads();
+                FTICK(TK_FW1);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (lvl_t0 + tid + u * T < lvl_t1 && bd[u] >= 0) UF[bf[u]] = U[bd[u]] * invD[bc[u]];
+                for (int t = lvl_t0 + tid + 2 * T; t < lvl_t1; t += T) {
+                    const int dst = P.fac_dst[t];
+                    if (dst >= 0) UF[P.fac_dstF[t]] = U[dst] * invD[P.fac_col[t]];
+                }
+                FTICK(TK_FB);
+                __syncthreads();
+                FTICK(TK_FW2);
             }
         }
-        __syncthreads();
-        for (int t = lvl_t0 + tid; t < lvl_t1; t += T) { // phase B: the level's targets are one contiguous range
-            const int dst = P.fac_dst[t];
-            if (dst >= 0) UF[P.fac_dstF[t]] = U[dst] * invD[P.fac_col[t]];
-        }
-        __syncthreads();
-        lv0 = lv1;
     }
     if (tid == 0) wi.n_factor++;
     __syncthreads();
@@ -548,22 +627,27 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     auto tab_cag = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_cag); else return P.cag_sl; }();
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rA); else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
-    ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_yz, cagv, wy, P.cag_slots, [&](int j, double s) { // -G'z - A'y: (y,z) contiguous
-        const double hr = -s, c_ = cv[j], xj = wx[j];
+    struct Pre2 { double a, b; };
+    struct Pre3 { double a, b, c; };
+    ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_yz, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j]}; },
+                [&](int j, double s, const Pre2 &pr) { // -G'z - A'y: (y,z) contiguous
+        const double hr = -s, c_ = pr.a, xj = pr.b;
         const double r = hr - tau * c_;
         rx[j] = r;
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
-    ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx, rAv, wx, P.rA_slots, [&](int r, double s) {
-        const double b_ = bv[r], yr = wy[r];
+    ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r]}; },
+                [&](int r, double s, const Pre2 &pr) {
+        const double b_ = pr.a, yr = pr.b;
         const double rr = s - tau * b_;
         ry[r] = rr;
         r8[4] += s * s; r8[5] += rr * rr; r8[6] += b_ * yr; r8[7] += yr * yr;
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
     double q6[6] = {0, 0, 0, 0, 0, 0}; // hresz2 rz2 hz nz2 ns2 gap
-    ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx, rGv, wx, P.rG_slots, [&](int i, double s) {
-        const double si = wsl[i], zi = wz[i], h_ = hv[i];
+    ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i]}; },
+                [&](int i, double s, const Pre3 &pr) {
+        const double si = pr.a, zi = pr.b, h_ = pr.c;
         const double hr = si + s, r = hr - tau * h_;
         rz[i] = r;
         q6[0] += hr * hr; q6[1] += r * r; q6[2] += h_ * zi; q6[3] += zi * zi; q6[4] += si * si; q6[5] += si * zi;
@@ -650,12 +734,18 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
         return ST_DONE;
     }
     if (g_S.fl[FL_SAVE]) { // w_best = w (vectors; ref :1153,1157)
-        FOR_T(j, n) bx_[j] = wx[j];
-        FOR_T(j, p) by_[j] = wy[j];
-        FOR_T(i, m) { bz_[i] = wz[i]; bs_[i] = wsl[i]; blam[i] = lam[i]; }
+        for_t_pre<T, 4>(n, [&](int j) { return V1{wx[j]}; }, [&](int j, const V1 &r) { bx_[j] = r.a; });
+        for_t_pre<T, 4>(p, [&](int j) { return V1{wy[j]}; }, [&](int j, const V1 &r) { by_[j] = r.a; });
+        for_t_pre<T, 4>(m, [&](int i) { return V3{wz[i], wsl[i], lam[i]}; },
+                        [&](int i, const V3 &r) { bz_[i] = r.a; bs_[i] = r.b; blam[i] = r.c; });
     }
     // ---- updateScalings (ref :411-479) + updateKKTScalings (ref :1691-1732) ----
-    FOR_T(i, l) { const double v = wsl[i] / wz[i]; lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; }
+    // the scaling block goes to the instance slab (Vv) and to the factor's target-ordered value stream (Kt)
+    gdbl_p Kt = W + P.w_Kt;
+    for_t_pre<T, 4>(l, [&](int i) { return IV2{P.v2t[i], wsl[i], wz[i]}; }, [&](int i, const IV2 &r) {
+        const double v = r.a / r.b;
+        lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; Kt[r.i] = -v - DELTASTAT;
+    });
     double firstfail = 1e300;
     if (P.nc > 0) {
         for_cones<T>(ps, [&](int c, auto G, int ln) { // phase 1: candidate scalings per cone
@@ -704,6 +794,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
             const int o = P.cone_off[c], d = P.cq[c];
             gdbl_p cs = csc + c * CSC_STRIDE;
             gdbl_p v = Vv + P.cone_vbase[c];
+            gint_p vt = P.v2t + P.cone_vbase[c];
             const double a = cs[CN_A], d1 = cs[CN_D1], eta2 = cs[CN_ETA2], u0 = cs[CN_U0], u1 = cs[CN_U1], v1 = cs[CN_V1];
             const double snorm = cs[CN_SN], znorm = cs[CN_ZN], gam = cs[CN_GAM];
             if (ln == 0) {
@@ -713,11 +804,13 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
             // KKT scaling block, slot order of ref cacheIndices :1955-1986: D[d], vdiag, v[d-1], udiag, u[d]
             for (int k = ln; k < d; k += g) {
                 const double qk = (k >= 1) ? (0.5 / gam) * (wsl[o + k] / snorm - wz[o + k] / znorm) : 0.;
-                if (k >= 1) { qv[o + k] = qk; v[d + k] = -eta2 * v1 * qk; }
-                v[k] = (k == 0) ? -eta2 * d1 - DELTASTAT : -eta2 - DELTASTAT;
-                v[2 * d + 1 + k] = (k == 0) ? -eta2 * u0 : -eta2 * u1 * qk;
+                if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[vt[d + k]] = e; }
+                const double e0 = (k == 0) ? -eta2 * d1 - DELTASTAT : -eta2 - DELTASTAT;
+                const double e2 = (k == 0) ? -eta2 * u0 : -eta2 * u1 * qk;
+                v[k] = e0; Kt[vt[k]] = e0;
+                v[2 * d + 1 + k] = e2; Kt[vt[2 * d + 1 + k]] = e2;
             }
-            if (ln == 0) { v[d] = -eta2; v[2 * d] = eta2 + DELTASTAT; }
+            if (ln == 0) { v[d] = -eta2; Kt[vt[d]] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[vt[2 * d]] = eta2 + DELTASTAT; }
         });
     }
     __syncthreads();
@@ -745,12 +838,12 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     // Roles: SV = vector the triangular sweeps run on; X = solution the residual gathers from; E = where the
     // residual is written.  NLDS = 2: SV = E and X both in LDS.  NLDS = 1 (one LDS vector, several workgroups
     // per CU): the LDS vector alternates between the sweep vector and X -- the ~25k gathers of a residual hit
-    // LDS, its ~N scattered stores go to E in the workspace slab, X's master copy (Xg) is updated with
-    // unit-stride read-modify-writes.  NLDS = 0: everything in the workspace slab.
+    // LDS, its ~N scattered stores go to E in the workspace slab, and X is parked in the slab (Xg) only while a
+    // further refinement step borrows the LDS vector.  NLDS = 0: everything in the workspace slab.
     auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return W + P.w_ek; }();
     auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return W + P.w_xk; }();
     auto E = [&] { if constexpr (NLDS == 1) return W + P.w_ek; else return SV; }();
-    gdbl_p Xg = W + P.w_xk;
+    gdbl_p Xg = W + P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
     auto tab_cag = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_cag); else return P.cag_sl; }();
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rA); else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
@@ -767,7 +860,10 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         // ---------------- solveKKT (ref :1471-1620) ----------------
         gcdbl_p bx = rhsk, by = rhsk + n, bz = rhsk + np;
         double nr = 0.;
-        FOR_T(i, P.Npad) { const double v = (i < N) ? rhsp[i] : 0.; SV[i] = v; nr = fmax(nr, fabs(v)); } // load the rhs; slots >= N stay 0
+        for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{rhsp[i < N ? i : N - 1]}; }, [&](int i, const V1 &r) {
+            const double v = (i < N) ? r.a : 0.; // load the rhs; slots >= N stay 0
+            SV[i] = v; nr = fmax(nr, fabs(v));
+        });
         nr = blk_reduce1<OpMax, T>(phase, nr);
         const double thr = (1. + nr) * LINSYSACC;
         double nerr_prev = DBL_MAX;
@@ -784,12 +880,11 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
                 tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
                 tri_sweep<T, false, false>(P.bsl, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
             }
-            if constexpr (NLDS == 1) { // the LDS vector becomes X again; master copy in the slab
-                if (k < 0) { FOR_T(i, N) Xg[i] = SV[i]; }
-                else { FOR_T(i, N) { const double dv = SV[i]; const double xv = Xg[i] + dv; dxr[i] = dv; Xg[i] = xv; SV[i] = xv; } }
+            if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
+                if (k >= 0) for_t_pre<T, 6>(N, [&](int i) { return V1{Xg[i]}; }, [&](int i, const V1 &r) { SV[i] = r.a + SV[i]; });
             } else {
-                if (k < 0) { FOR_T(i, P.Npad) X[i] = SV[i]; }                               // x = first solve (slot N.. = 0)
-                else { FOR_T(i, N) { const double dv = SV[i]; dxr[i] = dv; X[i] += dv; } } // x += dx_ref (ref :1602)
+                if (k < 0) for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{SV[i]}; }, [&](int i, const V1 &r) { X[i] = r.a; }); // x = first solve (slot N.. = 0)
+                else for_t_pre<T, 6>(N, [&](int i) { return V2{SV[i], X[i]}; }, [&](int i, const V2 &r) { dxr[i] = r.a; X[i] = r.b + r.a; }); // x += dx_ref (ref :1602)
             }
             if (tid == 0) wi.n_ldlsolve++;
             __syncthreads();
@@ -797,21 +892,26 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             k++;
             // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
             double nex = 0., ney = 0., nez = 0.;
-            ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_k, cagv, X, P.cag_slots, [&](int j, double s) {
-                const int o = P.ipx[j];
-                const double e = bx[j] - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
+            struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
+            ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_k, cagv, X, P.cag_slots, [&](int j) { return PreK{bx[j], 0., P.ipx[j], 0}; },
+                        [&](int j, double s, const PreK &pr) {
+                const int o = pr.o;
+                const double e = pr.b - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
                 E[o] = e; nex = fmax(nex, fabs(e));
             });
-            ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx_k, rAv, X, P.rA_slots, [&](int r, double s) {
-                const int o = P.ipy[r];
-                const double e = by[r] - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
+            ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx_k, rAv, X, P.rA_slots, [&](int r) { return PreK{by[r], 0., P.ipy[r], 0}; },
+                        [&](int r, double s, const PreK &pr) {
+                const int o = pr.o;
+                const double e = pr.b - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
                 E[o] = e; ney = fmax(ney, fabs(e));
             });
-            ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx_k, rGv, X, P.rG_slots, [&](int i, double s) {
-                const int o = P.ipz[i];
+            ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx_k, rGv, X, P.rG_slots,
+                        [&](int i) { return PreK{bz[i], lpv[i < l ? i : 0], P.ipz[i], (int)P.zdsign[i]}; },
+                        [&](int i, double s, const PreK &pr) {
+                const int o = pr.o;
                 const double xo = X[o];
-                double v = bz[i] - s + (double)P.zdsign[i] * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
-                if (i < l) { v += init ? xo : lpv[i] * xo; nez = fmax(nez, fabs(v)); } // ... + V dz (LP part)
+                double v = pr.b - s + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
+                if (i < l) { v += init ? xo : pr.w * xo; nez = fmax(nez, fabs(v)); } // ... + V dz (LP part)
                 E[o] = v;
             });
             if (P.nc > 0) {
@@ -854,19 +954,22 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             double nerr = fmax(nv[0], nv[2]);
             if (p > 0) nerr = fmax(nerr, nv[1]);
             if (k > 0 && nerr > nerr_prev) { // got worse: undo and quit (ref :1579-1585)
-                if constexpr (NLDS == 1) { FOR_T(i, N) { const double xv = Xg[i] - dxr[i]; Xg[i] = xv; X[i] = xv; } }
+                if constexpr (NLDS == 1) { FOR_T(i, N) X[i] = Xg[i]; } // Xg still holds the previous iterate
                 else { FOR_T(i, N) X[i] -= dxr[i]; }
                 k--;
                 break;
             }
             if (k == NITREF || nerr < thr || (k > 0 && nerr_prev < IRERRFACT * nerr)) break;
             nerr_prev = nerr;
-            if constexpr (NLDS == 1) { __syncthreads(); FOR_T(i, N) SV[i] = E[i]; } // residual -> sweep vector (unit stride)
+            if constexpr (NLDS == 1) { // another step: park the iterate in the slab, residual -> sweep vector (unit stride)
+                __syncthreads();
+                for_t_pre<T, 6>(N, [&](int i) { return V1{E[i]}; }, [&](int i, const V1 &r) { Xg[i] = X[i]; SV[i] = r.a; });
+            }
         }
         __syncthreads();
-        FOR_T(j, n) dx[j] = X[P.ipx[j]];
-        FOR_T(r, p) dy[r] = X[P.ipy[r]];
-        FOR_T(i, m) dz[i] = X[P.ipz[i]];
+        for_t_pre<T, 4>(n, [&](int j) { return V1{X[P.ipx[j]]}; }, [&](int j, const V1 &r) { dx[j] = r.a; });
+        for_t_pre<T, 4>(p, [&](int j) { return V1{X[P.ipy[j]]}; }, [&](int j, const V1 &r) { dy[j] = r.a; });
+        for_t_pre<T, 8>(m, [&](int i) { return V1{X[P.ipz[i]]}; }, [&](int i, const V1 &r) { dz[i] = r.a; });
         __syncthreads();
         kref = k;
         TICK_END(TK_KRES);
@@ -875,13 +978,13 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     // ---------------- post-processing of each KKT stage ----------------
     if (stage == ST_KKT_INIT1) { // ref :933-939
         if (tid == 0) wi.nitref1 = kref;
-        FOR_T(j, n) wx[j] = dx1[j];
+        for_t_pre<T, 4>(n, [&](int j) { return V1{dx1[j]}; }, [&](int j, const V1 &r) { wx[j] = r.a; });
         dev_bring_to_cone<T>(ps, dz1, -1., wsl);
         stage = ST_KKT_INIT2;
     } else if (stage == ST_KKT_INIT2) { // ref :966-992
-        FOR_T(j, p) wy[j] = dy2[j];
+        for_t_pre<T, 4>(p, [&](int j) { return V1{dy2[j]}; }, [&](int j, const V1 &r) { wy[j] = r.a; });
         dev_bring_to_cone<T>(ps, dz2, 1., wz);
-        FOR_T(j, n) { const double v = -cv[j]; rhs1[P.ipx[j]] = v; rhs1k[j] = v; }
+        for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], cv[j]}; }, [&](int j, const IV1 &r) { const double v = -r.a; rhs1[r.i] = v; rhs1k[j] = v; });
         if (tid == 0) {
             wi.nitref2 = kref;
             wi.kap = 1.; wi.tau = 1.; wi.step = 0.; wi.step_aff = 0.; wi.pinf = 0; wi.dinf = 0;
@@ -890,26 +993,27 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         __syncthreads();
         stage = ST_RESID;
     } else if (stage == ST_KKT1) { // RHSaffine (ref :1670-1689)
-        FOR_T(j, n) { const double v = rx[j]; rhs2[P.ipx[j]] = v; rhs2k[j] = v; }
-        FOR_T(r, p) { const double v = -ry[r]; rhs2[P.ipy[r]] = v; rhs2k[n + r] = v; }
-        FOR_T(i, m) { const double v = wsl[i] - rz[i]; rhs2[P.ipz[i]] = v; rhs2k[np + i] = v; } // expansion slots stay 0
+        for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], rx[j]}; }, [&](int j, const IV1 &r) { rhs2[r.i] = r.a; rhs2k[j] = r.a; });
+        for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], ry[j]}; }, [&](int j, const IV1 &r) { rhs2[r.i] = -r.a; rhs2k[n + j] = -r.a; });
+        for_t_pre<T, 8>(m, [&](int i) { return IV2{P.ipz[i], wsl[i], rz[i]}; },
+                        [&](int i, const IV2 &r) { const double v = r.a - r.b; rhs2[r.i] = v; rhs2k[np + i] = v; }); // expansion slots stay 0
         __syncthreads();
         stage = ST_KKT_AFF;
     } else if (stage == ST_KKT_AFF) { // ref :1181-1210
         double d6[6] = {0, 0, 0, 0, 0, 0}; // c.dx1 b.dy1 h.dz1 c.dx2 b.dy2 h.dz2
-        FOR_T(j, n) { const double c_ = cv[j]; d6[0] += c_ * dx1[j]; d6[3] += c_ * dx2[j]; }
-        FOR_T(r, p) { const double b_ = bv[r]; d6[1] += b_ * dy1[r]; d6[4] += b_ * dy2[r]; }
-        FOR_T(i, m) { const double h_ = hv[i]; d6[2] += h_ * dz1[i]; d6[5] += h_ * dz2[i]; }
+        for_t_pre<T, 4>(n, [&](int j) { return V3{cv[j], dx1[j], dx2[j]}; }, [&](int j, const V3 &r) { d6[0] += r.a * r.b; d6[3] += r.a * r.c; });
+        for_t_pre<T, 4>(p, [&](int j) { return V3{bv[j], dy1[j], dy2[j]}; }, [&](int j, const V3 &r) { d6[1] += r.a * r.b; d6[4] += r.a * r.c; });
+        for_t_pre<T, 4>(m, [&](int i) { return V3{hv[i], dz1[i], dz2[i]}; }, [&](int i, const V3 &r) { d6[2] += r.a * r.b; d6[5] += r.a * r.c; });
         blk_reduce<OpSum, T, 6>(phase, d6);
         const double kap = wi.kap, tau = wi.tau;
         const double dtau_denom = kap / tau - d6[0] - d6[1] - d6[2];
         const double dtauaff = (g_S.sv[SV_RT] - kap + d6[3] + d6[4] + d6[5]) / dtau_denom;
         const double dkapaff = -kap - kap / tau * dtauaff;
-        FOR_T(i, m) dz2[i] += dtauaff * dz1[i];
+        for_t_pre<T, 8>(m, [&](int i) { return V2{dz2[i], dz1[i]}; }, [&](int i, const V2 &r) { dz2[i] = r.a + dtauaff * r.b; });
         __syncthreads();
         if (tid == 0) { g_S.sv[SV_DTAUDEN] = dtau_denom; g_S.sv[SV_DTAUAFF] = dtauaff; g_S.sv[SV_DKAPAFF] = dkapaff; }
         dev_scale<T>(ps, W, dz2, wdz);
-        FOR_T(i, m) dsw[i] = -wdz[i] - lam[i];
+        for_t_pre<T, 8>(m, [&](int i) { return V2{wdz[i], lam[i]}; }, [&](int i, const V2 &r) { dsw[i] = -r.a - r.b; });
         const double step_aff = dev_line_search<T>(ps, W, tau, dtauaff, kap, dkapaff);
         const double oms_ = 1. - step_aff;
         const double sigma = fmin(fmax(oms_ * oms_ * oms_, SIGMAMIN), SIGMAMAX);
@@ -918,13 +1022,13 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         if (tid == 0) { wi.step_aff = step_aff; wi.sigma = sigma; }
         // ---- RHScombined (ref :1282-1325) ----
         const double sigmamu = sigma * mu, oms = 1. - sigma;
-        FOR_T(i, l) { // LP part: ds1 = lam*lam + dsw*wdz - sigmamu ; dsw = ds1/lam ; t1 = w*dsw
-            const double li = lam[i];
-            const double d1_ = li * li + dsw[i] * wdz[i] - sigmamu;
-            const double q_ = d1_ / li;
+        for_t_pre<T, 4>(l, [&](int i) { return V4{lam[i], dsw[i], wdz[i], lpw[i]}; }, [&](int i, const V4 &r) {
+            // LP part: ds1 = lam*lam + dsw*wdz - sigmamu ; dsw = ds1/lam ; t1 = w*dsw
+            const double d1_ = r.a * r.a + r.b * r.c - sigmamu;
+            const double q_ = d1_ / r.a;
             dsw[i] = q_;
-            t1[i] = lpw[i] * q_;
-        }
+            t1[i] = r.d * q_;
+        });
         if (P.nc > 0) {
             for_cones<T>(ps, [&](int c, auto G, int ln) {
                 constexpr int g = decltype(G)::value;
@@ -963,33 +1067,33 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             });
         }
         __syncthreads();
-        FOR_T(j, n) { const double v = rhs2k[j] * oms; rhs2k[j] = v; rhs2[P.ipx[j]] = v; }
-        FOR_T(r, p) { const double v = rhs2k[n + r] * oms; rhs2k[n + r] = v; rhs2[P.ipy[r]] = v; }
-        FOR_T(i, m) { const double v = -oms * rz[i] + t1[i]; rhs2k[np + i] = v; rhs2[P.ipz[i]] = v; }
+        for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], rhs2k[j]}; }, [&](int j, const IV1 &r) { const double v = r.a * oms; rhs2k[j] = v; rhs2[r.i] = v; });
+        for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], rhs2k[n + j]}; }, [&](int j, const IV1 &r) { const double v = r.a * oms; rhs2k[n + j] = v; rhs2[r.i] = v; });
+        for_t_pre<T, 8>(m, [&](int i) { return IV2{P.ipz[i], rz[i], t1[i]}; }, [&](int i, const IV2 &r) { const double v = -oms * r.a + r.b; rhs2k[np + i] = v; rhs2[r.i] = v; });
         __syncthreads();
         stage = ST_KKT_COMB;
     } else { // ST_KKT_COMB, ref :1212-1252
         double e3[3] = {0, 0, 0};
-        FOR_T(j, n) e3[0] += cv[j] * dx2[j];
-        FOR_T(r, p) e3[1] += bv[r] * dy2[r];
-        FOR_T(i, m) e3[2] += hv[i] * dz2[i];
+        for_t_pre<T, 4>(n, [&](int j) { return V2{cv[j], dx2[j]}; }, [&](int j, const V2 &r) { e3[0] += r.a * r.b; });
+        for_t_pre<T, 4>(p, [&](int j) { return V2{bv[j], dy2[j]}; }, [&](int j, const V2 &r) { e3[1] += r.a * r.b; });
+        for_t_pre<T, 8>(m, [&](int i) { return V2{hv[i], dz2[i]}; }, [&](int i, const V2 &r) { e3[2] += r.a * r.b; });
         blk_reduce<OpSum, T, 3>(phase, e3);
         const double kap = wi.kap, tau = wi.tau, sigma = wi.sigma;
         const double dtauaff = g_S.sv[SV_DTAUAFF], dkapaff = g_S.sv[SV_DKAPAFF];
         const double bkap = kap * tau + dkapaff * dtauaff - sigma * wi.mu;
         const double dtau = ((1. - sigma) * g_S.sv[SV_RT] - bkap / tau + e3[0] + e3[1] + e3[2]) / g_S.sv[SV_DTAUDEN];
         const double dkap = -(bkap + kap * dtau) / tau;
-        FOR_T(j, n) dx2[j] += dtau * dx1[j];
-        FOR_T(r, p) dy2[r] += dtau * dy1[r];
-        FOR_T(i, m) dz2[i] += dtau * dz1[i];
+        for_t_pre<T, 4>(n, [&](int j) { return V2{dx2[j], dx1[j]}; }, [&](int j, const V2 &r) { dx2[j] = r.a + dtau * r.b; });
+        for_t_pre<T, 4>(p, [&](int j) { return V2{dy2[j], dy1[j]}; }, [&](int j, const V2 &r) { dy2[j] = r.a + dtau * r.b; });
+        for_t_pre<T, 8>(m, [&](int i) { return V2{dz2[i], dz1[i]}; }, [&](int i, const V2 &r) { dz2[i] = r.a + dtau * r.b; });
         __syncthreads();
         dev_scale<T>(ps, W, dz2, wdz);
-        FOR_T(i, m) dsw[i] = -(dsw[i] + wdz[i]);
+        for_t_pre<T, 8>(m, [&](int i) { return V2{dsw[i], wdz[i]}; }, [&](int i, const V2 &r) { dsw[i] = -(r.a + r.b); });
         const double st = GAMMA * dev_line_search<T>(ps, W, tau, dtau, kap, dkap);
         dev_scale<T>(ps, W, dsw, dsa);
-        FOR_T(j, n) wx[j] += st * dx2[j];
-        FOR_T(r, p) wy[r] += st * dy2[r];
-        FOR_T(i, m) { wz[i] += st * dz2[i]; wsl[i] += st * dsa[i]; }
+        for_t_pre<T, 4>(n, [&](int j) { return V2{wx[j], dx2[j]}; }, [&](int j, const V2 &r) { wx[j] = r.a + st * r.b; });
+        for_t_pre<T, 4>(p, [&](int j) { return V2{wy[j], dy2[j]}; }, [&](int j, const V2 &r) { wy[j] = r.a + st * r.b; });
+        for_t_pre<T, 4>(m, [&](int i) { return V4{wz[i], dz2[i], wsl[i], dsa[i]}; }, [&](int i, const V4 &r) { wz[i] = r.a + st * r.b; wsl[i] = r.c + st * r.d; });
         if (tid == 0) {
             wi.nitref3 = kref; wi.step = st;
             wi.kap = kap + st * dkap;
@@ -1018,7 +1122,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
             wi = *ginfo; g_S.bi = wi;
             wi.n_factor = 0; wi.n_ldlsolve = 0;
             g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7;
-        for (int q = 0; q < 8; q++) g_S.tick[q] = 0;
+        for (int q = 0; q < 12; q++) g_S.tick[q] = 0;
         g_S.tick[7] = wall_clock64();
         }
         // resetKKTScalings (ref :807-846)
@@ -1034,6 +1138,10 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
         FOR_T(i, N) { rhs1[i] = 0.; rhs2[i] = 0.; }
         FOR_T(i, np + m) { rhs1k[i] = 0.; rhs2k[i] = 0.; }
         __syncthreads();
+        { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
+            gdbl_p Kt = W + P.w_Kt;
+            FOR_T(t, P.fac_nt) Kt[t] = I[P.fac_src[t]];
+        }
         {
             double nr3[3] = {0., 0., 0.};
             FOR_T(j, n) { const double c_ = cv[j]; rhs2[P.ipx[j]] = -c_; rhs2k[j] = -c_; nr3[0] += c_ * c_; }
@@ -1066,12 +1174,13 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
         gdbl_p tr = W + P.w_trace + (size_t)(TRACE_ROWS - 1) * TRACE_COLS;
         for (int q = 0; q < TK_COUNT; q++) tr[q] = (double)g_S.tick[q] * 0.01;
         tr[6] = (double)(wall_clock64() - g_S.tick[7]) * 0.01;
+        for (int q = 8; q < 12; q++) tr[q - 1] = (double)g_S.tick[q] * 0.01; // factor: phase A, barrier, phase B, barrier
     }
 }
 
 template <int T, int NLDS>
 __global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
-    int ps, double *inst, double *work, int B) {
+    int ps, double *inst, double *work, int B, int *queue, const int *order) {
     const DevPat &P = c_pat[ps];
     gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
@@ -1084,11 +1193,38 @@ __global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
         stage(P.rA_sl, P.rA_ns, P.lm_rA); stage(P.rG_sl, P.rG_ns, P.lm_rG);
         __syncthreads();
     }
-    for (int i = blockIdx.x; i < B; i += gridDim.x) {
-        solve_instance<T, NLDS>(ps, (gdbl_p)inst + (size_t)i * P.inst_stride, W);
+    // Instances differ in iteration count (12..18 on the headline batch): after its first instance (= its own
+    // index, so that workspace slot i holds the history of instance i when the batch fits the grid) a workgroup
+    // pulls the next unsolved instance from a queue instead of striding through the batch.
+    // `order` (batches larger than the grid): instances sorted by the work their previous solve took, longest first.
+    for (int i = blockIdx.x; i < B;) {
+        const int id = order ? order[i] : i;
+        solve_instance<T, NLDS>(ps, (gdbl_p)inst + (size_t)id * P.inst_stride, W);
         __syncthreads();
+        if (threadIdx.x == 0) g_S.next = (int)gridDim.x + atomicAdd(queue, 1);
+        __syncthreads();
+        i = g_S.next;
     }
 }
+// Longest-processing-time-first order for k_solve's queue: instances keyed by the number of LDL solves of their
+// previous solve (DevInfo::n_ldlsolve; 0 before the first solve), counting sort, descending.  One workgroup.
+__global__ __launch_bounds__(1024) void k_order(int ps, const double *inst, int B, int *order) {
+    const DevPat &P = c_pat[ps];
+    constexpr int NB = 1024;
+    __shared__ int cnt[NB];
+    for (int k = threadIdx.x; k < NB; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    auto key = [&](int i) {
+        const DevInfo *di = reinterpret_cast<const DevInfo *>(inst + (size_t)i * P.inst_stride + P.i_info);
+        return NB - 1 - min(max(di->n_ldlsolve, 0), NB - 1); // descending
+    };
+    for (int i = threadIdx.x; i < B; i += blockDim.x) atomicAdd(&cnt[key(i)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < NB; k++) { const int c = cnt[k]; cnt[k] = run; run += c; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) order[atomicAdd(&cnt[key(i)], 1)] = i;
+}
+
 // ============================================================================================
 // updateData for a range of instances: reference updateData(double*...) src/eicos.cpp:2053-2082
 // = unsetEquilibration (:389-404) -> copy-in -> setEquilibration (:302-374) -> transposes.
@@ -1181,41 +1317,15 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
     }
 }
 
-// Debug: factorise instance `i` with the KKT scaling block as it stands in memory.
+// Debug: factorise instance `i` with the KKT scaling block as it stands in memory (runs the solver's own stage).
 template <int T>
-__global__ __launch_bounds__(T) void k_debug_factor(int ps, double *inst, double *work, int i) {
+__global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_debug_factor(int ps, double *inst, double *work, int i) {
     const DevPat &P = c_pat[ps];
-    const int tid = threadIdx.x;
-    gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, W = (gdbl_p)work;
-    gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD;
-    for (int lv0 = 0; lv0 < P.fac_ns;) {
-        int lv1 = lv0;
-        for (int sl = lv0; sl < P.fac_ns; sl++) {
-            const SliceMeta m = P.fac_sl[sl];
-            if (m.newlev && sl > lv0) break;
-            lv1 = sl + 1;
-            const int lanes = m.cnt << m.lg;
-            double acc = 0.;
-            if (tid < lanes)
-                for (int kk = 0; kk < m.K; kk++) { const int slot = m.off + kk * lanes + tid; acc += U[P.fac_pa[slot]] * UF[P.fac_pb[slot]]; }
-            for (int o = (1 << m.lg) >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (tid < lanes && (tid & ((1 << m.lg) - 1)) == 0) {
-                const int t = m.row0 + (tid >> m.lg);
-                const double val = I[P.fac_src[t]] - acc;
-                const int dst = P.fac_dst[t];
-                if (dst < 0) { D[-dst - 1] = val; invD[-dst - 1] = 1. / val; }
-                else U[dst] = val;
-            }
-        }
-        __syncthreads();
-        for (int sl = lv0; sl < lv1; sl++)
-            for (int r = tid; r < P.fac_sl[sl].cnt; r += T) {
-                const int t = P.fac_sl[sl].row0 + r, dst = P.fac_dst[t];
-                if (dst >= 0) UF[P.fac_dstF[t]] = U[dst] * invD[P.fac_col[t]];
-            }
-        __syncthreads();
-        lv0 = lv1;
-    }
+    if (threadIdx.x == 0) { g_S.fl[FL_FATAL] = 0; g_S.wi.n_factor = 0; for (int k = 0; k < 12; k++) g_S.tick[k] = 0; }
+    gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
+    for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
+    __syncthreads();
+    stage_factor<T>(ps, I, (gdbl_p)work, -1);
 }
 
 // ---- launchers (called from api.cpp) ----
@@ -1231,11 +1341,18 @@ template <class F> static auto dispatch_solve(int threads, int nlds, F &&f) {
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
 }
-hipError_t launch_solve(int ps, double *inst, double *work, int B, int grid, int threads, int nlds,
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
                         size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // instance queue of this launch
+    if (e != hipSuccess) return e;
+    if (B <= grid) order = nullptr; // everything starts at once: identity (slot i = instance i, eicos_debug_trace)
+    else {
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     return dispatch_solve(threads, nlds, [&](const void *fn) {
-        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B};
+        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
 }
@@ -1245,8 +1362,14 @@ hipError_t launch_update(int ps, double *inst, int first, int count, const doubl
     hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
     return hipGetLastError();
 }
-hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, hipStream_t st) {
-    hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), 0, st, ps, inst, work, i);
+hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int threads, hipStream_t st) {
+    switch (threads) { // the factor program is built for the handle's workgroup size
+    case 128: hipLaunchKernelGGL(k_debug_factor<128>, dim3(1), dim3(128), 0, st, ps, inst, work, i); break;
+    case 256: hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), 0, st, ps, inst, work, i); break;
+    case 512: hipLaunchKernelGGL(k_debug_factor<512>, dim3(1), dim3(512), 0, st, ps, inst, work, i); break;
+    case 1024: hipLaunchKernelGGL(k_debug_factor<1024>, dim3(1), dim3(1024), 0, st, ps, inst, work, i); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 hipError_t solve_occupancy(int threads, int nlds, size_t dyn_lds, int *blocks_per_cu) {

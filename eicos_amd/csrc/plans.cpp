@@ -5,6 +5,22 @@
 
 namespace eicos {
 
+// Append slice `m`, cut into sub-slices of at most ELL_KMAX entries per lane (the depth the kernels prefetch);
+// the slot layout (off + k*lanes + lane) is unchanged, sub-slice j simply starts at k = j*ELL_KMAX.
+static void push_subslices(std::vector<SliceMeta> &sl, SliceMeta m) {
+    const int lanes = m.cnt << m.lg, K = m.K;
+    if (K <= ELL_KMAX) { sl.push_back(m); return; }
+    for (int k0 = 0; k0 < K; k0 += ELL_KMAX) {
+        SliceMeta s = m;
+        s.K = std::min(ELL_KMAX, K - k0);
+        s.off = m.off + k0 * lanes;
+        s.newlev = (k0 == 0) ? m.newlev : 0;
+        s.cont = (k0 > 0);
+        s.more = (k0 + ELL_KMAX < K);
+        sl.push_back(s);
+    }
+}
+
 TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
     TriPlan pl;
     pl.pos.assign(S.nnzL, 0);
@@ -29,7 +45,7 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
             int lg = 0;
             while ((1 << lg) < g) lg++;
             const int lanes = cnt * g;
-            pl.sl.push_back(SliceMeta{r, cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
+            push_subslices(pl.sl, SliceMeta{r, cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
             pl.idx.resize((size_t)pl.slots + (size_t)K * lanes, S.N); // padding gathers the zero slot N
             for (int i = r; i < r + cnt; i++)
                 for (int e = ptr[i]; e < ptr[i + 1]; e++) {
@@ -67,7 +83,7 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
             const int K = (int)((len(r) + g - 1) / g), lanes = cnt * g;
             int lg = 0;
             while ((1 << lg) < g) lg++;
-            pl.sl.push_back(SliceMeta{(int)pl.target.size(), cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
+            push_subslices(pl.sl, SliceMeta{(int)pl.target.size(), cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
             pl.pa.resize((size_t)pl.slots + (size_t)K * lanes, dummyB);
             pl.pb.resize(pl.pa.size(), dummyF);
             for (int i = r; i < r + cnt; i++) {
@@ -107,7 +123,7 @@ EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T) {
         const int g = gof(mx), K = (mx + g - 1) / g, lanes = cnt * g;
         int lg = 0;
         while ((1 << lg) < g) lg++;
-        pl.sl.push_back(SliceMeta{r, cnt, lg, K, pl.slots, 0, 0, 0});
+        push_subslices(pl.sl, SliceMeta{r, cnt, lg, K, pl.slots, 0, 0, 0});
         pl.src.resize((size_t)pl.slots + (size_t)K * lanes, -1);
         for (int i = r; i < r + cnt; i++)
             for (int e = ptr[i]; e < ptr[i + 1]; e++) {
