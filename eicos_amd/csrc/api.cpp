@@ -275,6 +275,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     {
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs; D.lm_cag = D.lm_b + D.nbs; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
+        if (D.fac_ns <= 512) { D.lm_fac = D.lm_total; D.lm_total += D.fac_ns; } // factor program's table too, when small
+        else D.lm_fac = -1;
         const size_t meta = (size_t)D.lm_total * sizeof(SliceMeta);
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
         // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
@@ -590,7 +592,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                 if (getenv("EICOS_PLAN_STATS")) { // developer aid: shape of the three programs for this workgroup size
                     auto stat = [&](const char *nm, const std::vector<SliceMeta> &sl, int slots) {
                         int lev = 0, kmax = 0; long lanes = 0, kl = 0;
-                        for (const SliceMeta &m : sl) { lev += m.newlev; kmax = std::max(kmax, m.K); lanes += (long)m.cnt << m.lg; kl += (long)m.K; }
+                        for (const SliceMeta &m : sl) { lev += m.newlev & 1; kmax = std::max(kmax, m.K); lanes += (long)m.cnt << m.lg; kl += (long)m.K; }
                         fprintf(stderr, "[plan T=%d] %-8s slices %zu levels %d slots %d sum(K) %ld maxK %d active-lane slices %.2f\n", T, nm,
                                 sl.size(), lev, slots, kl, kmax, (double)lanes / T);
                     };
@@ -604,7 +606,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                 std::vector<double> carry;
                 while (s0 < px.sl.size()) { // one level at a time: phase A (U, D), then phase B (L = U / D[col])
                     size_t s1 = s0 + 1;
-                    while (s1 < px.sl.size() && !px.sl[s1].newlev) s1++;
+                    while (s1 < px.sl.size() && !(px.sl[s1].newlev & 1)) s1++;
                     for (size_t si = s0; si < s1; si++) {
                         const SliceMeta &m = px.sl[si];
                         const int g = 1 << m.lg, lanes = m.cnt * g;

@@ -70,7 +70,7 @@ struct DevPat {
     const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
-    int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_total;
+    int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
     gint_p f_idx, b_idx, posF, posB;
     // numeric factorisation: sliced-ELL program (plans.hpp: FactorPlan); per target: source offset of its
     // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot

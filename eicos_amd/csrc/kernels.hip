@@ -498,7 +498,7 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
     (void)n; (void)p; (void)m; (void)l; (void)N; (void)np; (void)lane; (void)wave; (void)phase; (void)wi;
 
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
-template <int T>
+template <int T, int NLDS>
 __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
@@ -518,11 +518,14 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
     double carry = 0.; // partial sum of targets cut into sub-slices
     const int ns = P.fac_ns;
+    const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     auto fload = [&](int sidx, FSlot &o) {
-        const SliceMeta nm = P.fac_sl[sidx];
-        o.row0 = uni(nm.row0); o.cnt = uni(nm.cnt); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off); o.newlev = uni(nm.newlev);
+        SliceMeta nm;
+        if (tab_lds) nm = LDS_TABLE(P.lm_fac)[sidx]; else nm = P.fac_sl[sidx];
+        o.row0 = uni(nm.row0); o.cnt = uni(nm.cnt); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off);
+        const int nl = uni(nm.newlev);
+        o.newlev = nl & 1; o.last = nl >> 1;
         o.more = uni(nm.more); o.cont = uni(nm.cont);
-        o.last = (sidx + 1 >= ns) ? 1 : uni(P.fac_sl[sidx + 1].newlev);
         o.lanes = o.cnt << o.lg;
         const bool act = tid < o.lanes;
 #pragma unroll
@@ -1157,7 +1160,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     int stage = ST_FACTOR;
     int iter = -1; // -1 while initialising
     while (stage != ST_DONE) {
-        if (stage == ST_FACTOR) stage = stage_factor<T>(ps, I, W, iter);
+        if (stage == ST_FACTOR) stage = stage_factor<T, NLDS>(ps, I, W, iter);
         else if (stage == ST_RESID) stage = stage_resid<T, NLDS>(ps, I, W, iter);
         else {
             const int prev = stage;
@@ -1191,6 +1194,7 @@ __global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
         };
         stage(P.fsl, P.nfs, P.lm_f); stage(P.bsl, P.nbs, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
         stage(P.rA_sl, P.rA_ns, P.lm_rA); stage(P.rG_sl, P.rG_ns, P.lm_rG);
+        if (P.lm_fac >= 0) stage(P.fac_sl, P.fac_ns, P.lm_fac);
         __syncthreads();
     }
     // Instances differ in iteration count (12..18 on the headline batch): after its first instance (= its own
@@ -1325,7 +1329,7 @@ __global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_debug_factor(int ps, 
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
     for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
     __syncthreads();
-    stage_factor<T>(ps, I, (gdbl_p)work, -1);
+    stage_factor<T, 0>(ps, I, (gdbl_p)work, -1);
 }
 
 // ---- launchers (called from api.cpp) ----

@@ -101,6 +101,9 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
         }
     }
     pl.pa.push_back(dummyB); pl.pb.push_back(dummyF); // dummy slot `slots`
+    // newlev bit 1: last slice of its level (the kernel runs the level's second phase after it)
+    for (size_t i = 0; i < pl.sl.size(); i++)
+        if (i + 1 == pl.sl.size() || (pl.sl[i + 1].newlev & 1)) pl.sl[i].newlev |= 2;
     return pl;
 }
 
