@@ -210,7 +210,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
 
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     TriPlan planF = build_tri_plan(S, h->threads, true), planB = build_tri_plan(S, h->threads, false);
-    D.nfs = (int)planF.sl.size(); D.nbs = (int)planB.sl.size(); D.nUF = planF.slots; D.nUB = planB.slots;
+    D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nUF = planF.slots; D.nUB = planB.slots;
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     h->posB = planB.pos;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
@@ -273,7 +273,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     // 160 KiB per CU minus the static block (reductions + scalar state)
     D.Npad = (S.N + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding
     {
-        D.lm_f = 0; D.lm_b = D.lm_f + D.nfs; D.lm_cag = D.lm_b + D.nbs; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
+        D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
         if (D.fac_ns <= 512) { D.lm_fac = D.lm_total; D.lm_total += D.fac_ns; } // factor program's table too, when small
         else D.lm_fac = -1;
@@ -598,6 +598,15 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                     };
                     stat("forward", pf.sl, pf.slots); stat("backward", pb.sl, pb.slots); stat("factor", px.sl, px.slots);
                     fprintf(stderr, "[plan T=%d] factor targets %zu pairs %lld\n", T, px.target.size(), (long long)S.tp.back());
+                    if (T == 512) {
+                        fprintf(stderr, "[plan] level sizes:");
+                        for (int v = 0; v < S.nlev; v++) fprintf(stderr, " %d", S.lev_ptr[v + 1] - S.lev_ptr[v]);
+                        fprintf(stderr, "\n[plan T=512] backward slices (lanes x K):");
+                        for (const SliceMeta &m : pb.sl) fprintf(stderr, " %d%sx%d", m.cnt << m.lg, (m.newlev & 1) ? "*" : "", m.K);
+                        fprintf(stderr, "\n[plan T=512] forward slices (lanes x K):");
+                        for (const SliceMeta &m : pf.sl) fprintf(stderr, " %d%sx%d", m.cnt << m.lg, (m.newlev & 1) ? "*" : "", m.K);
+                        fprintf(stderr, "\n");
+                    }
                 }
                 std::vector<double> D2(N, 0.0), iD2(N, 0.0);
                 std::vector<int> colof(S.nnzL);

@@ -68,7 +68,8 @@ struct DevPat {
     // triangular solves: sliced-ELL plans (see SliceMeta).  UF = unit-lower L in the forward (row) slot order,
     // UB = U = L.*D (column-scaled) in the backward (column) slot order; posF/posB map a CSC entry of L to its slots
     const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
-    int nfs, nbs, nUF, nUB;
+    int nfs, nbs, nUF, nUB;   // nfs / nbs = slices of the workgroup-wide part of the forward / backward plan
+    int nfs_solo, nbs_solo;   // single-wavefront part (top of the tree): fsl = [wide | solo], bsl = [solo | wide]
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
     gint_p f_idx, b_idx, posF, posB;

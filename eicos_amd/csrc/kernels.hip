@@ -260,9 +260,13 @@ __device__ __forceinline__ void lds_barrier() {
 // Index/value/invD loads run TRI_DEPTH slices ahead of their use: they do not depend on ws, so
 // their HBM/L2 latency overlaps earlier levels and the dependent part of a level is only LDS
 // gathers + one LDS store + the barrier.  `sm` points to the slice table (LDS copy when staged).
-template <int T, bool FORWARD, bool LDSBAR, class SM, class WS>
+// SOLO: the narrow top of the elimination tree, laid out for 64 lanes and run by wavefront 0 alone -- no
+// workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
+// wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
+    if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
         int row0, lg, K, off, lanes, newlev, more, cont;
@@ -296,7 +300,11 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
             const int s = s0 + d;
             const Slot c = q[d];
             load(min(s + TRI_DEPTH, ns - 1), q[d]);
-            if (c.newlev) { if (LDSBAR) lds_barrier(); else __syncthreads(); }
+            if (c.newlev) {
+                if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
+                else if (LDSBAR) lds_barrier();
+                else __syncthreads();
+            }
             double acc = 0.;
 #pragma unroll
             for (int kk = 0; kk < ELL_KMAX; kk++) acc += c.val[kk] * ws[c.idx[kk]];
@@ -311,7 +319,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
             }
         }
     }
-    __syncthreads();
+    if (!SOLO) __syncthreads();
 }
 
 // ---------------- lambda = W z (ref scale :485-507); ends with a barrier ----------------
@@ -875,13 +883,25 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             // -------- SV <- L^-T D^-1 L^-1 SV in elimination order (replaces ldlt.solve, ref :1477,1599) --------
             TICK_END(TK_KRES);
             __syncthreads();
+            // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
+            const bool wave0 = uni(tid >> 6) == 0;
             if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-                tri_sweep<T, true, true>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
-                TICK_END(TK_FWD);
-                tri_sweep<T, false, true>(LDS_TABLE(P.lm_b), P.nbs, P.b_idx, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, true, false>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
+                if (wave0) {
+                    tri_sweep<T, true, true, true>(LDS_TABLE(P.lm_f) + P.nfs, P.nfs_solo, P.f_idx, UF, invD, SV, P.nUF);
+                    TICK_END(TK_FWD);
+                    tri_sweep<T, false, true, true>(LDS_TABLE(P.lm_b), P.nbs_solo, P.b_idx, UB, invD, SV, P.nUB);
+                }
+                __syncthreads();
+                tri_sweep<T, false, true, false>(LDS_TABLE(P.lm_b) + P.nbs_solo, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
             } else {
-                tri_sweep<T, true, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
-                tri_sweep<T, false, false>(P.bsl, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, false, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
+                if (wave0) {
+                    tri_sweep<T, true, false, true>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, UF, invD, SV, P.nUF);
+                    tri_sweep<T, false, false, true>(P.bsl, P.nbs_solo, P.b_idx, UB, invD, SV, P.nUB);
+                }
+                __syncthreads();
+                tri_sweep<T, false, false, false>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
             }
             if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
                 if (k >= 0) for_t_pre<T, 6>(N, [&](int i) { return V1{Xg[i]}; }, [&](int i, const V1 &r) { SV[i] = r.a + SV[i]; });
@@ -1192,7 +1212,7 @@ __global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
             gint_p si = reinterpret_cast<gint_p>(src);
             for (int q = threadIdx.x; q < cnt * 8; q += T) dst[at * 8 + q] = si[q];
         };
-        stage(P.fsl, P.nfs, P.lm_f); stage(P.bsl, P.nbs, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
+        stage(P.fsl, P.nfs + P.nfs_solo, P.lm_f); stage(P.bsl, P.nbs + P.nbs_solo, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
         stage(P.rA_sl, P.rA_ns, P.lm_rA); stage(P.rG_sl, P.rG_ns, P.lm_rG);
         if (P.lm_fac >= 0) stage(P.fac_sl, P.fac_ns, P.lm_fac);
         __syncthreads();

@@ -21,27 +21,37 @@ static void push_subslices(std::vector<SliceMeta> &sl, SliceMeta m) {
     }
 }
 
-TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
+TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) {
     TriPlan pl;
     pl.pos.assign(S.nnzL, 0);
     const std::vector<int> &ptr = forward ? S.Rp : S.Lp;
     const std::vector<int> &ind = forward ? S.Rj : S.Li;
     auto len = [&](int r) { return ptr[r + 1] - ptr[r]; };
     auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
-    auto emit_level = [&](int v) {
+    // shape of the next slice of a level at workgroup width Tw: rows [r, r+cnt), g lanes per row, K entries per lane
+    auto shape = [&](int r, int end, int Tw, int &g, int &cnt, int &K) {
+        // lanes per row from the longest row among the next Tw candidates (rows of a level are
+        // sorted by decreasing row length, so for the forward plan this is row r itself)
+        int mx = 0;
+        for (int i = r; i < std::min(end, r + Tw); i++) mx = std::max(mx, len(i));
+        g = std::max(1, std::min(64, pow2ceil((mx + ELL_KMAX - 1) / ELL_KMAX)));
+        cnt = std::min(Tw / g, end - r);
+        mx = 0;
+        for (int i = r; i < r + cnt; i++) mx = std::max(mx, len(i));
+        K = (mx + g - 1) / g;
+    };
+    auto slices_of = [&](int v, int Tw) {
+        int r = S.lev_ptr[v], n = 0;
+        while (r < S.lev_ptr[v + 1]) { int g, cnt, K; shape(r, S.lev_ptr[v + 1], Tw, g, cnt, K); r += cnt; n++; }
+        return n;
+    };
+    auto emit_level = [&](int v, int Tw) {
         int r = S.lev_ptr[v];
         const int end = S.lev_ptr[v + 1];
         bool first = true;
         while (r < end) {
-            // lanes per row from the longest row among the next T candidates (rows of a level are
-            // sorted by decreasing row length, so for the forward plan this is row r itself)
-            int mx = 0;
-            for (int i = r; i < std::min(end, r + T); i++) mx = std::max(mx, len(i));
-            const int g = std::max(1, std::min(64, pow2ceil((mx + ELL_KMAX - 1) / ELL_KMAX)));
-            const int cnt = std::min(T / g, end - r);
-            mx = 0;
-            for (int i = r; i < r + cnt; i++) mx = std::max(mx, len(i));
-            const int K = (mx + g - 1) / g;
+            int g, cnt, K;
+            shape(r, end, Tw, g, cnt, K);
             int lg = 0;
             while ((1 << lg) < g) lg++;
             const int lanes = cnt * g;
@@ -59,11 +69,26 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward) {
             first = false;
         }
     };
-    // forward (L y = b, unit lower L): level-0 rows (leaves of the elimination tree) have no entries: y = b
-    if (forward) for (int v = 1; v < S.nlev; v++) emit_level(v);
-    else for (int v = S.nlev - 1; v >= 0; v--) emit_level(v);
+    auto pad = [&]() { // empty slices: no loop tail in the kernel's TRI_DEPTH-deep software pipeline
+        while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0});
+    };
+    // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
+    const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
+    int vs = S.nlev;
+    if (allow_solo) while (vs > v_first && slices_of(vs - 1, 64) <= 2) vs--;
+    if (forward) {
+        for (int v = v_first; v < vs; v++) emit_level(v, T);
+        pad(); pl.n_wide = (int)pl.sl.size();
+        for (int v = std::max(vs, v_first); v < S.nlev; v++) emit_level(v, 64);
+        pad(); pl.n_solo = (int)pl.sl.size() - pl.n_wide;
+    } else {
+        for (int v = S.nlev - 1; v >= std::max(vs, v_first); v--) emit_level(v, 64);
+        pad(); pl.n_solo = (int)pl.sl.size();
+        for (int v = vs - 1; v >= v_first; v--) emit_level(v, T);
+        pad(); pl.n_wide = (int)pl.sl.size() - pl.n_solo;
+    }
+    for (SliceMeta &m : pl.sl) if (m.cnt == 0) m.off = pl.slots; // padding slices read the dummy slot
     pl.idx.push_back(S.N); // slot `slots`: the dummy (index N, value 0) read by inactive lanes
-    while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // empty slices: no loop tail
     return pl;
 }
 

@@ -9,13 +9,17 @@ namespace eicos {
 
 struct TriPlan {
     std::vector<SliceMeta> sl; // slices in sweep order (forward: levels up, backward: levels down)
+    // The narrow top of the elimination tree (levels that fit one wavefront in <= 2 slices) is laid out for 64
+    // lanes and run by a single wavefront without workgroup barriers: forward sl = [wide | solo], backward
+    // sl = [solo | wide]; each part padded to a multiple of TRI_DEPTH slices.
+    int n_wide = 0, n_solo = 0;
     std::vector<int> idx;      // per slot: index of the gathered solve-vector entry (padding -> N)
     std::vector<int> pos;      // per CSC entry of L: its slot
     int slots = 0;
 };
 
 // T = workgroup size the plan is laid out for.
-TriPlan build_tri_plan(const Symbolic &S, int T, bool forward);
+TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo = true);
 
 // Sliced-ELL plan of a plain row-wise sparse product (no levels): rows [0,nrows) of a CSR-like
 // pattern `ptr`, consecutive rows per slice.  src[slot] = CSR entry stored in that slot, -1 = padding.
