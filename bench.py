@@ -148,6 +148,16 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         abytes = algorithmic_bytes(dims, ia)
         achieved = abytes / (k_ms * 1e-3) / 1e9
+        # HBM traffic of one launch: PMC counters cannot be collected inside a timed run, so the figure comes from
+        # the committed summary of separate `rocprofv3 --pmc` passes over this same command (default workload only)
+        traffic, traffic_src = None, None
+        if args.pattern == "MPC02" and not args.soc and not args.perturb and B == 1024:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+                pm = json.load(open(f))
+                if "traffic_bytes" in pm:
+                    traffic, traffic_src = float(pm["traffic_bytes"]), os.path.relpath(f, ROOT)
+                    break
         out = {
             "metric": "ipm_iterations_per_sec", "value": value, "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -161,7 +171,7 @@ def main():
                        "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B, "generator": "perturbed" if args.perturb else "feasible",
                        "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (host cores are shared by all ranks)

@@ -232,9 +232,13 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V ev
             load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
             const int lanes = m.cnt << m.lg;
             const bool act = t < lanes;
+            double xg[ELL_KMAX];
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) xg[kk] = x[ci[kk]];
+            __builtin_amdgcn_sched_barrier(0);
             double acc = 0.;
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk] * x[ci[kk]];
+            for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk] * xg[kk];
             acc = grp_reduce_to_lane0(acc, m.lg);
             if (m.cont) acc += carry;
             if (m.more) carry = acc;
@@ -305,9 +309,13 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
                 else if (LDSBAR) lds_barrier();
                 else __syncthreads();
             }
+            double xg[ELL_KMAX]; // all gathers in flight before the first multiply (the scheduler would serialise them)
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) xg[kk] = ws[c.idx[kk]];
+            __builtin_amdgcn_sched_barrier(0);
             double acc = 0.;
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) acc += c.val[kk] * ws[c.idx[kk]];
+            for (int kk = 0; kk < ELL_KMAX; kk++) acc += c.val[kk] * xg[kk];
             acc = grp_reduce_to_lane0(acc, c.lg);
             if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
                 const int r = c.row0 + (t >> c.lg);

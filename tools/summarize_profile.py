@@ -4,9 +4,9 @@
 usage: python tools/summarize_profile.py gpurun_out/prof_r1 profiles/r01
 Per-launch averages of the PMC counters for the solve kernel; FETCH_SIZE/WRITE_SIZE are reported in
 bytes (rocprofv3 reports KiB).  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE counts
-128-B requests of wide (16 B/lane) streaming reads at 64 B, i.e. can under-report those by up to 2x; this
-kernel's loads are 4-8 B/lane gathers and unit-stride 8 B/lane streams, for which the guide gives no
-calibration, so both the raw and the 2x-corrected read figure are printed.
+128-B requests of streaming reads at 64 B; tools/dev/calib_fetch.hip (profiles/r01_fetch_calibration.md) confirms
+exactly 1/2 for the 4, 8 and 16 B/lane unit-stride reads this kernel issues and exact WRITE_SIZE for 8 B/lane
+stores, so traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB).
 """
 import collections
 import csv
@@ -36,10 +36,9 @@ for k in sorted(out):
     lines.append(f"{k}: {out[k]:.6g}")
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     rd, wr = out["FETCH_SIZE"] * 1024, out["WRITE_SIZE"] * 1024
-    lines += ["", f"HBM read bytes (FETCH_SIZE*1024): {rd:.4g}  (x2 if counted at half width: {2*rd:.4g})",
-              f"HBM write bytes (WRITE_SIZE*1024): {wr:.4g}", f"traffic per launch: {rd+wr:.4g} .. {2*rd+wr:.4g} bytes"]
-    out["traffic_bytes_low"] = rd + wr
-    out["traffic_bytes_high"] = 2 * rd + wr
+    lines += ["", f"HBM read bytes (2*FETCH_SIZE*1024, calibrated): {2*rd:.4g}  (raw counter: {rd:.4g})",
+              f"HBM write bytes (WRITE_SIZE*1024): {wr:.4g}", f"traffic per launch: {2*rd+wr:.4g} bytes"]
+    out["traffic_bytes"] = 2 * rd + wr
 if "SQ_WAVE_CYCLES" in out:
     lines.append(f"wait fraction SQ_WAIT_ANY/SQ_WAVE_CYCLES: {out['SQ_WAIT_ANY']/out['SQ_WAVE_CYCLES']:.3f}")
 if "TCC_HIT_sum" in out:
