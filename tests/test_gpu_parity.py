@@ -181,6 +181,38 @@ def test_random_socp_with_equalities(seed, n, p, l, q):
     _check_batch(pat, feasible_batch(pat, base, 0, 5, seed=100 + seed), 5, 5, x_rtol=1e-6)
 
 
+def test_batch_larger_than_the_resident_grid_uses_queue_and_history_order():
+    # more instances than resident workgroups: instances are pulled from the kernel's queue, and from the second
+    # solve on in longest-first order of the previous solve's LDL-solve counts; neither may change any result
+    pat, sets = load_fixture("lp_afiro")
+    g = eicos_amd.BatchSolver(pat, 8)
+    resident = g.dims()["resident_blocks"]
+    g.close()
+    B = 3000
+    assert resident >= 8
+    d = feasible_batch(pat, sets[0], 0, B, seed=77)
+    g = eicos_amd.BatchSolver(pat, B)
+    assert g.dims()["resident_blocks"] < B  # otherwise this test does not exercise the queue
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    c1 = g.solve().copy(); x1 = g.solution().copy(); it1 = g.info_arrays()["iter"].copy()
+    c2 = g.solve().copy(); x2 = g.solution().copy(); it2 = g.info_arrays()["iter"].copy()  # ordered by history now
+    assert np.array_equal(c1, c2) and np.array_equal(it1, it2) and np.array_equal(x1, x2)
+    assert np.all(c1 == 0) and len(np.unique(it1)) > 1  # heterogeneous work, or the order would be trivial
+    g.close()
+    # same instances in a batch that fits the grid (identity assignment): bit-identical results
+    sub = np.linspace(0, B - 1, 64).astype(int)
+    g = eicos_amd.BatchSolver(pat, len(sub))
+    g.update(d["Gpr"][sub], d["Apr"][sub], d["c"][sub], d["h"][sub], d["b"][sub])
+    g.solve()
+    assert np.array_equal(g.solution(), x1[sub]) and np.array_equal(g.info_arrays()["iter"], it1[sub])
+    g.close()
+    for i in sub[::16]:
+        o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+        assert o.solve() == 0 and o.info()["iter"] == it1[i]
+        assert np.abs(x1[i] - o.x()).max() <= 1e-7 * max(1.0, np.abs(o.x()).max())
+        o.close()
+
+
 def test_lpnetlib_perturbed_batch():
     pat, sets = load_fixture("lp_blend")
     d = perturbed_batch(pat, sets[0], 0, 32)
