@@ -125,11 +125,15 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
 
     auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
     {
-        // workgroup size by problem size (measured, batch 256: dim_K 129 -> 128, 1249 -> 256, >= 3815 -> 512 threads)
+        // workgroup size by problem size (measured, batch 256: dim_K 129 -> 128, 1249 -> 256, >= 3815 -> 512 threads);
+        // batches beyond one workgroup per CU are throughput-bound: 256 threads issue a third fewer wavefront-slices
+        // per instance than 512 and fit three workgroups per CU (MPC02 pattern: 500 k vs 414 k iterations/s)
         const int dimK = n + p + m + 2 * ncones;
-        const int dflt = dimK < 400 ? 128 : (dimK < 2000 ? 256 : 512);
+        int n_cu = 256;
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device < 0 ? 0 : device) == hipSuccess) n_cu = pr.multiProcessorCount; }
+        const int dflt = dimK < 400 ? 128 : ((dimK < 2000 || batch > n_cu) ? 256 : 512);
         const int t = env_int("EICOS_THREADS", dflt);
-        h->threads = (t == 128 || t == 256 || t == 512 || t == 1024) ? t : dflt;
+        h->threads = (t == 128 || t == 256 || t == 512) ? t : dflt;
     }
     // ---- slab layouts ----
     SlabLayout L;
@@ -275,10 +279,18 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     {
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
-        if (D.fac_ns <= 512) { D.lm_fac = D.lm_total; D.lm_total += D.fac_ns; } // factor program's table too, when small
-        else D.lm_fac = -1;
-        const size_t meta = (size_t)D.lm_total * sizeof(SliceMeta);
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
+        const size_t lds_static = 2048; // struct Sh of kernels.hip (reductions + scalar state), rounded up
+        // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
+        const int wgs_by_regs = (h->threads == 256 ? 3 : 4) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
+        auto wgs_per_cu = [&](int slices) {
+            return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(SliceMeta) + lds_static)));
+        };
+        // the factor program's table goes to LDS too when it is small and does not cost a resident workgroup
+        if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total) && env_int("EICOS_FAC_LDS", 1)) {
+            D.lm_fac = D.lm_total; D.lm_total += D.fac_ns;
+        } else D.lm_fac = -1;
+        const size_t meta = (size_t)D.lm_total * sizeof(SliceMeta);
         // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
         // all-global variant (NLDS = 0, plain __syncthreads between levels) is used
         // KKT-space vectors in LDS: E (rhs / residual / solve vector) and X (current solution), + both slice tables
@@ -295,6 +307,20 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     int bpc = 1;
     HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dyn_lds, &bpc));
     bpc = std::max(1, std::min(bpc, 8));
+    {
+        // Workgroups per CU for this batch.  A workgroup slows down by about half of its stand-alone time per
+        // co-resident workgroup (measured, MPC02: 13 / 19.8 / 25.8 ms per instance at 1 / 2 / 3 per CU), and a last,
+        // partly filled round still costs more than half a round; pick the cheapest estimate (e.g. batch 1024 on
+        // 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3 per CU, batch >= 1536 takes 3 per CU).
+        double best = 1e300; int best_r = 1;
+        for (int r = 1; r <= bpc; r++) {
+            const double rounds = (double)batch / ((double)prop.multiProcessorCount * r);
+            const double full = std::floor(rounds), f = rounds - full;
+            const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
+            if (cost < best - 1e-12) { best = cost; best_r = r; }
+        }
+        bpc = best_r;
+    }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min(batch, resident);
@@ -584,7 +610,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
         for (int i = 0; i < N; i++) rhs[i] = rnd() - 0.5;
         // the two sweeps exactly as the kernel walks its sliced-ELL plans (lane by lane)
         double plan_err = 0;
-        for (int T : {256, 512, 1024}) {
+        for (int T : {128, 256, 512}) {
             TriPlan pf = build_tri_plan(S, T, true), pb = build_tri_plan(S, T, false);
             std::vector<double> UF(pf.slots + 1, 0.0), UB(pb.slots + 1, 0.0), ws(N + 1, 0.0);
             { // numeric factorisation through the sliced-ELL factor plan, lane by lane as the kernel does it
@@ -660,7 +686,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
             sweep(pf, UF, true); sweep(pb, UB, false);
             std::vector<double> xt(N);
             for (int j = 0; j < N; j++) xt[S.perm[j]] = ws[j];
-            if (T == 256) x = xt;
+            if (T == 128) x = xt;
             for (int j = 0; j < N; j++) plan_err = std::max(plan_err, std::fabs(xt[j] - x[j]));
         }
         if (plan_err > 1e-9) return -3.0;

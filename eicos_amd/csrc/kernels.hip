@@ -42,14 +42,13 @@ __device__ constexpr double LINSYSACC = 1e-14, IRERRFACT = 6., STEPMIN = 1e-6, S
 __device__ constexpr double SIGMAMIN = 1e-4, SIGMAMAX = 1.0, SAFEGUARD = 500.;
 constexpr int EX_NOT_CONVERGED = -87;
 
-#ifndef EICOS_WAVES_PER_EU
-#define EICOS_WAVES_PER_EU 4
-#endif
-// EICOS_WAVES_PER_EU = waves per SIMD the register budget is sized for (4 -> 128 VGPRs: one
-// 1024-thread workgroup, two of 512 or four of 256 per CU); the AMDGPU attributor propagates the
-// kernel's budget to the non-inlined stage functions
+// Register budget per workgroup size = waves per SIMD the kernel is compiled for: 512 threads -> 4 (128 VGPRs,
+// two workgroups per CU), 256 threads -> 3 (168 VGPRs, three workgroups per CU: three 48 KB solve vectors are what
+// the 160 KB of LDS hold), 128 threads -> 4 (small patterns, up to eight workgroups per CU).  The AMDGPU
+// attributor propagates the kernel's budget to the non-inlined stage functions.
+template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : 4; }
 
-constexpr int RED_SLOTS = 16 * 8; // up to 16 wavefronts x 8 values per reduction
+constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values per reduction
 
 // scalar slots in LDS (written by thread 0 only)
 enum { SV_RESX0 = 0, SV_RESY0, SV_RESZ0, SV_PRESPREV, SV_RT, SV_DTAUDEN, SV_DTAUAFF, SV_DKAPAFF, SV_BKAP,
@@ -73,6 +72,7 @@ struct Sh {
 enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT, TK_FA = 8, TK_FW1, TK_FB, TK_FW2 }; // 8..11: inside the factor
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
+static_assert(sizeof(Sh) <= 2048, "api.cpp budgets 2 KB of static LDS per workgroup");
 __shared__ Sh g_S;
 extern __shared__ double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | slice tables of both sweeps
 
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
 }
 
 template <int T, int NLDS>
-__global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_solve(
+__global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
     int ps, double *inst, double *work, int B, int *queue, const int *order) {
     const DevPat &P = c_pat[ps];
     gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
 
 // Debug: factorise instance `i` with the KKT scaling block as it stands in memory (runs the solver's own stage).
 template <int T>
-__global__ __launch_bounds__(T, EICOS_WAVES_PER_EU) void k_debug_factor(int ps, double *inst, double *work, int i) {
+__global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, double *inst, double *work, int i) {
     const DevPat &P = c_pat[ps];
     if (threadIdx.x == 0) { g_S.fl[FL_FATAL] = 0; g_S.wi.n_factor = 0; for (int k = 0; k < 12; k++) g_S.tick[k] = 0; }
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
@@ -1368,7 +1368,6 @@ template <class F> static auto dispatch_solve(int threads, int nlds, F &&f) {
         if (nlds == 1) return f((const void *)k_solve<T, 1>);
         return f((const void *)k_solve<T, 0>);
     };
-    if (threads == 1024) return byT(std::integral_constant<int, 1024>{});
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
@@ -1399,7 +1398,6 @@ hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int th
     case 128: hipLaunchKernelGGL(k_debug_factor<128>, dim3(1), dim3(128), 0, st, ps, inst, work, i); break;
     case 256: hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), 0, st, ps, inst, work, i); break;
     case 512: hipLaunchKernelGGL(k_debug_factor<512>, dim3(1), dim3(512), 0, st, ps, inst, work, i); break;
-    case 1024: hipLaunchKernelGGL(k_debug_factor<1024>, dim3(1), dim3(1024), 0, st, ps, inst, work, i); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,4 +1,5 @@
-for cfg in "512 1 1024" "256 1 1024" "256 1 1536" "256 1 3072" "256 0 2048" "128 1 1536" "128 0 2048" "512 0 2048"; do
-  set -- $cfg
-  EICOS_THREADS=$1 EICOS_NLDS=$2 timeout 120 python tools/dev/gpu_sweep.py MPC02 $3 2 2>&1 | head -1 | cut -c1-170
+for B in 256 512 768 1024 1536 4096; do
+  timeout 200 python tools/dev/gpu_sweep.py MPC02 $B 3 2>&1 | head -1 | cut -c1-170
 done
+EICOS_THREADS=512 timeout 200 python tools/dev/gpu_sweep.py MPC02 256 3 2>&1 | head -1 | cut -c1-170
+EICOS_THREADS=256 timeout 200 python tools/dev/gpu_sweep.py MPC02 256 3 2>&1 | head -1 | cut -c1-170
