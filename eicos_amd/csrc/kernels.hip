@@ -535,9 +535,14 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     double carry = 0.; // partial sum of targets cut into sub-slices
     const int ns = P.fac_ns;
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
-    auto fload = [&](int sidx, FSlot &o) {
+    // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
+    // the loads that need them, so that their round trip is not on the path either
+    auto fmeta = [&](int sidx) {
         SliceMeta nm;
         if (tab_lds) nm = LDS_TABLE(P.lm_fac)[sidx]; else nm = P.fac_sl[sidx];
+        return nm;
+    };
+    auto fload = [&](const SliceMeta &nm, FSlot &o) {
         o.row0 = uni(nm.row0); o.cnt = uni(nm.cnt); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off);
         const int nl = uni(nm.newlev);
         o.newlev = nl & 1; o.last = nl >> 1;
@@ -554,7 +559,8 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
         o.dst = P.fac_dst[t];
     };
 #pragma unroll
-    for (int d = 0; d < FAC_DEPTH; d++) fload(min(d, ns - 1), q[d]);
+    for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(d, ns - 1)), q[d]);
+    SliceMeta pm = fmeta(min(FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
     double gu[ELL_KMAX], gl[ELL_KMAX];
     bool have = false;
@@ -564,17 +570,10 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             const int sidx = s0 + d;
             if (sidx >= ns) break;
             const FSlot c = q[d];
-            fload(min(sidx + FAC_DEPTH, ns - 1), q[d]);
+            fload(pm, q[d]);
+            pm = fmeta(min(sidx + FAC_DEPTH + 1, ns - 1));
             if (c.newlev) lvl_t0 = c.row0;
             const int lvl_t1 = c.row0 + c.cnt; // targets of a level are one contiguous range
-            int bd[2] = {-1, -1}, bf[2] = {0, 0}, bc[2] = {0, 0};
-            if (c.last) { // phase B's destinations for this thread's first two targets, ahead of the barrier
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int t = min(lvl_t0 + tid + u * T, lvl_t1 - 1);
-                    bd[u] = P.fac_dst[t]; bf[u] = P.fac_dstF[t]; bc[u] = P.fac_col[t];
-                }
-            }
             const bool act = tid < c.lanes;
             // gathered factor values: slices of one level are independent, so the next slice's gathers are
             // issued before this slice's arithmetic waits on its own (one L2 round trip per level, not per slice)
@@ -608,13 +607,12 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
                 FTICK(TK_FA);
                 __syncthreads();
                 FTICK(TK_FW1);
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-                    if (lvl_t0 + tid + u * T < lvl_t1 && bd[u] >= 0) UF[bf[u]] = U[bd[u]] * invD[bc[u]];
-                for (int t = lvl_t0 + tid + 2 * T; t < lvl_t1; t += T) {
-                    const int dst = P.fac_dst[t];
-                    if (dst >= 0) UF[P.fac_dstF[t]] = U[dst] * invD[P.fac_col[t]];
-                }
+                // phase B over the level's targets, four per thread in flight (index loads, then the two gathers)
+                struct PB { int dst, dstF; double u, d; };
+                for_t_pre<T, 4>(lvl_t1 - lvl_t0, [&](int k) {
+                    const int t = lvl_t0 + k, dst = P.fac_dst[t];
+                    return PB{dst, P.fac_dstF[t], U[max(dst, 0)], invD[P.fac_col[t]]};
+                }, [&](int k, const PB &r) { if (r.dst >= 0) UF[r.dstF] = r.u * r.d; });
                 FTICK(TK_FB);
                 __syncthreads();
                 FTICK(TK_FW2);
