@@ -39,7 +39,18 @@ constexpr int DEVINFO_DOUBLES = 32;
 // over the same rows: `more` = another sub-slice of these rows follows, `cont` = this one continues the previous.
 struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; };
 constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
-constexpr int TRI_DEPTH = 3; // ... this many slices ahead of their use (plans are padded to a multiple)
+#ifndef EICOS_TRI_DEPTH
+#define EICOS_TRI_DEPTH 3
+#endif
+#ifndef EICOS_ELL_DEPTH
+#define EICOS_ELL_DEPTH 2
+#endif
+#ifndef EICOS_FAC_DEPTH
+#define EICOS_FAC_DEPTH 2
+#endif
+constexpr int TRI_DEPTH = EICOS_TRI_DEPTH; // ... this many slices ahead of their use (plans are padded to a multiple)
+constexpr int ELL_DEPTH = EICOS_ELL_DEPTH; // same for the matrix-vector products
+constexpr int FAC_DEPTH = EICOS_FAC_DEPTH; // and for the static part of the factor program (no padding needed)
 
 // Everything the kernels need to know about the (shared) pattern.  All pointers are device
 // pointers into one int32 pattern buffer; all i_* / w_* members are offsets in doubles into

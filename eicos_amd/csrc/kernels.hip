@@ -190,7 +190,6 @@ __device__ __forceinline__ void for_t_pre(int cnt, L &&ld, F &&fn) {
 // ahead of the arithmetic (same register queue as tri_sweep, no barriers); plans are padded to a
 // multiple of ELL_DEPTH slices and hold at most ELL_KMAX entries per lane and slice (longer rows are
 // cut into sub-slices whose partial sums are carried in a register).  `sm` may live in LDS (staged by k_solve) or in global memory.
-constexpr int ELL_DEPTH = 2;
 // `pre(row)` loads whatever the epilogue needs per row (rhs entry, destination index, ...); it is issued with the
 // slice's index/value loads, ELL_DEPTH slices ahead, so that `epi(row, sum, pre(row))` starts no global load itself.
 template <int T, class SM, class V, class X, class Pre, class Epi>
@@ -530,7 +529,6 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     // per phase instead of an index load + gather + source-index load + value load chain.
     unsigned long long ft0 = (tid == 0) ? wall_clock64() : 0ull; // finer phase timers (thread 0's view)
 #define FTICK(slot) do { if (tid == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - ft0; ft0 = t1_; } } while (0)
-    constexpr int FAC_DEPTH = 2;
     struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
     double carry = 0.; // partial sum of targets cut into sub-slices
     const int ns = P.fac_ns;

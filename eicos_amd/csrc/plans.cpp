@@ -162,7 +162,7 @@ EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T) {
         r += cnt;
     }
     pl.src.push_back(-1); // dummy slot (index `slots`)
-    while (pl.sl.size() % 2) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // ELL_DEPTH = 2: no loop tail
+    while (pl.sl.size() % ELL_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // no loop tail
     return pl;
 }
 
