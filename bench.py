@@ -61,12 +61,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
-    ap.add_argument("--pattern", default="MPC02", help="fixture name under tests/golden (BASELINE config 3: lp_*), "
+    ap.add_argument("--pattern", default="MPC02", help="fixture name under tests/golden (BASELINE config 3: lp_*), a path to an EPB1 / ECOS data.h problem file, "
                     "or 'dense-front' (BASELINE config 4: n=2000, 32 cones x 64, generated)")
     ap.add_argument("--soc", action="store_true", help="MPC-SOC variant (332 cones of dim 3)")
     ap.add_argument("--perturb", action="store_true", help="LPnetlib-style batch: perturb c,h of the fixture "
                     "(SURVEY.md 8d config 4) instead of generating strictly feasible (c,h,b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--io", choices=("local", "root"), default="local", help="local: every rank regenerates its own shard "
+                    "(no collective, default); root: rank 0 holds the whole batch and scatters shards over RCCL/xGMI "
+                    "before the timed region, results are gathered back after it (times reported in config)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +96,10 @@ def main():
         pat, base = dense_front_pattern(2000, 32, 64)
         sets = [base]
     else:
-        pat, sets = eicos_amd.read_epb(os.path.join(ROOT, "tests", "golden", args.pattern + ".epb"))
+        # a fixture name, or a path to a problem file (EPB1 container or an ECOS-style data header such as the
+        # reference's data_MPC01.hpp, which is not in the mount: SURVEY.md F4) -- drop it in to bench the real thing
+        path = args.pattern if os.path.exists(args.pattern) else os.path.join(ROOT, "tests", "golden", args.pattern + ".epb")
+        pat, sets = eicos_amd.read_problem(path)
     if args.soc:
         pat = mpc_soc_variant(pat)
     B = args.batch
@@ -103,7 +109,24 @@ def main():
         data = perturbed_batch(pat, sets[0], first, B, SEED)
     else:
         data = feasible_batch(pat, sets[0], first, B, SEED)
-    dev = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in data.items()}
+    io_ms = {}
+    if args.io == "root" and dist is not None and world > 1:
+        # the batch originates on rank 0's GPU: scatter the shards (outside the timed region: inputs are resident in
+        # HBM when timing starts); every rank still knows its own data for the CPU cross-check below
+        from eicos_amd.dist_io import KEYS, scatter_batch
+        widths = {k: data[k].shape[1] for k in KEYS}
+        full = None
+        if rank == 0:
+            gen = perturbed_batch if args.perturb else feasible_batch
+            allv = gen(pat, sets[0], 0, world * B, SEED)
+            full = {k: torch.from_numpy(allv[k]).to(f"cuda:{local_rank}") for k in KEYS}
+        dist.barrier(); torch.cuda.synchronize(); t_sc = time.perf_counter()
+        dev = scatter_batch(full, widths, B, rank, world, f"cuda:{local_rank}", dist)
+        torch.cuda.synchronize(); dist.barrier(); io_ms["scatter_ms"] = (time.perf_counter() - t_sc) * 1e3
+        del full
+        assert all(torch.equal(dev[k].cpu(), torch.from_numpy(data[k])) for k in KEYS), "scattered shard differs"
+    else:
+        dev = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in data.items()}
     ptr = lambda k: dev[k].data_ptr() if dev[k].numel() else 0
 
     solver = eicos_amd.BatchSolver(pat, B, device=local_rank)
@@ -131,6 +154,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    if io_ms:  # results back to the root: x [B, n] straight from the instance slabs, then one gather
+        from eicos_amd.dist_io import gather_rows
+        torch.cuda.synchronize(); dist.barrier(); t_g = time.perf_counter()
+        xl = torch.from_numpy(solver.solution()).to(f"cuda:{local_rank}")
+        xall = gather_rows(xl, rank, world, dist)
+        torch.cuda.synchronize(); dist.barrier(); io_ms["gather_ms"] = (time.perf_counter() - t_g) * 1e3
+        if rank == 0:
+            assert xall.shape == (world * B, dims["n"])
     ia = solver.info_arrays()
     iters = int(ia["iter"].sum())
     ok = int((ia["exitcode"] == 0).sum())
@@ -169,7 +200,8 @@ def main():
                        "levels": dims["nlevels"], "mean_iter": float(ia["iter"].mean()),
                        "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
                        "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B, "generator": "perturbed" if args.perturb else "feasible",
-                       "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"]},
+                       "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
+                       "io": ("root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},

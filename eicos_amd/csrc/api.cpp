@@ -354,6 +354,33 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     return EICOS_OK;
 }
 
+// ---- single-instance surface: a batch of one (reference include/eicos.hpp:151-163, test/ecos.h:11-34)
+int eicos_create(int n, int m, int p, int l, int ncones, const int *q, const double *Gpr, const int *Gjc, const int *Gir,
+                 const double *Apr, const int *Ajc, const int *Air, const double *c, const double *h, const double *b,
+                 int device, eicos_batch **out) {
+    if (!out) return fail(EICOS_E_INVALID, "out is NULL");
+    const bool haveG = Gpr && Gjc && Gir, haveA = Apr && Ajc && Air; // NULL groups as in src/eicos.cpp:103-117
+    if (n > 0 && !c) return fail(EICOS_E_INVALID, "c is NULL");
+    eicos_batch *hd = nullptr;
+    int rc = eicos_batch_create(n, m, p, l, ncones, q, haveG ? Gjc : nullptr, haveG ? Gir : nullptr,
+                                haveA ? Ajc : nullptr, haveA ? Air : nullptr, 1, device, &hd);
+    if (rc != EICOS_OK) return rc;
+    rc = eicos_batch_update(hd, 0, 1, haveG ? Gpr : nullptr, haveA ? Apr : nullptr, c, haveG ? h : nullptr, haveA ? b : nullptr);
+    if (rc != EICOS_OK) { eicos_batch_destroy(hd); return rc; }
+    *out = hd;
+    return EICOS_OK;
+}
+int eicos_update(eicos_batch *hd, const double *Gpr, const double *Apr, const double *c, const double *h, const double *b) {
+    return eicos_batch_update(hd, 0, 1, Gpr, Apr, c, h, b);
+}
+int eicos_solve(eicos_batch *hd, int *exitcode) {
+    if (hd && hd->batch != 1) return fail(EICOS_E_INVALID, "eicos_solve needs a handle made by eicos_create (batch of one)");
+    return eicos_batch_solve(hd, exitcode);
+}
+int eicos_solution(eicos_batch *hd, double *x) { return eicos_batch_solution(hd, x); }
+int eicos_info_get(eicos_batch *hd, eicos_info *info) { return eicos_batch_info(hd, info); }
+int eicos_destroy(eicos_batch *hd) { return eicos_batch_destroy(hd); }
+
 int eicos_batch_destroy(eicos_batch *h) {
     if (!h) return EICOS_OK;
     (void)hipSetDevice(h->device);

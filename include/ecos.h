@@ -16,14 +16,9 @@ static inline pwork *ECOS_setup(idxint n, idxint m, idxint p, idxint l, idxint n
                                 pfloat *Gpr, idxint *Gjc, idxint *Gir, pfloat *Apr, idxint *Ajc, idxint *Air,
                                 pfloat *c, pfloat *h, pfloat *b) {
     (void)nexc; /* no exponential cones (the reference ignores the argument too, test/ecos.h:11) */
-    const int haveG = Gpr && Gjc && Gir, haveA = Apr && Ajc && Air;
     static pfloat zero = 0.0;
     pwork *w = new pwork{nullptr};
-    if (eicos_batch_create(c ? n : 0, m, p, l, ncones, q, haveG ? Gjc : nullptr, haveG ? Gir : nullptr,
-                           haveA ? Ajc : nullptr, haveA ? Air : nullptr, 1, -1, &w->h) != EICOS_OK ||
-        eicos_batch_update(w->h, 0, 1, haveG ? Gpr : nullptr, haveA ? Apr : nullptr, c ? c : &zero,
-                           haveG ? h : nullptr, haveA ? b : nullptr) != EICOS_OK) {
-        if (w->h) eicos_batch_destroy(w->h);
+    if (eicos_create(c ? n : 0, m, p, l, ncones, q, Gpr, Gjc, Gir, Apr, Ajc, Air, c ? c : &zero, h, b, -1, &w->h) != EICOS_OK) {
         delete w;
         return nullptr;
     }
@@ -31,15 +26,15 @@ static inline pwork *ECOS_setup(idxint n, idxint m, idxint p, idxint l, idxint n
 }
 static inline idxint ECOS_solve(pwork *w) {
     int code = EICOS_FATAL;
-    if (eicos_batch_solve(w->h, &code) != EICOS_OK) return EICOS_FATAL;
+    if (eicos_solve(w->h, &code) != EICOS_OK) return EICOS_FATAL;
     return code;
 }
 static inline void ECOS_updateData(pwork *w, pfloat *Gpr, pfloat *Apr, pfloat *c, pfloat *h, pfloat *b) {
-    eicos_batch_update(w->h, 0, 1, Gpr, Apr, c, h, b);
+    eicos_update(w->h, Gpr, Apr, c, h, b);
 }
 static inline void ECOS_cleanup(pwork *w, idxint keepvars) {
     (void)keepvars;
-    if (w) { eicos_batch_destroy(w->h); delete w; }
+    if (w) { eicos_destroy(w->h); delete w; }
 }
 
 #define ECOS_OPTIMAL (0)

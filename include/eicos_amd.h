@@ -113,6 +113,26 @@ int eicos_batch_last_update_ms(eicos_batch *hd, float *ms);
 /* replaces the Solver destructor / ECOS_cleanup (reference test/ecos.h:31-34) */
 int eicos_batch_destroy(eicos_batch *hd);
 
+/* ---- single-instance surface: the same entry points for one problem, i.e. exactly what
+ * class EiCOS::Solver needs.  A handle made by eicos_create is a batch of one; every eicos_batch_* call works on it.
+ *   eicos_create   <-> Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)  include/eicos.hpp:151-154
+ *                      / ECOS_setup (reference test/ecos.h:11-24); values are copied, NULL groups allowed
+ *   eicos_update   <-> Solver::updateData(Gpr,Apr,c,h,b)  include/eicos.hpp:155-156 / ECOS_updateData test/ecos.h:28-29
+ *   eicos_solve    <-> exitcode Solver::solve()  include/eicos.hpp:158 / ECOS_solve test/ecos.h:26; returns the
+ *                      exit code through *exitcode (the function's own return value is the EICOS_E_* status)
+ *   eicos_solution <-> Solver::solution()  include/eicos.hpp:160 (x[n], host)
+ *   eicos_info_get <-> Solver::getInfo()   include/eicos.hpp:163
+ *   eicos_destroy  <-> ~Solver / ECOS_cleanup test/ecos.h:31-34 */
+int eicos_create(int n, int m, int p, int l, int ncones, const int *q,
+                 const double *Gpr, const int *Gjc, const int *Gir,
+                 const double *Apr, const int *Ajc, const int *Air,
+                 const double *c, const double *h, const double *b, int device, eicos_batch **out);
+int eicos_update(eicos_batch *hd, const double *Gpr, const double *Apr, const double *c, const double *h, const double *b);
+int eicos_solve(eicos_batch *hd, int *exitcode);
+int eicos_solution(eicos_batch *hd, double *x);
+int eicos_info_get(eicos_batch *hd, eicos_info *info);
+int eicos_destroy(eicos_batch *hd);
+
 const char *eicos_last_error(void);
 /* number of visible HIP devices (0 when there is no GPU); never initialises a context */
 int eicos_device_count(void);

@@ -24,33 +24,13 @@ import numpy as np
 REF = "/root/reference/test"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
-ARRAY_RE = re.compile(
-    r"(?:static\s+)?(idxint|pfloat)\s+(\*?\w+)\s*(\[\s*\d*\s*\])?\s*=\s*(\{[^}]*\}|[^;{]+);", re.S)
+sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+from eicos_amd.problem_io import parse_c_initialisers  # noqa: E402  (the package's ECOS data.h parser)
 
 
 def parse_header(path):
     """Return {name: int | float | np.ndarray | None} for every scalar/array initialiser."""
-    text = open(path).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    out = {}
-    for typ, name, arr, init in ARRAY_RE.findall(text):
-        init = init.strip()
-        if name.startswith("*"):
-            out[name[1:]] = None  # NULL pointer
-            continue
-        if init.startswith("{"):
-            body = init[1:-1].replace("\n", " ")
-            toks = [t for t in (s.strip() for s in body.split(",")) if t]
-            if typ == "idxint":
-                out[name] = np.array([int(t) for t in toks], dtype=np.int32)
-            else:
-                out[name] = np.array([float(t) for t in toks], dtype=np.float64)
-        elif arr == "":
-            try:
-                out[name] = int(init) if typ == "idxint" else float(init)
-            except ValueError:
-                pass
-    return out
+    return parse_c_initialisers(open(path).read())
 
 
 def problem(n, m, p, l, q, Gjc, Gir, Ajc, Air, sets):

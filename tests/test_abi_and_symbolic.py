@@ -94,3 +94,26 @@ def test_generator_is_shard_invariant():
         f, c = shard_range(6, r, 4)
         parts.append(feasible_batch(pat, sets[0], f, c)["h"])
     assert np.array_equal(np.concatenate(parts), full["h"])
+
+
+def test_ecos_header_loader_round_trip(tmp_path):
+    # N1 of SURVEY.md 8f: the ECOS data.h layout (what src/run.cpp:18-31 consumes) <-> EPB1, both directions,
+    # with and without a name prefix, with absent groups (no A / no cones)
+    import numpy as np
+    import eicos_amd
+    from conftest import load_fixture
+    for name, prefix in (("update_data", "udd_"), ("lp_afiro", ""), ("issue98", "x_")):
+        pat, sets = load_fixture(name)
+        h = str(tmp_path / f"{name}.h")
+        eicos_amd.write_ecos_header(h, pat, sets[0], prefix)
+        pat2, sets2 = eicos_amd.read_problem(h)
+        for k in ("n", "m", "p", "l"):
+            assert getattr(pat, k) == getattr(pat2, k)
+        for k in ("q", "Gjc", "Gir", "Ajc", "Air"):
+            assert np.array_equal(getattr(pat, k), getattr(pat2, k)), (name, k)
+        for k in ("Gpr", "Apr", "c", "h", "b"):
+            assert np.array_equal(getattr(sets[0], k), getattr(sets2[0], k)), (name, k)
+        e = str(tmp_path / f"{name}.epb")
+        eicos_amd.write_epb(e, pat2, sets2)
+        pat3, sets3 = eicos_amd.read_problem(e)
+        assert np.array_equal(sets3[0].Gpr, sets[0].Gpr) and pat3.nnzA == pat.nnzA

@@ -154,7 +154,7 @@ def test_dense_front_socp():
 
 
 @pytest.mark.parametrize("env", [{"EICOS_NLDS": "0"}, {"EICOS_NLDS": "1"}, {"EICOS_NLDS": "2"}, {"EICOS_THREADS": "128"},
-                                 {"EICOS_THREADS": "128"}, {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}])
+                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
     # or in the workspace slab, 128/256/512 threads) through an LP, an SOC and an infeasible fixture
@@ -318,3 +318,40 @@ def test_cpp_solver_surface_demo(tmp_path):
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "MPC02.epb")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("exit 0") == 2 and "pcost 0.16" in out.stdout, out.stdout
+
+
+def test_ecos_shim_runs_a_reference_style_test(tmp_path):
+    # include/ecos.h = drop-in for the reference's test/ecos.h: the shape of a reference test (ECOS_setup ->
+    # ECOS_solve -> ECOS_updateData -> ECOS_solve -> ECOS_cleanup, test/updateData/update_data.h) on inline data:
+    # min -x1 - x2  s.t.  x1 + x2 <= 1, x >= 0  (optimum -1), then h0 = 3 (optimum -3)
+    import os, subprocess
+    from conftest import ROOT
+    src = tmp_path / "shim.cpp"
+    src.write_text(r'''
+#include "ecos.h"
+#include <cstdio>
+int main() {
+    idxint Gjc[3] = {0, 2, 4}, Gir[4] = {0, 1, 0, 2};
+    pfloat Gpr[4] = {1, -1, 1, -1}, c[2] = {-1, -1}, h[3] = {1, 0, 0};
+    pwork *w = ECOS_setup(2, 3, 0, 3, 0, nullptr, 0, Gpr, Gjc, Gir, nullptr, nullptr, nullptr, c, h, nullptr);
+    if (!w) { std::printf("setup failed: %s\n", eicos_last_error()); return 1; }
+    idxint e1 = ECOS_solve(w);
+    eicos_info i1; eicos_info_get(w->h, &i1);
+    pfloat h2[3] = {3, 0, 0};
+    ECOS_updateData(w, Gpr, nullptr, c, h2, nullptr);
+    idxint e2 = ECOS_solve(w);
+    eicos_info i2; eicos_info_get(w->h, &i2);
+    double x[2]; eicos_solution(w->h, x);
+    std::printf("exit %d pcost %.9f | exit %d pcost %.9f x1+x2 %.9f\n", e1, i1.pcost, e2, i2.pcost, x[0] + x[1]);
+    ECOS_cleanup(w, 0);
+    return (e1 == ECOS_OPTIMAL && e2 == ECOS_OPTIMAL) ? 0 : 2;
+}
+''')
+    exe = str(tmp_path / "shim")
+    lib = os.path.join(ROOT, "eicos_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-L", lib, "-leicos_amd",
+                           "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    toks = out.stdout.split()
+    assert abs(float(toks[3]) + 1.0) < 1e-7 and abs(float(toks[8]) + 3.0) < 1e-7 and abs(float(toks[10]) - 3.0) < 1e-6, out.stdout
