@@ -182,7 +182,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
-    D.w_xk = Wl.add((size_t)S.N + 16); D.w_ek = Wl.add((size_t)S.N + 16); D.w_dxr = Wl.add(S.N); D.w_ws = Wl.add(S.N);
+    D.w_xk = Wl.add((size_t)S.N + 16); D.w_ek = Wl.add((size_t)S.N + 16); D.w_dxr = Wl.add(S.N);
     D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N); // w_UF / w_UB are added once the slice plans are known
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
 
@@ -241,7 +241,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(D.cq, S.q); put(D.cone_off, S.cone_off); put(D.cone_vbase, cone_vbase); put(D.cone_small, cone_small); put(D.cone_big, cone_big);
     D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
     put(D.zdsign, zdsign);
-    put(D.f_idx, planF.idx); put(D.b_idx, planB.idx); put(D.posF, planF.pos); put(D.posB, planB.pos);
+    put(D.f_idx, planF.idx); put(D.b_idx, planB.idx);
     const int *fsl_p = nullptr, *bsl_p = nullptr, *cag_sl_p = nullptr, *rA_sl_p = nullptr, *rG_sl_p = nullptr;
     put(fsl_p, fsl_i); put(bsl_p, bsl_i); put(cag_sl_p, cag_sl_i); put(rA_sl_p, rA_sl_i); put(rG_sl_p, rG_sl_i);
     put(D.cag_idx_k, cag_idx_k); put(D.cag_idx_yz, cag_idx_yz); put(D.cag_src, cag_src);

@@ -77,13 +77,13 @@ struct DevPat {
     gint_p zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
     // LDL' pattern, level ordered
     // triangular solves: sliced-ELL plans (see SliceMeta).  UF = unit-lower L in the forward (row) slot order,
-    // UB = U = L.*D (column-scaled) in the backward (column) slot order; posF/posB map a CSC entry of L to its slots
+    // UB = U = L.*D (column-scaled) in the backward (column) slot order (the CSC-entry -> slot maps stay on the host)
     const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;   // nfs / nbs = slices of the workgroup-wide part of the forward / backward plan
     int nfs_solo, nbs_solo;   // single-wavefront part (top of the tree): fsl = [wide | solo], bsl = [solo | wide]
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
-    gint_p f_idx, b_idx, posF, posB;
+    gint_p f_idx, b_idx;
     // numeric factorisation: sliced-ELL program (plans.hpp: FactorPlan); per target: source offset of its
     // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot
     const SliceMeta EICOS_GLOBAL *fac_sl;
@@ -96,7 +96,7 @@ struct DevPat {
     // workspace slab offsets
     int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2, w_rhs1k, w_rhs2k;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
-    int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_ws, w_UF, w_UB, w_D, w_invD, w_trace;
+    int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_UF, w_UB, w_D, w_invD, w_trace;
     size_t inst_stride, work_stride; // in doubles
 };
 

@@ -2,7 +2,8 @@
 //
 // Execution model: ONE WORKGROUP PER PROBLEM INSTANCE, persistent over the whole
 // interior-point solve.  The grid is sized to what is co-resident on the chip
-// (256 CUs x blocks/CU); each workgroup walks instances blockIdx.x, +gridDim.x, ...
+// (256 CUs x 1-3 workgroups); each workgroup solves instance blockIdx.x and then pulls further
+// instances from a queue, longest first by the work of their previous solve (k_order).
 // Every step of the reference's solve() (reference src/eicos.cpp:848-1262) is executed by
 // all threads of the workgroup with workgroup-uniform control flow.  The scalar state
 // (struct Information, tau/kappa, step lengths, exit decisions) lives in LDS and is advanced
@@ -17,7 +18,9 @@
 // per row, unit-stride index/value loads with no row pointers, DPP row reductions, and the loads of
 // the next slices are issued before the current one is consumed (register queue; across the LDS-only
 // level barriers of the sweeps).  KKT-space vectors live in elimination order, the solve vector (and
-// the current solution when one workgroup owns a CU) in LDS.
+// the current solution when one workgroup owns a CU) in LDS.  The narrow top of the elimination tree is
+// swept by a single wavefront without workgroup barriers; elementwise passes issue the loads of several
+// iterations before the first use (for_t_pre) because the compiler will not.
 //
 // Code shape: the solve is a small state machine so that the three big pieces -- numeric
 // factorisation, LDL' solve, KKT solve with iterative refinement -- each have exactly ONE call site,
