@@ -225,13 +225,49 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
     std::vector<int> col_of(S.nnzL);
     for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) col_of[e] = j;
-    auto meta_ints = [](const std::vector<SliceMeta> &v) {
-        std::vector<int> o(v.size() * 8);
-        if (!v.empty()) std::memcpy(o.data(), v.data(), o.size() * sizeof(int));
+    // ---- device form of the slice tables (PackedSlice) and 16-bit gather indices ----
+    // One 8-byte entry per lane and slice = its ELL_KMAX gather indices; entry position = off16 of the slice + lane;
+    // the entry after the last slice is all padding (read by inactive lanes).  Used when every index fits 16 bits.
+    bool idx16_ok = true;
+    auto lane_offsets = [](const std::vector<SliceMeta> &sl, int &dummy) {
+        std::vector<int> off16(sl.size());
+        int pos = 0;
+        for (size_t i = 0; i < sl.size(); i++) { off16[i] = pos; pos += sl[i].cnt << sl[i].lg; }
+        dummy = pos;
+        return off16;
+    };
+    auto pack16 = [&](const std::vector<SliceMeta> &sl, const std::vector<int> &off16, int dummy, const std::vector<int> &idx, int pad) {
+        std::vector<int> words(((size_t)dummy + 1) * 2, 0); // two 32-bit words = four 16-bit indices per lane entry
+        auto set = [&](size_t entry, int kk, int v) {
+            if (v < 0 || v > 65535) { idx16_ok = false; v = 0; }
+            words[entry * 2 + (kk >> 1)] |= v << (16 * (kk & 1));
+        };
+        for (size_t i = 0; i < sl.size(); i++) {
+            const int lanes = sl[i].cnt << sl[i].lg;
+            for (int t = 0; t < lanes; t++)
+                for (int kk = 0; kk < ELL_KMAX; kk++)
+                    set((size_t)off16[i] + t, kk, kk < sl[i].K ? idx[(size_t)sl[i].off + (size_t)kk * lanes + t] : pad);
+        }
+        for (int kk = 0; kk < ELL_KMAX; kk++) set((size_t)dummy, kk, pad);
+        return words;
+    };
+    auto meta_ints = [](const std::vector<SliceMeta> &v, const std::vector<int> &off16) {
+        std::vector<int> o(v.size() * 4);
+        for (size_t i = 0; i < v.size(); i++) {
+            const PackedSlice ps = pack_slice(v[i], off16.empty() ? 0 : off16[i]);
+            std::memcpy(o.data() + 4 * i, &ps, sizeof ps);
+        }
         return o;
     };
-    std::vector<int> fsl_i = meta_ints(planF.sl), bsl_i = meta_ints(planB.sl), fac_sl_i = meta_ints(planX.sl);
-    std::vector<int> cag_sl_i = meta_ints(pcag.sl), rA_sl_i = meta_ints(prA.sl), rG_sl_i = meta_ints(prG.sl);
+    const std::vector<int> f_o16 = lane_offsets(planF.sl, D.f_d16), b_o16 = lane_offsets(planB.sl, D.b_d16);
+    const std::vector<int> cag_o16 = lane_offsets(pcag.sl, D.cag_d16), rA_o16 = lane_offsets(prA.sl, D.rA_d16), rG_o16 = lane_offsets(prG.sl, D.rG_d16);
+    const std::vector<int> f_w16 = pack16(planF.sl, f_o16, D.f_d16, planF.idx, S.N), b_w16 = pack16(planB.sl, b_o16, D.b_d16, planB.idx, S.N);
+    const std::vector<int> cag_k_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_k, S.N), cag_yz_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_yz, 0);
+    const std::vector<int> rA_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx, 0), rA_k_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx_k, S.N);
+    const std::vector<int> rG_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx, 0), rG_k_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx_k, S.N);
+    D.idx16 = (idx16_ok && env_int("EICOS_IDX16", 1)) ? 1 : 0;
+    std::vector<int> fsl_i = meta_ints(planF.sl, f_o16), bsl_i = meta_ints(planB.sl, b_o16), fac_sl_i = meta_ints(planX.sl, {});
+    std::vector<int> cag_sl_i = meta_ints(pcag.sl, cag_o16), rA_sl_i = meta_ints(prA.sl, rA_o16), rG_sl_i = meta_ints(prG.sl, rG_o16);
 
     struct Slot { const int **dst; size_t off; };
     std::vector<Slot> slots;
@@ -242,6 +278,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
     put(D.zdsign, zdsign);
     put(D.f_idx, planF.idx); put(D.b_idx, planB.idx);
+    put(D.f_idx16, f_w16); put(D.b_idx16, b_w16); put(D.cag_k16, cag_k_w16); put(D.cag_yz16, cag_yz_w16);
+    put(D.rA_16, rA_w16); put(D.rA_k16, rA_k_w16); put(D.rG_16, rG_w16); put(D.rG_k16, rG_k_w16);
     const int *fsl_p = nullptr, *bsl_p = nullptr, *cag_sl_p = nullptr, *rA_sl_p = nullptr, *rG_sl_p = nullptr;
     put(fsl_p, fsl_i); put(bsl_p, bsl_i); put(cag_sl_p, cag_sl_i); put(rA_sl_p, rA_sl_i); put(rG_sl_p, rG_sl_i);
     put(D.cag_idx_k, cag_idx_k); put(D.cag_idx_yz, cag_idx_yz); put(D.cag_src, cag_src);
@@ -284,13 +322,13 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
         const int wgs_by_regs = (h->threads == 256 ? 3 : 4) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
-            return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(SliceMeta) + lds_static)));
+            return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + lds_static)));
         };
         // the factor program's table goes to LDS too when it is small and does not cost a resident workgroup
         if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total) && env_int("EICOS_FAC_LDS", 1)) {
             D.lm_fac = D.lm_total; D.lm_total += D.fac_ns;
         } else D.lm_fac = -1;
-        const size_t meta = (size_t)D.lm_total * sizeof(SliceMeta);
+        const size_t meta = (size_t)D.lm_total * sizeof(PackedSlice);
         // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
         // all-global variant (NLDS = 0, plain __syncthreads between levels) is used
         // KKT-space vectors in LDS: E (rhs / residual / solve vector) and X (current solution), + both slice tables
@@ -303,9 +341,9 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
         h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : 0;
     }
-    HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dyn_lds));
+    HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
     int bpc = 1;
-    HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dyn_lds, &bpc));
+    HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
     bpc = std::max(1, std::min(bpc, 8));
     {
         // Workgroups per CU for this batch.  A workgroup slows down by about half of its stand-alone time per
@@ -329,10 +367,10 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
     HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
     for (auto &s : slots) *s.dst = h->d_pattern + s.off;
-    D.fsl = reinterpret_cast<const SliceMeta *>(fsl_p); D.bsl = reinterpret_cast<const SliceMeta *>(bsl_p);
-    D.cag_sl = reinterpret_cast<const SliceMeta *>(cag_sl_p); D.rA_sl = reinterpret_cast<const SliceMeta *>(rA_sl_p);
-    D.rG_sl = reinterpret_cast<const SliceMeta *>(rG_sl_p);
-    D.fac_sl = reinterpret_cast<const SliceMeta *>(fac_sl_p);
+    D.fsl = reinterpret_cast<const PackedSlice *>(fsl_p); D.bsl = reinterpret_cast<const PackedSlice *>(bsl_p);
+    D.cag_sl = reinterpret_cast<const PackedSlice *>(cag_sl_p); D.rA_sl = reinterpret_cast<const PackedSlice *>(rA_sl_p);
+    D.rG_sl = reinterpret_cast<const PackedSlice *>(rG_sl_p);
+    D.fac_sl = reinterpret_cast<const PackedSlice *>(fac_sl_p);
     {
         std::lock_guard<std::mutex> lk(g_slot_mu);
         for (int q = 0; q < max_patterns() && q < 64; q++) if (!g_slot_used[device % 16][q]) { h->pslot = q; g_slot_used[device % 16][q] = true; break; }
@@ -455,7 +493,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dyn_lds, h->stream));
+    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;

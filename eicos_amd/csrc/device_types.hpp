@@ -37,8 +37,20 @@ constexpr int DEVINFO_DOUBLES = 32;
 // One slice of a sliced-ELL program: rows/targets [row0, row0+cnt), 2^lg lanes per row, K entries per lane at
 // slot off + k*lanes + lane.  Rows longer than ELL_KMAX << lg are cut into consecutive sub-slices of K <= ELL_KMAX
 // over the same rows: `more` = another sub-slice of these rows follows, `cont` = this one continues the previous.
-struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; };
+struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; }; // host form (plan building, host emulation)
 constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
+
+// Device form of a slice: 16 bytes = one ds_read_b128 / s_load_dwordx4.  off16 = index of the slice's first lane
+// in the plan's packed 16-bit gather-index array (one 8-byte entry = ELL_KMAX indices per lane), see api.cpp.
+// bits: cnt [0,11) | lg [11,14) | K [14,17) | newlev 17 | last slice of its level 18 (factor plan) | more 19 | cont 20
+struct PackedSlice { int row0, off, off16, bits; };
+constexpr int PS_LG = 11, PS_K = 14, PS_NEWLEV = 17, PS_LAST = 18, PS_MORE = 19, PS_CONT = 20;
+inline PackedSlice pack_slice(const SliceMeta &m, int off16) {
+    return PackedSlice{m.row0, m.off, off16,
+                       m.cnt | (m.lg << PS_LG) | (m.K << PS_K) | ((m.newlev & 1) << PS_NEWLEV) | (((m.newlev >> 1) & 1) << PS_LAST) |
+                           ((m.more & 1) << PS_MORE) | ((m.cont & 1) << PS_CONT)};
+}
+static_assert(ELL_KMAX == 4, "the packed index entries hold four 16-bit indices per lane");
 #ifndef EICOS_TRI_DEPTH
 #define EICOS_TRI_DEPTH 3
 #endif
@@ -65,7 +77,7 @@ struct DevPat {
     // (cag: x-space results), rows of A (rA), rows of G (rG).  *_src: slot -> offset of the CSC value
     // relative to Av (-1 = padding); cag has two gather-index sets: KKT indices (refinement) and
     // offsets into the contiguous (y, z) block of the instance slab (residuals).
-    const SliceMeta EICOS_GLOBAL *cag_sl; const SliceMeta EICOS_GLOBAL *rA_sl; const SliceMeta EICOS_GLOBAL *rG_sl;
+    const PackedSlice EICOS_GLOBAL *cag_sl; const PackedSlice EICOS_GLOBAL *rA_sl; const PackedSlice EICOS_GLOBAL *rG_sl;
     int cag_ns, rA_ns, rG_ns, cag_slots, rA_slots, rG_slots;
     gint_p cag_idx_k, cag_idx_yz, cag_src, rA_idx, rA_idx_k, rA_src, rG_idx, rG_idx_k, rG_src;
     // KKT-space vectors live in the (level-ordered) elimination order on the device: position of
@@ -78,15 +90,19 @@ struct DevPat {
     // LDL' pattern, level ordered
     // triangular solves: sliced-ELL plans (see SliceMeta).  UF = unit-lower L in the forward (row) slot order,
     // UB = U = L.*D (column-scaled) in the backward (column) slot order (the CSC-entry -> slot maps stay on the host)
-    const SliceMeta EICOS_GLOBAL *fsl; const SliceMeta EICOS_GLOBAL *bsl;
+    const PackedSlice EICOS_GLOBAL *fsl; const PackedSlice EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;   // nfs / nbs = slices of the workgroup-wide part of the forward / backward plan
     int nfs_solo, nbs_solo;   // single-wavefront part (top of the tree): fsl = [wide | solo], bsl = [solo | wide]
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
     gint_p f_idx, b_idx;
+    // 16-bit gather indices (idx16 = 1: every index of every plan fits 16 bits): per plan one 8-byte entry per lane and
+    // slice holding its ELL_KMAX indices, PackedSlice::off16 + lane; *_d16 = the all-padding entry inactive lanes read
+    int idx16, f_d16, b_d16, cag_d16, rA_d16, rG_d16;
+    gint_p f_idx16, b_idx16, cag_k16, cag_yz16, rA_16, rA_k16, rG_16, rG_k16;
     // numeric factorisation: sliced-ELL program (plans.hpp: FactorPlan); per target: source offset of its
     // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot
-    const SliceMeta EICOS_GLOBAL *fac_sl;
+    const PackedSlice EICOS_GLOBAL *fac_sl;
     int fac_ns, fac_slots, fac_nt; // slices, pair slots, targets
     int w_Kt;                      // [fac_nt] KKT entry of every target, in target order (workspace slab)
     gint_p v2t;                    // [nV] scaling-block entry -> its target

@@ -193,29 +193,46 @@ __device__ __forceinline__ void for_t_pre(int cnt, L &&ld, F &&fn) {
 // ahead of the arithmetic (same register queue as tri_sweep, no barriers); plans are padded to a
 // multiple of ELL_DEPTH slices and hold at most ELL_KMAX entries per lane and slice (longer rows are
 // cut into sub-slices whose partial sums are carried in a register).  `sm` may live in LDS (staged by k_solve) or in global memory.
+// Decoded slice descriptor; every field is workgroup-uniform (SGPRs).
+struct Sl { int row0, off, off16, cnt, lg, K, newlev, last, more, cont; };
+template <class Tab> __device__ __forceinline__ Sl slice_at(const Tab *tab, int s) {
+    const PackedSlice w = tab[s]; // 16 bytes: one ds_read_b128 (LDS copy) or one global/scalar load
+    const int b = uni(w.bits);
+    return Sl{uni(w.row0), uni(w.off), uni(w.off16), b & ((1 << PS_LG) - 1), (b >> PS_LG) & 7, (b >> PS_K) & 7,
+              (b >> PS_NEWLEV) & 1, (b >> PS_LAST) & 1, (b >> PS_MORE) & 1, (b >> PS_CONT) & 1};
+}
+// The ELL_KMAX gather indices of one lane: four 32-bit loads, or (I16) one 8-byte load of four packed 16-bit indices.
+typedef const uint2 EICOS_GLOBAL *gidx16_p;
+template <bool I16> __device__ __forceinline__ void load_indices(int (&ni)[ELL_KMAX], gint_p eidx, gint_p eidx16, bool act, int K, int off,
+                                                                 int lanes, int t, int dummy_slot, int off16, int d16) {
+    if constexpr (I16) {
+        const uint2 w = reinterpret_cast<gidx16_p>(eidx16)[act ? off16 + t : d16];
+        ni[0] = w.x & 0xffffu; ni[1] = w.x >> 16; ni[2] = w.y & 0xffffu; ni[3] = w.y >> 16;
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < ELL_KMAX; kk++) ni[kk] = eidx[(act && kk < K) ? off + kk * lanes + t : dummy_slot];
+    }
+}
+
 // `pre(row)` loads whatever the epilogue needs per row (rhs entry, destination index, ...); it is issued with the
 // slice's index/value loads, ELL_DEPTH slices ahead, so that `epi(row, sum, pre(row))` starts no global load itself.
-template <int T, class SM, class V, class X, class Pre, class Epi>
-__device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V eval, X x, int dummy_slot, Pre &&pre, Epi &&epi) {
+template <int T, bool I16, class SM, class V, class X, class Pre, class Epi>
+__device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, V eval, X x, int dummy_slot,
+                                         Pre &&pre, Epi &&epi) {
     if (ns == 0) return; // no rows
     const int t = threadIdx.x;
     using R = decltype(pre(0));
     int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX]; R qr[ELL_DEPTH];
-    auto meta = [&](int s) {
-        SliceMeta m = sm[s];
-        m.row0 = uni(m.row0); m.cnt = uni(m.cnt); m.lg = uni(m.lg); m.K = uni(m.K); m.off = uni(m.off);
-        m.more = uni(m.more); m.cont = uni(m.cont);
-        return m;
-    };
+    auto meta = [&](int s) { return slice_at(sm, s); };
     double carry = 0.; // partial sum of rows cut into sub-slices (SliceMeta::more / cont)
     auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX], R &nr) {
-        const SliceMeta nm = meta(s);
+        const Sl nm = meta(s);
         const int lanes = nm.cnt << nm.lg;
         const bool act = t < lanes;
+        load_indices<I16>(ni, eidx, eidx16, act, nm.K, nm.off, lanes, t, dummy_slot, nm.off16, d16);
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
-            ni[kk] = eidx[slot];
             nv[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per pass: keep the shared index arrays in L2
         }
         nr = pre(act ? nm.row0 + (t >> nm.lg) : 0);
@@ -226,7 +243,7 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, V ev
 #pragma unroll
         for (int d = 0; d < ELL_DEPTH; d++) {
             const int s = s0 + d;
-            const SliceMeta m = meta(s);
+            const Sl m = meta(s);
             int ci[ELL_KMAX]; double cv[ELL_KMAX];
             const R cr = qr[d];
 #pragma unroll
@@ -269,8 +286,8 @@ __device__ __forceinline__ void lds_barrier() {
 // SOLO: the narrow top of the elimination tree, laid out for 64 lanes and run by wavefront 0 alone -- no
 // workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
-template <int T, bool FORWARD, bool LDSBAR, bool SOLO, class SM, class WS>
-__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcdbl_p eval, gcdbl_p invD, WS ws,
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, class SM, class WS>
+__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
@@ -278,18 +295,18 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gcd
         int row0, lg, K, off, lanes, newlev, more, cont;
         int idx[ELL_KMAX]; double val[ELL_KMAX]; double d, own;
     } q[TRI_DEPTH];
-    // every slice issues exactly 2*ELL_KMAX+1 global loads per lane (inactive lanes / padding read the
-    // plan's dummy slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
+    // every slice issues the same number of global loads per lane (inactive lanes / padding read the plan's dummy
+    // slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
     auto load = [&](int s, Slot &o) {
-        const SliceMeta nm = sm[s];
-        o.row0 = uni(nm.row0); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off); o.newlev = uni(nm.newlev);
-        o.more = uni(nm.more); o.cont = uni(nm.cont);
-        o.lanes = uni(nm.cnt) << o.lg;
+        const Sl nm = slice_at(sm, s);
+        o.row0 = nm.row0; o.lg = nm.lg; o.K = nm.K; o.off = nm.off; o.newlev = nm.newlev;
+        o.more = nm.more; o.cont = nm.cont;
+        o.lanes = nm.cnt << o.lg;
         const bool act = t < o.lanes;
+        load_indices<I16>(o.idx, eidx, eidx16, act, o.K, o.off, o.lanes, t, dummy_slot, nm.off16, d16);
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
-            o.idx[kk] = eidx[slot];
             o.val[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per sweep: do not displace the index arrays in L2
         }
         const int r = act ? o.row0 + (t >> o.lg) : 0;
@@ -495,7 +512,7 @@ __device__ __forceinline__ void restore_scalars() { // w = w_best (scalars), cou
 }
 
 // Slice table `which` of the current pattern: the LDS copy (NLDS >= 1) or the one in global memory.
-#define LDS_TABLE(at) (reinterpret_cast<const SliceMeta *>(g_dyn + (size_t)NLDS * P.Npad) + (at))
+#define LDS_TABLE(at) (reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)NLDS * P.Npad) + (at))
 
 // states of the solve program
 enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KKT_AFF, ST_KKT_COMB, ST_DONE };
@@ -538,16 +555,11 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
     // the loads that need them, so that their round trip is not on the path either
-    auto fmeta = [&](int sidx) {
-        SliceMeta nm;
-        if (tab_lds) nm = LDS_TABLE(P.lm_fac)[sidx]; else nm = P.fac_sl[sidx];
-        return nm;
-    };
-    auto fload = [&](const SliceMeta &nm, FSlot &o) {
-        o.row0 = uni(nm.row0); o.cnt = uni(nm.cnt); o.lg = uni(nm.lg); o.K = uni(nm.K); o.off = uni(nm.off);
-        const int nl = uni(nm.newlev);
-        o.newlev = nl & 1; o.last = nl >> 1;
-        o.more = uni(nm.more); o.cont = uni(nm.cont);
+    auto fmeta = [&](int sidx) { return tab_lds ? slice_at(LDS_TABLE(P.lm_fac), sidx) : slice_at(P.fac_sl, sidx); };
+    auto fload = [&](const Sl &nm, FSlot &o) {
+        o.row0 = nm.row0; o.cnt = nm.cnt; o.lg = nm.lg; o.K = nm.K; o.off = nm.off;
+        o.newlev = nm.newlev; o.last = nm.last;
+        o.more = nm.more; o.cont = nm.cont;
         o.lanes = o.cnt << o.lg;
         const bool act = tid < o.lanes;
 #pragma unroll
@@ -561,7 +573,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     };
 #pragma unroll
     for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(d, ns - 1)), q[d]);
-    SliceMeta pm = fmeta(min(FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
+    Sl pm = fmeta(min(FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
     double gu[ELL_KMAX], gl[ELL_KMAX];
     bool have = false;
@@ -628,7 +640,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
-template <int T, int NLDS>
+template <int T, int NLDS, bool I16>
 __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
@@ -647,14 +659,14 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
     struct Pre2 { double a, b; };
     struct Pre3 { double a, b, c; };
-    ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_yz, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j]}; },
+    ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_yz, P.cag_yz16, P.cag_d16, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j]}; },
                 [&](int j, double s, const Pre2 &pr) { // -G'z - A'y: (y,z) contiguous
         const double hr = -s, c_ = pr.a, xj = pr.b;
         const double r = hr - tau * c_;
         rx[j] = r;
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
-    ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r]}; },
+    ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx, P.rA_16, P.rA_d16, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r]}; },
                 [&](int r, double s, const Pre2 &pr) {
         const double b_ = pr.a, yr = pr.b;
         const double rr = s - tau * b_;
@@ -663,7 +675,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
     double q6[6] = {0, 0, 0, 0, 0, 0}; // hresz2 rz2 hz nz2 ns2 gap
-    ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i]}; },
+    ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx, P.rG_16, P.rG_d16, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i]}; },
                 [&](int i, double s, const Pre3 &pr) {
         const double si = pr.a, zi = pr.b, h_ = pr.c;
         const double hr = si + s, r = hr - tau * h_;
@@ -838,7 +850,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
 }
 
 // ---------------- the KKT stages: pick rhs / outputs, solveKKT, post-process ----------------
-template <int T, int NLDS>
+template <int T, int NLDS, bool I16>
 __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     STAGE_PROLOGUE
     stage = uni(stage);
@@ -893,22 +905,22 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
             const bool wave0 = uni(tid >> 6) == 0;
             if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-                tri_sweep<T, true, true, false>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, UF, invD, SV, P.nUF); // barriers at level starts + end
+                tri_sweep<T, true, true, false, I16>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
                 if (wave0) {
-                    tri_sweep<T, true, true, true>(LDS_TABLE(P.lm_f) + P.nfs, P.nfs_solo, P.f_idx, UF, invD, SV, P.nUF);
+                    tri_sweep<T, true, true, true, I16>(LDS_TABLE(P.lm_f) + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     TICK_END(TK_FWD);
-                    tri_sweep<T, false, true, true>(LDS_TABLE(P.lm_b), P.nbs_solo, P.b_idx, UB, invD, SV, P.nUB);
+                    tri_sweep<T, false, true, true, I16>(LDS_TABLE(P.lm_b), P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
                 __syncthreads();
-                tri_sweep<T, false, true, false>(LDS_TABLE(P.lm_b) + P.nbs_solo, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
+                tri_sweep<T, false, true, false, I16>(LDS_TABLE(P.lm_b) + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             } else {
-                tri_sweep<T, true, false, false>(P.fsl, P.nfs, P.f_idx, UF, invD, SV, P.nUF);
+                tri_sweep<T, true, false, false, I16>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                 if (wave0) {
-                    tri_sweep<T, true, false, true>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, UF, invD, SV, P.nUF);
-                    tri_sweep<T, false, false, true>(P.bsl, P.nbs_solo, P.b_idx, UB, invD, SV, P.nUB);
+                    tri_sweep<T, true, false, true, I16>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tri_sweep<T, false, false, true, I16>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
                 __syncthreads();
-                tri_sweep<T, false, false, false>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, UB, invD, SV, P.nUB);
+                tri_sweep<T, false, false, false, I16>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
             if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
                 if (k >= 0) for_t_pre<T, 6>(N, [&](int i) { return V1{Xg[i]}; }, [&](int i, const V1 &r) { SV[i] = r.a + SV[i]; });
@@ -923,19 +935,19 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
             double nex = 0., ney = 0., nez = 0.;
             struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
-            ell_dots<T>(tab_cag, P.cag_ns, P.cag_idx_k, cagv, X, P.cag_slots, [&](int j) { return PreK{bx[j], 0., P.ipx[j], 0}; },
+            ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots, [&](int j) { return PreK{bx[j], 0., P.ipx[j], 0}; },
                         [&](int j, double s, const PreK &pr) {
                 const int o = pr.o;
                 const double e = pr.b - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
                 E[o] = e; nex = fmax(nex, fabs(e));
             });
-            ell_dots<T>(tab_rA, P.rA_ns, P.rA_idx_k, rAv, X, P.rA_slots, [&](int r) { return PreK{by[r], 0., P.ipy[r], 0}; },
+            ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots, [&](int r) { return PreK{by[r], 0., P.ipy[r], 0}; },
                         [&](int r, double s, const PreK &pr) {
                 const int o = pr.o;
                 const double e = pr.b - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
                 E[o] = e; ney = fmax(ney, fabs(e));
             });
-            ell_dots<T>(tab_rG, P.rG_ns, P.rG_idx_k, rGv, X, P.rG_slots,
+            ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
                         [&](int i) { return PreK{bz[i], lpv[i < l ? i : 0], P.ipz[i], (int)P.zdsign[i]}; },
                         [&](int i, double s, const PreK &pr) {
                 const int o = pr.o;
@@ -1136,7 +1148,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     return stage;
 }
 
-template <int T, int NLDS>
+template <int T, int NLDS, bool I16>
 __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
@@ -1188,10 +1200,10 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     int iter = -1; // -1 while initialising
     while (stage != ST_DONE) {
         if (stage == ST_FACTOR) stage = stage_factor<T, NLDS>(ps, I, W, iter);
-        else if (stage == ST_RESID) stage = stage_resid<T, NLDS>(ps, I, W, iter);
+        else if (stage == ST_RESID) stage = stage_resid<T, NLDS, I16>(ps, I, W, iter);
         else {
             const int prev = stage;
-            stage = stage_kkt<T, NLDS>(ps, I, W, stage);
+            stage = stage_kkt<T, NLDS, I16>(ps, I, W, stage);
             if (stage == ST_RESID) iter = (prev == ST_KKT_INIT2) ? 0 : iter + 1; // a pass of the main loop completed
         }
     }
@@ -1208,16 +1220,16 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     }
 }
 
-template <int T, int NLDS>
+template <int T, int NLDS, bool I16>
 __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
     int ps, double *inst, double *work, int B, int *queue, const int *order) {
     const DevPat &P = c_pat[ps];
     gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
         int *dst = reinterpret_cast<int *>(g_dyn + (size_t)NLDS * P.Npad);
-        auto stage = [&](const SliceMeta EICOS_GLOBAL *src, int cnt, int at) {
+        auto stage = [&](const PackedSlice EICOS_GLOBAL *src, int cnt, int at) {
             gint_p si = reinterpret_cast<gint_p>(src);
-            for (int q = threadIdx.x; q < cnt * 8; q += T) dst[at * 8 + q] = si[q];
+            for (int q = threadIdx.x; q < cnt * 4; q += T) dst[at * 4 + q] = si[q];
         };
         stage(P.fsl, P.nfs + P.nfs_solo, P.lm_f); stage(P.bsl, P.nbs + P.nbs_solo, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
         stage(P.rA_sl, P.rA_ns, P.lm_rA); stage(P.rG_sl, P.rG_ns, P.lm_rG);
@@ -1230,7 +1242,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
     // `order` (batches larger than the grid): instances sorted by the work their previous solve took, longest first.
     for (int i = blockIdx.x; i < B;) {
         const int id = order ? order[i] : i;
-        solve_instance<T, NLDS>(ps, (gdbl_p)inst + (size_t)id * P.inst_stride, W);
+        solve_instance<T, NLDS, I16>(ps, (gdbl_p)inst + (size_t)id * P.inst_stride, W);
         __syncthreads();
         if (threadIdx.x == 0) g_S.next = (int)gridDim.x + atomicAdd(queue, 1);
         __syncthreads();
@@ -1360,19 +1372,24 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
 }
 
 // ---- launchers (called from api.cpp) ----
-template <class F> static auto dispatch_solve(int threads, int nlds, F &&f) {
+template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        if (nlds >= 2) return f((const void *)k_solve<T, 2>);
-        if (nlds == 1) return f((const void *)k_solve<T, 1>);
-        return f((const void *)k_solve<T, 0>);
+        if (idx16) {
+            if (nlds >= 2) return f((const void *)k_solve<T, 2, true>);
+            if (nlds == 1) return f((const void *)k_solve<T, 1, true>);
+            return f((const void *)k_solve<T, 0, true>);
+        }
+        if (nlds >= 2) return f((const void *)k_solve<T, 2, false>);
+        if (nlds == 1) return f((const void *)k_solve<T, 1, false>);
+        return f((const void *)k_solve<T, 0, false>);
     };
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
 }
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        size_t dyn_lds, hipStream_t st) {
+                        int idx16, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // instance queue of this launch
     if (e != hipSuccess) return e;
@@ -1381,7 +1398,7 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    return dispatch_solve(threads, nlds, [&](const void *fn) {
+    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
@@ -1401,14 +1418,14 @@ hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int th
     }
     return hipGetLastError();
 }
-hipError_t solve_occupancy(int threads, int nlds, size_t dyn_lds, int *blocks_per_cu) {
-    return dispatch_solve(threads, nlds, [&](const void *fn) {
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu) {
+    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, threads, dyn_lds);
     });
 }
-hipError_t solve_set_max_lds(int threads, int nlds, size_t dyn_lds) {
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds) {
     if (dyn_lds == 0) return hipSuccess;
-    return dispatch_solve(threads, nlds, [&](const void *fn) {
+    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
     });
 }

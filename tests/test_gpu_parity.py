@@ -154,7 +154,7 @@ def test_dense_front_socp():
 
 
 @pytest.mark.parametrize("env", [{"EICOS_NLDS": "0"}, {"EICOS_NLDS": "1"}, {"EICOS_NLDS": "2"}, {"EICOS_THREADS": "128"},
-                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}])
+                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_IDX16": "0"}, {"EICOS_IDX16": "0", "EICOS_NLDS": "0"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
     # or in the workspace slab, 128/256/512 threads) through an LP, an SOC and an infeasible fixture
