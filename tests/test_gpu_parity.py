@@ -355,3 +355,26 @@ int main() {
     assert out.returncode == 0, out.stdout + out.stderr
     toks = out.stdout.split()
     assert abs(float(toks[3]) + 1.0) < 1e-7 and abs(float(toks[8]) + 3.0) < 1e-7 and abs(float(toks[10]) - 3.0) < 1e-6, out.stdout
+
+
+def test_large_pattern_uses_slab_vectors_and_32bit_indices():
+    # dim_K > 65535: the solve vector does not fit LDS (NLDS = 0, slab vectors, plain barriers), gather indices stay
+    # 32-bit, and the factor program's slice table is read from global memory -- the paths small fixtures never take
+    from scipy.sparse import csc_matrix, vstack, identity, diags
+    from eicos_amd.problem_io import Pattern
+    n = 24000
+    rng = np.random.default_rng(11)
+    band = diags([rng.uniform(0.5, 1.5, n - 1), rng.uniform(0.5, 1.5, n - 2)], [1, 2], shape=(n // 2, n))
+    G = csc_matrix(vstack([-identity(n), identity(n), band])); G.sort_indices()
+    rows = np.repeat(np.arange(n // 4), 3)
+    cols = (4 * np.arange(n // 4))[:, None] + np.arange(3)[None, :]
+    A = csc_matrix((rng.uniform(0.5, 1.5, rows.size) * np.tile([1, 0.1, -1], n // 4), (rows, cols.ravel())), shape=(n // 4, n))
+    A.sort_indices()
+    pat = Pattern(n, G.shape[0], A.shape[0], G.shape[0], np.zeros(0, np.int32), G.indptr.astype(np.int32),
+                  G.indices.astype(np.int32), A.indptr.astype(np.int32), A.indices.astype(np.int32))
+    base = Values(G.data.copy(), A.data.copy(), np.zeros(n), np.zeros(G.shape[0]), np.zeros(A.shape[0]))
+    assert pat.n + pat.p + pat.m > 65535
+    g = eicos_amd.BatchSolver(pat, 2)
+    assert g.dims()["lds_bytes"] == 0 and g.dims()["dim_K"] > 65535
+    g.close()
+    _check_batch(pat, feasible_batch(pat, base, 0, 2, seed=5), 2, 1, x_rtol=1e-7)

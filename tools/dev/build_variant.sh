@@ -5,7 +5,7 @@ set -e
 tag=$1; shift
 cd "$(dirname "$0")/../../eicos_amd/csrc"
 out=../../build_exp/obj_$tag; mkdir -p $out
-F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-parameter -ffp-contract=off $*"
+F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-parameter ${FPC:--ffp-contract=off} $*"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F -c kernels.hip -o $out/kernels.o &
 /opt/rocm/bin/hipcc $F -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c api.cpp -o $out/api.o
 /opt/rocm/bin/hipcc $F -x c++ -c symbolic.cpp -o $out/symbolic.o
