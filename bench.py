@@ -67,6 +67,11 @@ def main():
     ap.add_argument("--perturb", action="store_true", help="LPnetlib-style batch: perturb c,h of the fixture "
                     "(SURVEY.md 8d config 4) instead of generating strictly feasible (c,h,b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resolve", type=float, default=0.0, metavar="EPS", help="MPC-style re-solves: steps alternate between "
+                    "the batch and a copy with c, h perturbed by EPS (relative), so every solve follows an updateData with "
+                    "nearby data (not the headline workload)")
+    ap.add_argument("--warm", type=float, default=0.0, metavar="SHIFT", help="with --resolve: warm-start each solve from the "
+                    "previous solution (extension, eicos_batch_set_warm_start); 0 = cold start as in the reference")
     ap.add_argument("--io", choices=("local", "root"), default="local", help="local: every rank regenerates its own shard "
                     "(no collective, default); root: rank 0 holds the whole batch and scatters shards over RCCL/xGMI "
                     "before the timed region, results are gathered back after it (times reported in config)")
@@ -127,14 +132,26 @@ def main():
         assert all(torch.equal(dev[k].cpu(), torch.from_numpy(data[k])) for k in KEYS), "scattered shard differs"
     else:
         dev = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in data.items()}
-    ptr = lambda k: dev[k].data_ptr() if dev[k].numel() else 0
+    devs = [dev]
+    if args.resolve > 0:
+        rng = np.random.default_rng(SEED + 17 + rank)
+        alt = dict(data)
+        alt["c"] = data["c"] * (1 + args.resolve * rng.uniform(-1, 1, data["c"].shape))
+        alt["h"] = data["h"] + args.resolve * (1 + np.abs(data["h"])) * rng.uniform(0, 1, data["h"].shape)
+        devs.append({k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in alt.items()})
+    step_no = [0]
+    ptr = lambda k: (lambda t: t.data_ptr() if t.numel() else 0)(devs[step_no[0] % len(devs)][k])
 
     solver = eicos_amd.BatchSolver(pat, B, device=local_rank)
     dims = solver.dims()
 
+    if args.warm > 0:
+        solver.set_warm_start(args.warm)
+
     def step():
         solver.update_device(ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))
         solver.solve_async()
+        step_no[0] += 1
 
     def fence():
         if dist is not None:
@@ -201,7 +218,8 @@ def main():
                        "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
                        "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B, "generator": "perturbed" if args.perturb else "feasible",
                        "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
-                       "io": ("root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms},
+                       "io": ("root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms,
+                       **({"resolve_eps": args.resolve, "warm_shift": args.warm} if args.resolve > 0 else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},

@@ -78,6 +78,8 @@ def _lib():
         L.eicos_batch_solution_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.eicos_batch_dims.argtypes = [vp, C.POINTER(Dims)]
         L.eicos_batch_set_stream.argtypes = [vp, vp]
+        L.eicos_batch_set_warm_start.argtypes = [vp, C.c_double]
+        L.eicos_batch_set_warm_start.restype = C.c_int
         L.eicos_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_last_update_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_destroy.argtypes = [vp]
@@ -161,6 +163,10 @@ class BatchSolver:
 
     def sync(self):
         _chk(_lib().eicos_batch_sync(self._h))
+
+    def set_warm_start(self, shift: float):
+        """shift > 0: re-solves start from the previous solution (not in the reference; see include/eicos_amd.h)."""
+        _chk(_lib().eicos_batch_set_warm_start(self._h, float(shift)))
 
     def set_stream(self, stream_ptr: int):
         _chk(_lib().eicos_batch_set_stream(self._h, C.c_void_p(int(stream_ptr) or None)))

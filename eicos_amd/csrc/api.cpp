@@ -44,6 +44,7 @@ struct eicos_batch {
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     int *d_queue = nullptr; // instance queue of the solve kernel (reset per launch)
+    double warm_shift = 0.; // > 0: warm start (eicos_batch_set_warm_start)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
     bool solve_timed = false, update_timed = false;
@@ -434,6 +435,12 @@ int eicos_batch_destroy(eicos_batch *h) {
     return EICOS_OK;
 }
 
+int eicos_batch_set_warm_start(eicos_batch *h, double shift) {
+    if (!h || !(shift >= 0.)) return fail(EICOS_E_INVALID, "bad argument");
+    h->warm_shift = shift;
+    return EICOS_OK;
+}
+
 int eicos_batch_set_stream(eicos_batch *h, void *hip_stream) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
@@ -493,7 +500,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, h->dyn_lds, h->stream));
+    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, h->warm_shift, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;

@@ -56,7 +56,7 @@ constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values 
 // scalar slots in LDS (written by thread 0 only)
 enum { SV_RESX0 = 0, SV_RESY0, SV_RESZ0, SV_PRESPREV, SV_RT, SV_DTAUDEN, SV_DTAUAFF, SV_DKAPAFF, SV_BKAP,
        SV_DTAU, SV_DKAP, SV_ALPHA, SV_COUNT };
-enum { FL_FATAL = 0, FL_ACTION, FL_RESTORE, FL_SAVE, FL_CODE, FL_COUNT };
+enum { FL_FATAL = 0, FL_ACTION, FL_RESTORE, FL_SAVE, FL_CODE, FL_WARM, FL_COUNT };
 enum { ACT_CONTINUE = 0, ACT_BREAK = 1 };
 
 // Pattern descriptors live in the constant address space: field loads are scalar (s_load) and
@@ -1149,7 +1149,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
 }
 
 template <int T, int NLDS, bool I16>
-__device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
+__device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, double warm) {
     const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
     const int tid = threadIdx.x;
@@ -1162,6 +1162,8 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     __syncthreads();
         if (tid == 0) { // sticky across solve() calls like the reference's w.i
             wi = *ginfo; g_S.bi = wi;
+            // warm start (N3, not in the reference): needs a previous OPTIMAL solve of this instance
+            g_S.fl[FL_WARM] = (warm > 0. && wi.n_factor > 0 && (wi.exitcode == 0 || wi.exitcode == 10)) ? 1 : 0;
             wi.n_factor = 0; wi.n_ldlsolve = 0;
             g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7;
         for (int q = 0; q < 12; q++) g_S.tick[q] = 0;
@@ -1198,6 +1200,40 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
     }
     int stage = ST_FACTOR;
     int iter = -1; // -1 while initialising
+    __syncthreads();
+    if (g_S.fl[FL_WARM]) {
+        // ---- warm start: previous (x, y, z, s) of this instance (still in its slab, backscaled) re-equilibrated and
+        // pushed into the cone -- LP rows floored at warm * mean|.|, cone heads at ||tail|| + the same margin --
+        // instead of the two initialisation solves (ref :929-972); tau = kap = 1, first pass = iteration 0.
+        gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s, cv = I + P.i_c;
+        gcdbl_p xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
+        gdbl_p rhs1 = W + P.w_rhs1, rhs1k = W + P.w_rhs1k;
+        int phase = 0;
+        FOR_T(j, n) wx[j] *= xe[j];
+        FOR_T(r, p) wy[r] *= ae[r];
+        double sz2[2] = {0., 0.};
+        FOR_T(i, m) { const double g = ge[i], zv = wz[i] * g, sv = wsl[i] / g; wz[i] = zv; wsl[i] = sv; sz2[0] += fabs(sv); sz2[1] += fabs(zv); }
+        blk_reduce<OpSum, T, 2>(phase, sz2);
+        const double as = warm * sz2[0] / (double)max(1, m), az = warm * sz2[1] / (double)max(1, m);
+        __syncthreads();
+        FOR_T(i, l) { wsl[i] = fmax(wsl[i], as); wz[i] = fmax(wz[i], az); }
+        for_cones<T>(ps, [&](int c, auto G, int ln) {
+            constexpr int g = decltype(G)::value;
+            const int o = P.cone_off[c], d = P.cq[c];
+            double ts = 0., tz = 0.;
+            for (int k = 1 + ln; k < d; k += g) { ts += wsl[o + k] * wsl[o + k]; tz += wz[o + k] * wz[o + k]; }
+            ts = grp_sum<g>(ts); tz = grp_sum<g>(tz);
+            if (ln == 0) { wsl[o] = fmax(wsl[o], sqrt(ts) + as); wz[o] = fmax(wz[o], sqrt(tz) + az); }
+        });
+        FOR_T(j, n) { const double v = -cv[j]; rhs1[P.ipx[j]] = v; rhs1k[j] = v; } // as after the second init solve (ref :966-972)
+        if (tid == 0) {
+            wi.nitref1 = 0; wi.nitref2 = 0;
+            wi.kap = 1.; wi.tau = 1.; wi.step = 0.; wi.step_aff = 0.; wi.pinf = 0; wi.dinf = 0;
+            g_S.sv[SV_PRESPREV] = DBL_MAX;
+        }
+        __syncthreads();
+        stage = ST_RESID; iter = 0;
+    }
     while (stage != ST_DONE) {
         if (stage == ST_FACTOR) stage = stage_factor<T, NLDS>(ps, I, W, iter);
         else if (stage == ST_RESID) stage = stage_resid<T, NLDS, I16>(ps, I, W, iter);
@@ -1222,7 +1258,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W) {
 
 template <int T, int NLDS, bool I16>
 __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
-    int ps, double *inst, double *work, int B, int *queue, const int *order) {
+    int ps, double *inst, double *work, int B, int *queue, const int *order, double warm) {
     const DevPat &P = c_pat[ps];
     gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
@@ -1242,7 +1278,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
     // `order` (batches larger than the grid): instances sorted by the work their previous solve took, longest first.
     for (int i = blockIdx.x; i < B;) {
         const int id = order ? order[i] : i;
-        solve_instance<T, NLDS, I16>(ps, (gdbl_p)inst + (size_t)id * P.inst_stride, W);
+        solve_instance<T, NLDS, I16>(ps, (gdbl_p)inst + (size_t)id * P.inst_stride, W, warm);
         __syncthreads();
         if (threadIdx.x == 0) g_S.next = (int)gridDim.x + atomicAdd(queue, 1);
         __syncthreads();
@@ -1389,7 +1425,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
     return byT(std::integral_constant<int, 256>{});
 }
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        int idx16, size_t dyn_lds, hipStream_t st) {
+                        int idx16, double warm, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // instance queue of this launch
     if (e != hipSuccess) return e;
@@ -1399,7 +1435,7 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
-        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order};
+        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order, (void *)&warm};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
 }

@@ -124,6 +124,8 @@ namespace EiCOS
         {
             detail::check(eicos_batch_update(h_, first, count < 0 ? batch_ : count, Gpr, Apr, c, h, b), "eicos_batch_update");
         }
+        // Extension (not in the reference): re-solves start from the previous solution, see eicos_amd.h
+        void setWarmStart(double shift) { detail::check(eicos_batch_set_warm_start(h_, shift), "eicos_batch_set_warm_start"); }
         std::vector<exitcode> solve()
         {
             std::vector<int> codes(batch_);
@@ -231,6 +233,8 @@ namespace EiCOS
 #endif
         Settings &getSettings() { return settings_; }
         const Information &getInfo() const { return info_; }
+        // Extension (not in the reference, which cold-starts every solve): warm-start the next solves after updateData
+        void setWarmStart(double shift) { eicos_batch_set_warm_start(h_, shift); }
 
     private:
         eicos_batch *h_ = nullptr;

@@ -103,6 +103,13 @@ int eicos_batch_info(eicos_batch *hd, eicos_info *info /* [batch] */);
 /* Device-resident results (no copy): pointer to instance 0's x and the stride in doubles. */
 int eicos_batch_solution_device(eicos_batch *hd, const double **dx, size_t *stride_doubles);
 
+/* ---- warm start (N3 of SURVEY.md 8f; NOT in the reference, whose solve() always cold-starts, src/eicos.cpp:855-984).
+ * shift > 0: a solve of an instance whose previous solve ended OPTIMAL skips the two initialisation solves and starts
+ * from that solution -- re-equilibrated, with s and z pushed into the cone (LP rows floored at shift * mean|.|, cone
+ * heads at ||tail|| + the same margin), tau = kap = 1.  shift = 0 (default) restores the reference behaviour.
+ * 0.1 is a good value for MPC re-solves (1 % data perturbation: 13-15 -> 8-10 iterations). */
+int eicos_batch_set_warm_start(eicos_batch *hd, double shift);
+
 /* ---- plumbing */
 int eicos_batch_dims(eicos_batch *hd, eicos_dims *out);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the own stream. */

@@ -772,6 +772,29 @@ struct Solver {
         for (int j = 0; j < m; j++) w.s[j] *= (geq[j] / w.tau);
     }
 
+    /* ---------- N3 of SURVEY.md 8f (NOT in the reference, off by default): warm start ----------
+     * With warm_shift > 0 and a previous OPTIMAL solve on this object, solve() skips the two initialisation solves
+     * (ref :929-972) and starts from the previous (x, y, z, s), re-equilibrated, with s and z pushed into the cone:
+     * LP rows s_i = max(s_i, a_s), z_i = max(z_i, a_z); SOC: head = max(head, ||tail|| + a), where
+     * a_s = warm_shift * mean|s|, a_z = warm_shift * mean|z|.  tau = kap = 1. */
+    double warm_shift = 0.;
+    vec px, py, pz, ps; bool have_prev = false;
+    void warm_init() {
+        for (int j = 0; j < n; j++) w.x[j] = px[j] * xeq[j];
+        for (int j = 0; j < p; j++) w.y[j] = py[j] * aeq[j];
+        double sm = 0, zm = 0;
+        for (int j = 0; j < m; j++) { w.z[j] = pz[j] * geq[j]; w.s[j] = ps[j] / geq[j]; sm += std::fabs(w.s[j]); zm += std::fabs(w.z[j]); }
+        const double as = warm_shift * sm / std::max(1, m), az = warm_shift * zm / std::max(1, m);
+        for (int j = 0; j < l; j++) { w.s[j] = std::max(w.s[j], as); w.z[j] = std::max(w.z[j], az); }
+        int cs = l;
+        for (const Cone &sc : cones) {
+            double ts = 0, tz = 0;
+            for (int k = 1; k < sc.dim; k++) { ts += w.s[cs + k] * w.s[cs + k]; tz += w.z[cs + k] * w.z[cs + k]; }
+            w.s[cs] = std::max(w.s[cs], std::sqrt(ts) + as); w.z[cs] = std::max(w.z[cs], std::sqrt(tz) + az);
+            cs += sc.dim;
+        }
+    }
+
     /* ---------- ref solve src/eicos.cpp:848-1262 ---------- */
     int solve() {
         int code = EX_FATAL;
@@ -786,9 +809,13 @@ struct Solver {
         std::fill(rhs2.begin(), rhs2.end(), 0.0);
         for (int j = 0; j < n; j++) rhs2[j] = -c[j];
         resx0 = std::max(1., norm2(c)); resy0 = std::max(1., norm2(b)); resz0 = std::max(1., norm2(h));
+        vec dx1(n), dy1(p), dz1(m), dx2(n), dy2(p), dz2(m), neg(m);
+        if (warm_shift > 0. && have_prev && (last_exit == EX_OPTIMAL || last_exit == EX_OPTIMAL + EX_INACC)) {
+            warm_init();
+            w.i.nitref1 = 0; w.i.nitref2 = 0;
+        } else {
         n_factor++;
         if (!ldl.factorize(K.val)) return last_exit = EX_FATAL; /* ref :900-905 */
-        vec dx1(n), dy1(p), dz1(m), dx2(n), dy2(p), dz2(m), neg(m);
         w.i.nitref1 = solve_kkt(rhs1, dx1, dy1, dz1, true);
         w.x = dx1;
         for (int i = 0; i < m; i++) neg[i] = -dz1[i];
@@ -796,6 +823,7 @@ struct Solver {
         w.i.nitref2 = solve_kkt(rhs2, dx2, dy2, dz2, true);
         w.y = dy2;
         bring_to_cone(dz2, w.z);
+        }
         for (int j = 0; j < n; j++) rhs1[j] = -c[j];
         w.kap = 1.; w.tau = 1.;
         w.i.step = 0.; w.i.step_aff = 0.; w.i.pinf = false; w.i.dinf = false;
@@ -876,6 +904,7 @@ struct Solver {
             w.tau += w.i.step * dtau;
         }
         backscale();
+        px = w.x; py = w.y; pz = w.z; ps = w.s; have_prev = true;
         return last_exit = code;
     }
 };
@@ -925,6 +954,7 @@ int oracle_get_trace(void *s, double *out, int max_rows) {
     for (int r = 0; r < rows; r++) std::copy(S->history[r].begin(), S->history[r].end(), out + 12 * r);
     return (int)S->history.size();
 }
+void oracle_set_warm_start(void *s, double shift) { static_cast<Solver *>(s)->warm_shift = shift; }
 void oracle_destroy(void *s) { delete static_cast<Solver *>(s); }
 
 double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,

@@ -46,6 +46,8 @@ void oracle_get_dims(void *s, int *dimK, int *nnzK, int *nnzL);
 /* per-iteration history of the last solve: rows of {pcost,dcost,gap,pres,dres,kap/tau,mu,step,sigma,tau,kap,nitref3};
  * returns the number of rows available */
 int oracle_get_trace(void *s, double *out, int max_rows);
+/* N3 (not in the reference): shift > 0 enables the warm start described at Solver::warm_init; 0 = cold start */
+void oracle_set_warm_start(void *s, double shift);
 void oracle_destroy(void *s);
 
 /* CPU-baseline driver: solve `batch` instances that share one pattern, one instance at a

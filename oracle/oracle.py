@@ -49,6 +49,7 @@ def lib():
         L.oracle_get_yzs.argtypes = [C.c_void_p, dp, dp, dp]
         L.oracle_get_dims.argtypes = [C.c_void_p, ip, ip, ip]
         L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_warm_start.argtypes = [C.c_void_p, C.c_double]
         L.oracle_get_trace.argtypes = [C.c_void_p, dp, C.c_int]
         L.oracle_get_trace.restype = C.c_int
         L.oracle_batch_solve.restype = C.c_double
@@ -112,6 +113,9 @@ class OracleSolver:
         y, z, s = np.zeros(max(self.pat.p, 1)), np.zeros(max(self.pat.m, 1)), np.zeros(max(self.pat.m, 1))
         lib().oracle_get_yzs(self._h, _dp(y), _dp(z), _dp(s))
         return y[: self.pat.p], z[: self.pat.m], s[: self.pat.m]
+
+    def set_warm_start(self, shift: float):
+        lib().oracle_set_warm_start(self._h, float(shift))
 
     def trace(self):
         out = np.zeros((102, 12))

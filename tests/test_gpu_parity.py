@@ -378,3 +378,49 @@ def test_large_pattern_uses_slab_vectors_and_32bit_indices():
     assert g.dims()["lds_bytes"] == 0 and g.dims()["dim_K"] > 65535
     g.close()
     _check_batch(pat, feasible_batch(pat, base, 0, 2, seed=5), 2, 1, x_rtol=1e-7)
+
+
+@pytest.mark.parametrize("soc", [False, True])
+def test_warm_start_matches_oracle_and_saves_iterations(soc):
+    # N3 (extension, off by default): after updateData with slightly different data the solve starts from the previous
+    # solution.  Same rule in the oracle -> same iteration counts and optimum; fewer iterations than the cold start.
+    pat, sets = load_fixture("MPC02")
+    if soc:
+        pat = mpc_soc_variant(pat, sets[0])
+    B = 4
+    d = feasible_batch(pat, sets[0], 0, B, seed=3)
+    rng = np.random.default_rng(0)
+    d2 = dict(d)
+    d2["c"] = d["c"] * (1 + 0.01 * rng.uniform(-1, 1, d["c"].shape))
+    d2["h"] = d["h"] + 0.01 * (1 + np.abs(d["h"])) * rng.uniform(0, 1, d["h"].shape)
+    g = eicos_amd.BatchSolver(pat, B)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    assert np.all(g.solve() == 0)
+    cold_first = g.info_arrays()["iter"].copy()
+    g.update(d2["Gpr"], d2["Apr"], d2["c"], d2["h"], d2["b"])
+    assert np.all(g.solve() == 0)
+    cold = g.info_arrays()["iter"].copy(); pc_cold = g.info_arrays()["pcost"].copy()
+    # again, warm: solve the first data set, switch the option on, update, solve
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"]); g.solve()
+    g.set_warm_start(0.1)
+    g.update(d2["Gpr"], d2["Apr"], d2["c"], d2["h"], d2["b"])
+    assert np.all(g.solve() == 0)
+    ia = g.info_arrays(); x = g.solution()
+    assert np.all(ia["iter"] < cold) and np.all(ia["nitref1"] == 0)
+    assert np.all(np.abs(ia["pcost"] - pc_cold) <= 1e-7 * np.maximum(1, np.abs(pc_cold)))
+    for i in range(B):
+        o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+        o.set_warm_start(0.1)
+        assert o.solve() == 0 and o.info()["iter"] == cold_first[i]
+        o.update(Values(d2["Gpr"][i], d2["Apr"][i], d2["c"][i], d2["h"][i], d2["b"][i]))
+        assert o.solve() == 0
+        assert abs(o.info()["iter"] - ia["iter"][i]) <= 1, (i, o.info()["iter"], ia["iter"][i])
+        assert abs(o.info()["pcost"] - ia["pcost"][i]) <= 1e-8 * max(1.0, abs(o.info()["pcost"]))
+        if o.info()["iter"] == ia["iter"][i]:
+            assert np.abs(x[i] - o.x()).max() <= 1e-7 * max(1.0, np.abs(o.x()).max())
+        o.close()
+    # switching it off again restores the cold start bit for bit
+    g.set_warm_start(0.0)
+    g.update(d2["Gpr"], d2["Apr"], d2["c"], d2["h"], d2["b"]); g.solve()
+    assert np.array_equal(g.info_arrays()["iter"], cold)
+    g.close()
