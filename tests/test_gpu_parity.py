@@ -424,3 +424,24 @@ def test_warm_start_matches_oracle_and_saves_iterations(soc):
     g.update(d2["Gpr"], d2["Apr"], d2["c"], d2["h"], d2["b"]); g.solve()
     assert np.array_equal(g.info_arrays()["iter"], cold)
     g.close()
+
+
+def test_bench_emits_the_contract_json_line():
+    # bench.py's one-line JSON: metric/unit of BASELINE.json, roofline and cpu_baseline objects, whole-job value
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "ipm_iterations_per_sec" and d["unit"] == "iter/s" and d["dtype"] == "f64" and d["n_gpus"] == 1
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["optimal"] == 64
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["iters_match_gpu"] is True
+    assert abs(d["value"] - d["config"]["mean_iter"] * 64 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
