@@ -266,8 +266,18 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     const std::vector<int> cag_k_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_k, S.N), cag_yz_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_yz, 0);
     const std::vector<int> rA_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx, 0), rA_k_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx_k, S.N);
     const std::vector<int> rG_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx, 0), rG_k_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx_k, S.N);
+    // factor program: the (pa, pb) slot pairs of a lane, 16 bytes per lane and slice (pa words then pb words)
+    const std::vector<int> x_o16 = lane_offsets(planX.sl, D.fac_d16);
+    std::vector<int> fac_w16;
+    {
+        const std::vector<int> wa = pack16(planX.sl, x_o16, D.fac_d16, planX.pa, planB.slots), wb = pack16(planX.sl, x_o16, D.fac_d16, planX.pb, planF.slots);
+        fac_w16.resize(wa.size() * 2);
+        for (size_t e = 0; e * 2 < wa.size(); e++) {
+            fac_w16[4 * e] = wa[2 * e]; fac_w16[4 * e + 1] = wa[2 * e + 1]; fac_w16[4 * e + 2] = wb[2 * e]; fac_w16[4 * e + 3] = wb[2 * e + 1];
+        }
+    }
     D.idx16 = (idx16_ok && env_int("EICOS_IDX16", 1)) ? 1 : 0;
-    std::vector<int> fsl_i = meta_ints(planF.sl, f_o16), bsl_i = meta_ints(planB.sl, b_o16), fac_sl_i = meta_ints(planX.sl, {});
+    std::vector<int> fsl_i = meta_ints(planF.sl, f_o16), bsl_i = meta_ints(planB.sl, b_o16), fac_sl_i = meta_ints(planX.sl, x_o16);
     std::vector<int> cag_sl_i = meta_ints(pcag.sl, cag_o16), rA_sl_i = meta_ints(prA.sl, rA_o16), rG_sl_i = meta_ints(prG.sl, rG_o16);
 
     struct Slot { const int **dst; size_t off; };
@@ -298,7 +308,7 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(D.v2t, v2t);
     const int *fac_sl_p = nullptr;
     put(fac_sl_p, fac_sl_i);
-    put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb);
+    put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb); put(D.fac_p16, fac_w16);
     put(D.fac_src, fac_src); put(D.fac_dst, fac_dst); put(D.fac_dstF, fac_dstF); put(D.fac_col, fac_col);
 
     // ---- device resources ----

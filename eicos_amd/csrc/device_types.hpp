@@ -107,6 +107,7 @@ struct DevPat {
     int w_Kt;                      // [fac_nt] KKT entry of every target, in target order (workspace slab)
     gint_p v2t;                    // [nV] scaling-block entry -> its target
     gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;
+    gint_p fac_p16; int fac_d16; // idx16: per lane and slice the four (pa, pb) pairs as eight 16-bit slot numbers (16 bytes)
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets

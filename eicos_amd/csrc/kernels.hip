@@ -533,7 +533,7 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
     (void)n; (void)p; (void)m; (void)l; (void)N; (void)np; (void)lane; (void)wave; (void)phase; (void)wi;
 
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
-template <int T, int NLDS>
+template <int T, int NLDS, bool I16>
 __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
@@ -562,10 +562,16 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
         o.more = nm.more; o.cont = nm.cont;
         o.lanes = o.cnt << o.lg;
         const bool act = tid < o.lanes;
+        if constexpr (I16) { // the lane's four (pa, pb) pairs packed as eight 16-bit slot numbers: one 16-byte load
+            const uint4 w = reinterpret_cast<const uint4 EICOS_GLOBAL *>(P.fac_p16)[act ? nm.off16 + tid : P.fac_d16];
+            o.ia[0] = w.x & 0xffffu; o.ia[1] = w.x >> 16; o.ia[2] = w.y & 0xffffu; o.ia[3] = w.y >> 16;
+            o.ib[0] = w.z & 0xffffu; o.ib[1] = w.z >> 16; o.ib[2] = w.w & 0xffffu; o.ib[3] = w.w >> 16;
+        } else {
 #pragma unroll
-        for (int u = 0; u < ELL_KMAX; u++) {
-            const int slot = (act && u < o.K) ? o.off + u * o.lanes + tid : P.fac_slots; // dummy pair: 0 * 0
-            o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot];
+            for (int u = 0; u < ELL_KMAX; u++) {
+                const int slot = (act && u < o.K) ? o.off + u * o.lanes + tid : P.fac_slots; // dummy pair: 0 * 0
+                o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot];
+            }
         }
         const int t = act ? o.row0 + (tid >> o.lg) : 0;
         o.kv = Kt[t];
@@ -1235,7 +1241,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         stage = ST_RESID; iter = 0;
     }
     while (stage != ST_DONE) {
-        if (stage == ST_FACTOR) stage = stage_factor<T, NLDS>(ps, I, W, iter);
+        if (stage == ST_FACTOR) stage = stage_factor<T, NLDS, I16>(ps, I, W, iter);
         else if (stage == ST_RESID) stage = stage_resid<T, NLDS, I16>(ps, I, W, iter);
         else {
             const int prev = stage;
@@ -1404,7 +1410,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
     for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
     __syncthreads();
-    stage_factor<T, 0>(ps, I, (gdbl_p)work, -1);
+    stage_factor<T, 0, false>(ps, I, (gdbl_p)work, -1);
 }
 
 // ---- launchers (called from api.cpp) ----
