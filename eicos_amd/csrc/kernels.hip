@@ -83,6 +83,15 @@ extern __shared__ double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | sli
 // so move them to SGPRs: address math and branches on them become scalar (s_load, s_cbranch) instead
 // of per-lane loads and exec-masked regions.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Element `i` of a workgroup-uniform global array through a 32-bit byte offset: the address is SGPR base + VGPR
+// offset (global_load ... v_off, s[base:base+1]), one shift instead of a sign extension + 64-bit shift-add per
+// load.  Every array addressed this way is smaller than 4 GB.
+template <class E> __device__ __forceinline__ E ld_u32(const E EICOS_GLOBAL *base, int i) {
+    return *reinterpret_cast<const E EICOS_GLOBAL *>(reinterpret_cast<const char EICOS_GLOBAL *>(base) + (unsigned)i * (unsigned)sizeof(E));
+}
+template <class E> __device__ __forceinline__ E ld_u32_nt(const E EICOS_GLOBAL *base, int i) {
+    return __builtin_nontemporal_load(reinterpret_cast<const E EICOS_GLOBAL *>(reinterpret_cast<const char EICOS_GLOBAL *>(base) + (unsigned)i * (unsigned)sizeof(E)));
+}
 template <class Ptr> __device__ __forceinline__ Ptr uni_ptr(Ptr p) {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -206,11 +215,11 @@ typedef const uint2 EICOS_GLOBAL *gidx16_p;
 template <bool I16> __device__ __forceinline__ void load_indices(int (&ni)[ELL_KMAX], gint_p eidx, gint_p eidx16, bool act, int K, int off,
                                                                  int lanes, int t, int dummy_slot, int off16, int d16) {
     if constexpr (I16) {
-        const uint2 w = reinterpret_cast<gidx16_p>(eidx16)[act ? off16 + t : d16];
+        const uint2 w = ld_u32(reinterpret_cast<gidx16_p>(eidx16), act ? off16 + t : d16);
         ni[0] = w.x & 0xffffu; ni[1] = w.x >> 16; ni[2] = w.y & 0xffffu; ni[3] = w.y >> 16;
     } else {
 #pragma unroll
-        for (int kk = 0; kk < ELL_KMAX; kk++) ni[kk] = eidx[(act && kk < K) ? off + kk * lanes + t : dummy_slot];
+        for (int kk = 0; kk < ELL_KMAX; kk++) ni[kk] = ld_u32(eidx, (act && kk < K) ? off + kk * lanes + t : dummy_slot);
     }
 }
 
@@ -233,7 +242,7 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
-            nv[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per pass: keep the shared index arrays in L2
+            nv[kk] = ld_u32_nt(eval, slot); // streamed once per pass: keep the shared index arrays in L2
         }
         nr = pre(act ? nm.row0 + (t >> nm.lg) : 0);
     };
@@ -307,10 +316,10 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
-            o.val[kk] = __builtin_nontemporal_load(&eval[slot]); // streamed once per sweep: do not displace the index arrays in L2
+            o.val[kk] = ld_u32_nt(eval, slot); // streamed once per sweep: do not displace the index arrays in L2
         }
         const int r = act ? o.row0 + (t >> o.lg) : 0;
-        o.d = FORWARD ? 0. : invD[r]; // forward is L y = b with unit-lower L: no pivot needed
+        o.d = FORWARD ? 0. : ld_u32(invD, r); // forward is L y = b with unit-lower L: no pivot needed
         o.own = ws[r]; // rows of later slices are not written before their own slice runs
     };
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
@@ -563,7 +572,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
         o.lanes = o.cnt << o.lg;
         const bool act = tid < o.lanes;
         if constexpr (I16) { // the lane's four (pa, pb) pairs packed as eight 16-bit slot numbers: one 16-byte load
-            const uint4 w = reinterpret_cast<const uint4 EICOS_GLOBAL *>(P.fac_p16)[act ? nm.off16 + tid : P.fac_d16];
+            const uint4 w = ld_u32(reinterpret_cast<const uint4 EICOS_GLOBAL *>(P.fac_p16), act ? nm.off16 + tid : P.fac_d16);
             o.ia[0] = w.x & 0xffffu; o.ia[1] = w.x >> 16; o.ia[2] = w.y & 0xffffu; o.ia[3] = w.y >> 16;
             o.ib[0] = w.z & 0xffffu; o.ib[1] = w.z >> 16; o.ib[2] = w.w & 0xffffu; o.ib[3] = w.w >> 16;
         } else {
@@ -574,8 +583,8 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             }
         }
         const int t = act ? o.row0 + (tid >> o.lg) : 0;
-        o.kv = Kt[t];
-        o.dst = P.fac_dst[t];
+        o.kv = ld_u32(Kt, t);
+        o.dst = ld_u32(P.fac_dst, t);
     };
 #pragma unroll
     for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(d, ns - 1)), q[d]);
@@ -598,7 +607,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             // issued before this slice's arithmetic waits on its own (one L2 round trip per level, not per slice)
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = U[c.ia[u]]; gl[u] = UF[c.ib[u]]; }
+                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = ld_u32((gcdbl_p)U, c.ia[u]); gl[u] = ld_u32((gcdbl_p)UF, c.ib[u]); }
             }
             double cu[ELL_KMAX], cl[ELL_KMAX];
 #pragma unroll
@@ -607,7 +616,7 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             if (have) {
                 const FSlot &nx = q[(d + 1) % FAC_DEPTH];
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = U[nx.ia[u]]; gl[u] = UF[nx.ib[u]]; }
+                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = ld_u32((gcdbl_p)U, nx.ia[u]); gl[u] = ld_u32((gcdbl_p)UF, nx.ib[u]); }
             }
             double acc = 0.;
 #pragma unroll
