@@ -108,13 +108,15 @@ template <int CTRL> __device__ __forceinline__ double dpp_shl_add(double v) {
     return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 __device__ __forceinline__ double grp_reduce_to_lane0(double v, int lg) { // lg is wavefront-uniform
-    if (lg >= 6) v += __shfl_xor(v, 32, 64);
-    if (lg >= 5) v += __shfl_xor(v, 16, 64);
-    if (lg >= 4) v = dpp_shl_add<0x108>(v); // row_shl:8
-    if (lg >= 3) v = dpp_shl_add<0x104>(v); // row_shl:4
+    if (lg == 0) return v; // one lane per row (most slices): one scalar branch instead of the six of the ladder
+    if (lg >= 3) {
+        if (lg >= 6) v += __shfl_xor(v, 32, 64);
+        if (lg >= 5) v += __shfl_xor(v, 16, 64);
+        if (lg >= 4) v = dpp_shl_add<0x108>(v); // row_shl:8
+        v = dpp_shl_add<0x104>(v);              // row_shl:4
+    }
     if (lg >= 2) v = dpp_shl_add<0x102>(v); // row_shl:2
-    if (lg >= 1) v = dpp_shl_add<0x101>(v); // row_shl:1
-    return v;
+    return dpp_shl_add<0x101>(v);           // row_shl:1
 }
 
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
@@ -950,20 +952,20 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
             double nex = 0., ney = 0., nez = 0.;
             struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
-            ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots, [&](int j) { return PreK{bx[j], 0., P.ipx[j], 0}; },
+            ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots, [&](int j) { return PreK{ld_u32(bx, j), 0., ld_u32(P.ipx, j), 0}; },
                         [&](int j, double s, const PreK &pr) {
                 const int o = pr.o;
                 const double e = pr.b - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
                 E[o] = e; nex = fmax(nex, fabs(e));
             });
-            ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots, [&](int r) { return PreK{by[r], 0., P.ipy[r], 0}; },
+            ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots, [&](int r) { return PreK{ld_u32(by, r), 0., ld_u32(P.ipy, r), 0}; },
                         [&](int r, double s, const PreK &pr) {
                 const int o = pr.o;
                 const double e = pr.b - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
                 E[o] = e; ney = fmax(ney, fabs(e));
             });
             ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
-                        [&](int i) { return PreK{bz[i], lpv[i < l ? i : 0], P.ipz[i], (int)P.zdsign[i]}; },
+                        [&](int i) { return PreK{ld_u32(bz, i), ld_u32((gcdbl_p)lpv, i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i)}; },
                         [&](int i, double s, const PreK &pr) {
                 const int o = pr.o;
                 const double xo = X[o];
