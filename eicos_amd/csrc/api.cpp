@@ -132,7 +132,9 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         const int dimK = n + p + m + 2 * ncones;
         int n_cu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device < 0 ? 0 : device) == hipSuccess) n_cu = pr.multiProcessorCount; }
-        const int dflt = dimK < 400 ? 128 : ((dimK < 2000 || batch > n_cu) ? 256 : 512);
+        // (sparse factors only: with ~50 entries per row of L -- the dense-front config -- 512 threads stay ahead)
+        const bool throughput_bound = batch > n_cu && (long long)S.nnzL < 16LL * S.N;
+        const int dflt = dimK < 400 ? 128 : ((dimK < 2000 || throughput_bound) ? 256 : 512);
         const int t = env_int("EICOS_THREADS", dflt);
         h->threads = (t == 128 || t == 256 || t == 512) ? t : dflt;
     }
