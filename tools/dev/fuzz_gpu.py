@@ -1,0 +1,67 @@
+"""Dev script (GPU): randomized differential campaign GPU vs oracle over random sparse SOCP patterns and kernel
+variants.  usage: python tools/dev/fuzz_gpu.py [n_cases] [seed0]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import eicos_amd
+from eicos_amd.generate import feasible_batch, random_socp_pattern
+from eicos_amd.problem_io import Values
+from oracle.oracle import OracleSolver
+
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+t0 = time.time()
+for case in range(ncase):
+    rng = np.random.default_rng(seed0 + case)
+    scale = int(os.environ.get("FUZZ_SCALE", "1"))
+    n = int(rng.integers(2, 70 * scale))
+    p = int(rng.integers(0, max(1, n // 2)))
+    l = int(rng.integers(0, 50 * scale))
+    nc = int(rng.integers(0, 5 * scale))
+    q = [int(rng.choice([1, 2, 3, 4, 7, 12, 33, 40])) for _ in range(nc)]
+    if l + sum(q) == 0:
+        l = 3
+    dens = float(rng.choice([0.05, 0.15, 0.3, 0.6])) / scale
+    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16"):
+        os.environ.pop(k, None)
+    var = {}
+    if rng.random() < 0.7:
+        var["EICOS_THREADS"] = str(rng.choice([128, 256, 512]))
+    if rng.random() < 0.7:
+        var["EICOS_NLDS"] = str(rng.choice([0, 1, 2]))
+    if rng.random() < 0.3:
+        var["EICOS_IDX16"] = "0"
+    os.environ.update(var)
+    try:
+        pat, base = random_socp_pattern(n, p, l, q, density=dens, seed=seed0 + case)
+        B = 3
+        d = feasible_batch(pat, base, 0, B, seed=seed0 + case)
+        g = eicos_amd.BatchSolver(pat, B)
+        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+        codes = g.solve(); ia = g.info_arrays(); x = g.solution()
+        msg = []
+        for i in range(B):
+            o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+            oc = o.solve(); oi = o.info()
+            if codes[i] != oc:
+                # -7 = exactly cancelling pivot in ONE of the two elimination orders (static regularisation only,
+                # as in the reference): ordering-dependent by nature, reported separately
+                tag = "ORDERING-DEPENDENT FATAL " if -7 in (codes[i], oc) else ""
+                msg.append(f"{tag}inst {i}: exit {codes[i]} vs oracle {oc}")
+            elif oc in (0, 10):
+                if abs(ia["iter"][i] - oi["iter"]) > 1:
+                    msg.append(f"inst {i}: iter {ia['iter'][i]} vs {oi['iter']}")
+                if abs(ia["pcost"][i] - oi["pcost"]) > 1e-7 * max(1, abs(oi["pcost"])):
+                    msg.append(f"inst {i}: pcost {ia['pcost'][i]} vs {oi['pcost']}")
+                if ia["iter"][i] == oi["iter"] and np.abs(x[i] - o.x()).max() > 1e-5 * max(1, np.abs(o.x()).max()):
+                    msg.append(f"inst {i}: x differs by {np.abs(x[i] - o.x()).max():.2e}")
+            o.close()
+        g.close()
+    except Exception as e:  # noqa: BLE001
+        msg = [f"exception {type(e).__name__}: {e}"]
+    if msg:
+        bad += 1
+        print(f"case {seed0 + case}: n={n} p={p} l={l} q={q} dens={dens} {var}: " + "; ".join(msg), flush=True)
+print(f"{ncase} cases, {bad} with differences, {time.time() - t0:.0f}s")
