@@ -80,6 +80,8 @@ def _lib():
         L.eicos_batch_set_stream.argtypes = [vp, vp]
         L.eicos_batch_set_warm_start.argtypes = [vp, C.c_double]
         L.eicos_batch_set_warm_start.restype = C.c_int
+        L.eicos_batch_set_dynamic_regularization.argtypes = [vp, C.c_double, C.c_double]
+        L.eicos_batch_set_dynamic_regularization.restype = C.c_int
         L.eicos_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_last_update_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_destroy.argtypes = [vp]
@@ -167,6 +169,10 @@ class BatchSolver:
     def set_warm_start(self, shift: float):
         """shift > 0: re-solves start from the previous solution (not in the reference; see include/eicos_amd.h)."""
         _chk(_lib().eicos_batch_set_warm_start(self._h, float(shift)))
+
+    def set_dynamic_regularization(self, delta: float, eps: float):
+        """delta > 0: ECOS-style dynamic regularisation of the LDL' pivots (not in the reference)."""
+        _chk(_lib().eicos_batch_set_dynamic_regularization(self._h, float(delta), float(eps)))
 
     def set_stream(self, stream_ptr: int):
         _chk(_lib().eicos_batch_set_stream(self._h, C.c_void_p(int(stream_ptr) or None)))

@@ -45,6 +45,7 @@ struct eicos_batch {
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     int *d_queue = nullptr; // instance queue of the solve kernel (reset per launch)
     double warm_shift = 0.; // > 0: warm start (eicos_batch_set_warm_start)
+    double dyn_delta = 0., dyn_eps = 0.; // > 0: dynamic regularisation (eicos_batch_set_dynamic_regularization)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
     bool solve_timed = false, update_timed = false;
@@ -299,9 +300,18 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     put(D.rA_idx, rA_idx); put(D.rA_src, rA_src); put(D.rG_idx, rG_idx); put(D.rG_src, rG_src);
     put(D.rA_idx_k, rA_idx_k); put(D.rG_idx_k, rG_idx_k);
     put(D.ipx, ipx); put(D.ipy, ipy); put(D.ipz, ipz); put(D.ipv, ipv); put(D.ipu, ipu);
+    // quasi-definite sign of pivot `pos` (elimination position): + for the x block and the u expansion of every cone
+    // (ref setupKKT :1734-1890), - elsewhere; only used by the dynamic-regularisation extension
+    auto pivot_positive = [&](int pos) {
+        const int orig = S.perm[pos];
+        if (orig < S.n) return true;
+        int k = S.n + S.p + S.l;
+        for (int c = 0; c < S.nc; c++) { if (orig == k + S.q[c] + 1) return true; k += S.q[c] + 2; }
+        return false;
+    };
     for (size_t t = 0; t < planX.target.size(); t++) {
         const int tgt = planX.target[t];
-        if (tgt < S.N) { fac_src[t] = srcoff(S.Dkind[tgt], S.Dsrc[tgt]); fac_dst[t] = -tgt - 1; fac_dstF[t] = 0; }
+        if (tgt < S.N) { fac_src[t] = srcoff(S.Dkind[tgt], S.Dsrc[tgt]); fac_dst[t] = -tgt - 1 - (pivot_positive(tgt) ? DIAG_POS : 0); fac_dstF[t] = 0; }
         else { const int e = tgt - S.N; fac_src[t] = srcoff(S.Lkind[e], S.Lsrc[e]); fac_dst[t] = planB.pos[e]; fac_dstF[t] = planF.pos[e]; fac_col[t] = col_of[e]; }
     }
     std::vector<int> v2t(std::max(S.nV, 1), D.fac_nt); // entries that are no target (none by construction) -> spare slot
@@ -453,6 +463,12 @@ int eicos_batch_set_warm_start(eicos_batch *h, double shift) {
     return EICOS_OK;
 }
 
+int eicos_batch_set_dynamic_regularization(eicos_batch *h, double delta, double eps) {
+    if (!h || !(delta >= 0.) || !(eps >= 0.)) return fail(EICOS_E_INVALID, "bad argument");
+    h->dyn_delta = delta; h->dyn_eps = eps;
+    return EICOS_OK;
+}
+
 int eicos_batch_set_stream(eicos_batch *h, void *hip_stream) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
@@ -512,7 +528,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, h->warm_shift, h->dyn_lds, h->stream));
+    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;

@@ -39,6 +39,7 @@ constexpr int DEVINFO_DOUBLES = 32;
 // over the same rows: `more` = another sub-slice of these rows follows, `cont` = this one continues the previous.
 struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; }; // host form (plan building, host emulation)
 constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
+constexpr int DIAG_POS = 1 << 30; // factor program, diagonal targets: dst = -(j + 1) - (pivot sign is + ? DIAG_POS : 0)
 
 // Device form of a slice: 16 bytes = one ds_read_b128 / s_load_dwordx4.  off16 = index of the slice's first lane
 // in the plan's packed 16-bit gather-index array (one 8-byte entry = ELL_KMAX indices per lane), see api.cpp.

@@ -68,6 +68,7 @@ struct Sh {
     double red[2 * RED_SLOTS];
     DevInfo wi, bi;
     double sv[SV_COUNT];
+    double dyn_delta, dyn_eps; // dynamic regularisation of the pivots (extension; 0 = off), set by k_solve
     int fl[FL_COUNT];
     int next; // next instance of this workgroup (k_solve's queue)
     unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
@@ -627,9 +628,14 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             if (c.cont) acc += carry;
             if (c.more) carry = acc;
             else if (act && (tid & ((1 << c.lg) - 1)) == 0) {
-                const double val = c.kv - acc;
-                if (c.dst < 0) {
-                    D[-c.dst - 1] = val; invD[-c.dst - 1] = 1. / val;
+                double val = c.kv - acc;
+                if (c.dst < 0) { // diagonal target: -(j+1), plus DIAG_POS when the quasi-definite sign of pivot j is +
+                    const int e = -c.dst - 1, j = e & (DIAG_POS - 1);
+                    if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
+                        const double sg = (e & DIAG_POS) ? 1. : -1.;
+                        if (sg * val <= g_S.dyn_eps) val = sg * g_S.dyn_delta;
+                    }
+                    D[j] = val; invD[j] = 1. / val;
                     if (val == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
                 } else U[c.dst] = val;
             }
@@ -1275,7 +1281,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
 
 template <int T, int NLDS, bool I16>
 __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
-    int ps, double *inst, double *work, int B, int *queue, const int *order, double warm) {
+    int ps, double *inst, double *work, int B, int *queue, const int *order, double warm, double dyn_delta, double dyn_eps) {
     const DevPat &P = c_pat[ps];
     gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
@@ -1289,6 +1295,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
         if (P.lm_fac >= 0) stage(P.fac_sl, P.fac_ns, P.lm_fac);
         __syncthreads();
     }
+    if (threadIdx.x == 0) { g_S.dyn_delta = dyn_delta; g_S.dyn_eps = dyn_eps; }
     // Instances differ in iteration count (12..18 on the headline batch): after its first instance (= its own
     // index, so that workspace slot i holds the history of instance i when the batch fits the grid) a workgroup
     // pulls the next unsolved instance from a queue instead of striding through the batch.
@@ -1417,7 +1424,7 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
 template <int T>
 __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, double *inst, double *work, int i) {
     const DevPat &P = c_pat[ps];
-    if (threadIdx.x == 0) { g_S.fl[FL_FATAL] = 0; g_S.wi.n_factor = 0; for (int k = 0; k < 12; k++) g_S.tick[k] = 0; }
+    if (threadIdx.x == 0) { g_S.fl[FL_FATAL] = 0; g_S.wi.n_factor = 0; g_S.dyn_delta = 0.; g_S.dyn_eps = 0.; for (int k = 0; k < 12; k++) g_S.tick[k] = 0; }
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
     for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
     __syncthreads();
@@ -1442,7 +1449,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
     return byT(std::integral_constant<int, 256>{});
 }
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        int idx16, double warm, size_t dyn_lds, hipStream_t st) {
+                        int idx16, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // instance queue of this launch
     if (e != hipSuccess) return e;
@@ -1452,7 +1459,8 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
-        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order, (void *)&warm};
+        void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order, (void *)&warm, (void *)&dyn_delta,
+                        (void *)&dyn_eps};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
 }

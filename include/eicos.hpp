@@ -126,6 +126,11 @@ namespace EiCOS
         }
         // Extension (not in the reference): re-solves start from the previous solution, see eicos_amd.h
         void setWarmStart(double shift) { detail::check(eicos_batch_set_warm_start(h_, shift), "eicos_batch_set_warm_start"); }
+        // Extension: ECOS-style dynamic regularisation (the reference's Settings::delta / ::eps are never read)
+        void setDynamicRegularization(double delta, double eps)
+        {
+            detail::check(eicos_batch_set_dynamic_regularization(h_, delta, eps), "eicos_batch_set_dynamic_regularization");
+        }
         std::vector<exitcode> solve()
         {
             std::vector<int> codes(batch_);
@@ -235,6 +240,7 @@ namespace EiCOS
         const Information &getInfo() const { return info_; }
         // Extension (not in the reference, which cold-starts every solve): warm-start the next solves after updateData
         void setWarmStart(double shift) { eicos_batch_set_warm_start(h_, shift); }
+        void setDynamicRegularization(double delta, double eps) { eicos_batch_set_dynamic_regularization(h_, delta, eps); }
 
     private:
         eicos_batch *h_ = nullptr;

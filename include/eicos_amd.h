@@ -110,6 +110,13 @@ int eicos_batch_solution_device(eicos_batch *hd, const double **dx, size_t *stri
  * 0.1 is a good value for MPC re-solves (1 % data perturbation: 13-15 -> 8-10 iterations). */
 int eicos_batch_set_warm_start(eicos_batch *hd, double shift);
 
+/* ---- dynamic regularisation (N4 of SURVEY.md 8f; NOT in the reference, whose Settings::delta / ::eps are dead,
+ * include/eicos.hpp:26,28).  delta > 0: during the numeric LDL' a pivot whose sign disagrees with the quasi-definite
+ * sign pattern of the KKT matrix, or whose magnitude is below eps, is replaced by sign * delta (ECOS: delta = 2e-7,
+ * eps = 1e-13).  delta = 0 (default): static regularisation only, an exactly zero pivot ends the solve with
+ * EICOS_FATAL as in the reference (src/eicos.cpp:1166-1170). */
+int eicos_batch_set_dynamic_regularization(eicos_batch *hd, double delta, double eps);
+
 /* ---- plumbing */
 int eicos_batch_dims(eicos_batch *hd, eicos_dims *out);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the own stream. */

@@ -98,6 +98,11 @@ struct Ldl {
     ivec parent, Lp, Li, Lnz, flag, pattern;
     vec Lx, D, Y;
     bool ok = false;
+    /* N4 of SURVEY.md 8f (NOT in the reference, whose `delta`/`eps` settings are dead, include/eicos.hpp:26,28; off
+     * by default): ECOS-style dynamic regularisation -- a pivot whose sign disagrees with the quasi-definite sign
+     * pattern, or is smaller than dyn_eps in magnitude, is replaced by sign * dyn_delta.  sign[] is by ORIGINAL index. */
+    double dyn_delta = 0., dyn_eps = 0.;
+    ivec sign;
 
     /* plain minimum-degree ordering on the elimination graph (ties -> lowest index);
      * replaces Eigen's AMD (analyzePattern, ref src/eicos.cpp:897). */
@@ -192,6 +197,7 @@ struct Ldl {
                 dk -= lki * yi;
                 Li[p2] = k; Lx[p2] = lki; Lnz[i]++;
             }
+            if (dyn_delta > 0. && !sign.empty()) { const double sg = sign[perm[k]]; if (sg * dk <= dyn_eps) dk = sg * dyn_delta; }
             D[k] = dk;
             if (dk == 0.0) { ok = false; return false; }
         }
@@ -955,6 +961,16 @@ int oracle_get_trace(void *s, double *out, int max_rows) {
     return (int)S->history.size();
 }
 void oracle_set_warm_start(void *s, double shift) { static_cast<Solver *>(s)->warm_shift = shift; }
+void oracle_set_dynamic_regularization(void *s, double delta, double eps) {
+    Solver *S = static_cast<Solver *>(s);
+    S->ldl.dyn_delta = delta; S->ldl.dyn_eps = eps;
+    /* sign pattern of the KKT matrix (ref setupKKT :1734-1890): +delta block of x, negative y / z blocks, per cone the
+     * q rows and the v expansion are negative, the u expansion is positive */
+    S->ldl.sign.assign(S->N, -1);
+    for (int j = 0; j < S->n; j++) S->ldl.sign[j] = 1;
+    int k = S->n + S->p + S->l;
+    for (const Cone &sc : S->cones) { S->ldl.sign[k + sc.dim + 1] = 1; k += sc.dim + 2; }
+}
 void oracle_destroy(void *s) { delete static_cast<Solver *>(s); }
 
 double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,

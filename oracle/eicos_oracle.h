@@ -48,6 +48,8 @@ void oracle_get_dims(void *s, int *dimK, int *nnzK, int *nnzL);
 int oracle_get_trace(void *s, double *out, int max_rows);
 /* N3 (not in the reference): shift > 0 enables the warm start described at Solver::warm_init; 0 = cold start */
 void oracle_set_warm_start(void *s, double shift);
+/* N4 (not in the reference): ECOS-style dynamic regularisation of the LDL' pivots; delta = 0 switches it off */
+void oracle_set_dynamic_regularization(void *s, double delta, double eps);
 void oracle_destroy(void *s);
 
 /* CPU-baseline driver: solve `batch` instances that share one pattern, one instance at a

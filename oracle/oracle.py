@@ -50,6 +50,7 @@ def lib():
         L.oracle_get_dims.argtypes = [C.c_void_p, ip, ip, ip]
         L.oracle_destroy.argtypes = [C.c_void_p]
         L.oracle_set_warm_start.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_set_dynamic_regularization.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.oracle_get_trace.argtypes = [C.c_void_p, dp, C.c_int]
         L.oracle_get_trace.restype = C.c_int
         L.oracle_batch_solve.restype = C.c_double
@@ -116,6 +117,9 @@ class OracleSolver:
 
     def set_warm_start(self, shift: float):
         lib().oracle_set_warm_start(self._h, float(shift))
+
+    def set_dynamic_regularization(self, delta: float, eps: float):
+        lib().oracle_set_dynamic_regularization(self._h, float(delta), float(eps))
 
     def trace(self):
         out = np.zeros((102, 12))

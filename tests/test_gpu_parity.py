@@ -445,3 +445,31 @@ def test_bench_emits_the_contract_json_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["iters_match_gpu"] is True
     assert abs(d["value"] - d["config"]["mean_iter"] * 64 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+
+
+def test_dynamic_regularisation_extension_matches_oracle():
+    # N4 (extension, off by default): same rule on both sides -> same result on the instance whose pivot cancels in
+    # the oracle's elimination order; and switching it on must not disturb a well-conditioned batch
+    from test_oracle_golden import _fuzz_case
+    pat, d = _fuzz_case(9024)
+    g = eicos_amd.BatchSolver(pat, 3)
+    g.set_dynamic_regularization(2e-7, 1e-13)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve(); ia = g.info_arrays(); x = g.solution()
+    assert np.all(codes == 0)
+    for i in range(3):
+        o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+        o.set_dynamic_regularization(2e-7, 1e-13)
+        assert o.solve() == 0
+        assert abs(o.info()["iter"] - ia["iter"][i]) <= 1
+        assert abs(o.info()["pcost"] - ia["pcost"][i]) <= 1e-7 * max(1.0, abs(o.info()["pcost"]))
+        o.close()
+    g.close()
+    pat, sets = load_fixture("MPC02")
+    dd = feasible_batch(pat, sets[0], 0, 8)
+    g = eicos_amd.BatchSolver(pat, 8)
+    g.update(dd["Gpr"], dd["Apr"], dd["c"], dd["h"], dd["b"]); g.solve()
+    x0 = g.solution().copy(); it0 = g.info_arrays()["iter"].copy()
+    g.set_dynamic_regularization(2e-7, 1e-13); g.solve()
+    assert np.array_equal(g.info_arrays()["iter"], it0) and np.abs(g.solution() - x0).max() <= 1e-9 * np.abs(x0).max()
+    g.close()
