@@ -39,11 +39,15 @@ for case in range(ncase):
         B = 3
         d = feasible_batch(pat, base, 0, B, seed=seed0 + case)
         g = eicos_amd.BatchSolver(pat, B)
+        if os.environ.get("FUZZ_DYNREG"):
+            g.set_dynamic_regularization(2e-7, 1e-13)
         g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
         codes = g.solve(); ia = g.info_arrays(); x = g.solution()
         msg = []
         for i in range(B):
             o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+            if os.environ.get("FUZZ_DYNREG"):
+                o.set_dynamic_regularization(2e-7, 1e-13)
             oc = o.solve(); oi = o.info()
             if codes[i] != oc:
                 # -7 = exactly cancelling pivot in ONE of the two elimination orders (static regularisation only,
