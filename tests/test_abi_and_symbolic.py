@@ -117,3 +117,27 @@ def test_ecos_header_loader_round_trip(tmp_path):
         eicos_amd.write_epb(e, pat2, sets2)
         pat3, sets3 = eicos_amd.read_problem(e)
         assert np.array_equal(sets3[0].Gpr, sets[0].Gpr) and pat3.nnzA == pat.nnzA
+
+
+def test_product_never_references_the_oracle():
+    # oracle/ is test infrastructure: nothing under eicos_amd/, include/ or examples/ may import, include or link it,
+    # and the shared library must not depend on liboracle.so
+    import os, re, subprocess
+    from conftest import ROOT
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include\s*[\"<].*oracle)", re.M)
+    for top in ("eicos_amd", "include", "examples"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert not pat.search(text), os.path.join(dirpath, f)
+                    if f == "Makefile":
+                        assert "oracle" not in text
+    lib = os.path.join(ROOT, "eicos_amd", "libeicos_amd.so")
+    if os.path.exists(lib):
+        needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+        assert "oracle" not in needed
+    # and the ctypes mirror fails loudly without the HIP library instead of falling back to anything
+    import eicos_amd.binding as b
+    src = open(b.__file__).read()
+    assert "oracle" not in src
