@@ -228,14 +228,26 @@ def main():
             # CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload
             from oracle import oracle as orc
             cores = usable_cores()
-            ns = int(min(B, max(64, 24 * cores)))
-            r = orc.batch_solve(pat, data["Gpr"][:ns], data["Apr"][:ns], data["c"][:ns], data["h"][:ns], data["b"][:ns], cores)
-            wall = r["seconds"] + r["update_seconds"]
-            out["cpu_baseline"] = {"value": float(r["iters"].sum() / wall), "unit": "iter/s", "cores": cores,
-                                   "kind": "port", "sample": f"first {ns} instances of the same batch, one instance per "
-                                   f"thread at a time (updateData+solve), {wall:.2f}s wall",
-                                   "iters_match_gpu": bool(np.array_equal(r["iters"], ia["iter"][:ns])),
-                                   "per_core": float(r["iters"].sum() / wall / cores)}
+            sub = lambda k, a, b: data[k][a:b]
+            run = lambda a, b: orc.batch_solve(pat, sub("Gpr", a, b), sub("Apr", a, b), sub("c", a, b), sub("h", a, b), sub("b", a, b), cores)
+            # bounded sample: a pilot of one instance per core sizes the sample to ~15 s of CPU work (capped at four
+            # passes over the batch), so that small and large patterns are both timed over a comparable span
+            npil = int(min(B, cores))
+            r0 = run(0, npil)
+            per_inst_cpu = (r0["seconds"] + r0["update_seconds"]) * min(cores, npil) / npil
+            want = int(max(npil, min(4 * B, 15.0 / max(per_inst_cpu, 1e-9))))
+            reps, ns = (1, want) if want <= B else (min(4, -(-want // B)), B)
+            tot_iters, wall, match = 0, 0.0, True
+            for _ in range(reps):
+                r = run(0, ns)
+                tot_iters += int(r["iters"].sum()); wall += r["seconds"] + r["update_seconds"]
+                match = match and bool(np.array_equal(r["iters"], ia["iter"][:ns]))
+            out["cpu_baseline"] = {"value": float(tot_iters / wall), "unit": "iter/s", "cores": cores,
+                                   "kind": "port", "sample": f"first {ns} instances of the same batch x {reps} pass(es), one "
+                                   f"instance per thread at a time (updateData+solve), {wall:.2f}s wall = "
+                                   f"{wall * cores:.0f} core-seconds",
+                                   "iters_match_gpu": match,
+                                   "per_core": float(tot_iters / wall / cores)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
