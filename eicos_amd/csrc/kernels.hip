@@ -1397,19 +1397,23 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
                 for (int k = P.Gjc[j]; k < P.Gjc[j + 1]; k++) Gv[k] = (Gv[k] / gt[P.Gir[k]]) / xj;
                 xe[j] *= xj;
             }
-            FOR_T(r, p) ae[r] *= at[r];
-            FOR_T(i, m) ge[i] *= gt[i];
+            for_t_pre<T, 4>(p, [&](int j) { return V2{ae[j], at[j]}; }, [&](int j, const V2 &r) { ae[j] = r.a * r.b; });
+            for_t_pre<T, 8>(m, [&](int i) { return V2{ge[i], gt[i]}; }, [&](int i, const V2 &r) { ge[i] = r.a * r.b; });
             __syncthreads();
         }
-        FOR_T(j, n) cv[j] /= xe[j];
-        FOR_T(r, p) bv[r] /= ae[r];
-        FOR_T(i, m) hv[i] /= ge[i];
+        for_t_pre<T, 4>(n, [&](int j) { return V2{cv[j], xe[j]}; }, [&](int j, const V2 &r) { cv[j] = r.a / r.b; });
+        for_t_pre<T, 4>(p, [&](int j) { return V2{bv[j], ae[j]}; }, [&](int j, const V2 &r) { bv[j] = r.a / r.b; });
+        for_t_pre<T, 8>(m, [&](int i) { return V2{hv[i], ge[i]}; }, [&](int i, const V2 &r) { hv[i] = r.a / r.b; });
         // sliced-ELL value copies for the products (stand in for the reference's Gt/At, :2078-2079);
         // *_src is relative to Av (G values follow at i_Gv - i_Av); padding and the dummy slot get 0
         __syncthreads();
-        FOR_T(k, P.cag_slots + 1) { const int e = P.cag_src[k]; cagv[k] = e < 0 ? 0. : Av[e]; }
-        FOR_T(k, P.rA_slots + 1) { const int e = P.rA_src[k]; rAv[k] = e < 0 ? 0. : Av[e]; }
-        FOR_T(k, P.rG_slots + 1) { const int e = P.rG_src[k]; rGv[k] = e < 0 ? 0. : Av[e]; }
+        auto ell_copy = [&](gdbl_p dst, gint_p src, int cnt) { // eight gathers per thread in flight (23 k slots per instance)
+            for_t_pre<T, 8>(cnt, [&](int k) { const int e = src[k]; return IV1{e, Av[max(e, 0)]}; },
+                            [&](int k, const IV1 &r) { dst[k] = r.i < 0 ? 0. : r.a; });
+        };
+        ell_copy(cagv, P.cag_src, P.cag_slots + 1);
+        ell_copy(rAv, P.rA_src, P.rA_slots + 1);
+        ell_copy(rGv, P.rG_src, P.rG_slots + 1);
         // static-regularisation constants read by the factor program
         if (threadIdx.x == 0) {
             gdbl_p cst = I + P.i_cst;
