@@ -1207,13 +1207,13 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         __syncthreads();
         { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
             gdbl_p Kt = W + P.w_Kt;
-            FOR_T(t, P.fac_nt) Kt[t] = I[P.fac_src[t]];
+            for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[t] = r.a; });
         }
         {
             double nr3[3] = {0., 0., 0.};
-            FOR_T(j, n) { const double c_ = cv[j]; rhs2[P.ipx[j]] = -c_; rhs2k[j] = -c_; nr3[0] += c_ * c_; }
-            FOR_T(r, p) { const double b_ = bv[r]; rhs1[P.ipy[r]] = b_; rhs1k[n + r] = b_; nr3[1] += b_ * b_; }
-            FOR_T(i, m) { const double h_ = hv[i]; rhs1[P.ipz[i]] = h_; rhs1k[np + i] = h_; nr3[2] += h_ * h_; }
+            for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], cv[j]}; }, [&](int j, const IV1 &r) { rhs2[r.i] = -r.a; rhs2k[j] = -r.a; nr3[0] += r.a * r.a; });
+            for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], bv[j]}; }, [&](int j, const IV1 &r) { rhs1[r.i] = r.a; rhs1k[n + j] = r.a; nr3[1] += r.a * r.a; });
+            for_t_pre<T, 8>(m, [&](int i) { return IV1{P.ipz[i], hv[i]}; }, [&](int i, const IV1 &r) { rhs1[r.i] = r.a; rhs1k[np + i] = r.a; nr3[2] += r.a * r.a; });
             blk_reduce<OpSum, T, 3>(phase, nr3);
             if (tid == 0) {
                 g_S.sv[SV_RESX0] = fmax(1., sqrt(nr3[0])); g_S.sv[SV_RESY0] = fmax(1., sqrt(nr3[1])); g_S.sv[SV_RESZ0] = fmax(1., sqrt(nr3[2]));
