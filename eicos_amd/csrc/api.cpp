@@ -108,10 +108,20 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         ProblemPattern &P = h->pat;
         P.n = n; P.m = m; P.p = p; P.nc = ncones;
         P.q.assign(q, q + ncones);
-        if (haveG) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else P.Gjc.assign(n + 1, 0);
-        if (haveA) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else P.Ajc.assign(n + 1, 0);
-        for (int r : P.Gir) if (r < 0 || r >= m) throw std::invalid_argument("G row index out of range");
-        for (int r : P.Air) if (r < 0 || r >= p) throw std::invalid_argument("A row index out of range");
+        // compressed CSC as the reference assumes (src/eicos.cpp:2038-2039): pointers start at 0 and do not decrease,
+        // row indices in range and strictly increasing inside a column
+        auto take = [&](const int *jc, const int *ir, int rows, std::vector<int> &ojc, std::vector<int> &oir, const char *nm) {
+            if (jc[0] != 0) throw std::invalid_argument(std::string(nm) + ": column pointers must start at 0");
+            for (int j = 0; j < n; j++) if (jc[j + 1] < jc[j]) throw std::invalid_argument(std::string(nm) + ": column pointers decrease");
+            ojc.assign(jc, jc + n + 1); oir.assign(ir, ir + jc[n]);
+            for (int j = 0; j < n; j++)
+                for (int k = jc[j]; k < jc[j + 1]; k++) {
+                    if (ir[k] < 0 || ir[k] >= rows) throw std::invalid_argument(std::string(nm) + " row index out of range");
+                    if (k > jc[j] && ir[k] <= ir[k - 1]) throw std::invalid_argument(std::string(nm) + ": row indices of a column must be strictly increasing");
+                }
+        };
+        if (haveG) take(Gjc, Gir, m, P.Gjc, P.Gir, "G"); else P.Gjc.assign(n + 1, 0);
+        if (haveA) take(Ajc, Air, p, P.Ajc, P.Air, "A"); else P.Ajc.assign(n + 1, 0);
         h->sym = analyze(P, -1);
     } catch (const std::invalid_argument &e) { delete h; return fail(EICOS_E_INVALID, e.what()); }
     catch (const std::runtime_error &e) { delete h; return fail(EICOS_E_UNSUPPORTED, e.what()); }

@@ -473,3 +473,31 @@ def test_dynamic_regularisation_extension_matches_oracle():
     g.set_dynamic_regularization(2e-7, 1e-13); g.solve()
     assert np.array_equal(g.info_arrays()["iter"], it0) and np.abs(g.solution() - x0).max() <= 1e-9 * np.abs(x0).max()
     g.close()
+
+
+def test_invalid_arguments_are_refused_with_error_codes():
+    # the ABI never throws or crashes on bad input: negative codes + a message (eicos_last_error)
+    import ctypes as C
+    from eicos_amd import binding as b
+    L = b._lib()
+    ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    h = C.c_void_p()
+    create = lambda n, m, p, q, Gjc, Gir: L.eicos_batch_create(n, m, p, m, len(q), ip(q) if len(q) else None, ip(Gjc), ip(Gir), None, None, 1, -1, C.byref(h))
+    good = ([0, 1, 2], [0, 1])
+    assert create(2, 2, 0, [], *good) == 0
+    L.eicos_batch_destroy(h)
+    assert create(-1, 2, 0, [], *good) == -1                       # negative dimension
+    assert create(2, 2, 0, [3], *good) == -1                       # sum(q) > m
+    assert create(2, 2, 0, [0], *good) == -1                       # cone of dimension 0
+    assert create(2, 2, 0, [], [0, 1, 2], [0, 5]) == -1            # row index out of range
+    assert create(2, 2, 0, [], [0, 2, 1], [0, 1]) == -1            # column pointers decrease
+    assert create(2, 2, 0, [], [0, 2, 2], [1, 1]) == -1            # duplicate row index in a column
+    assert b"column" in L.eicos_last_error() or b"row" in L.eicos_last_error()
+    pat, sets = load_fixture("lp_afiro")
+    g = eicos_amd.BatchSolver(pat, 2)
+    dp = C.POINTER(C.c_double)
+    z = np.zeros(8)
+    assert L.eicos_batch_update(g._h, 1, 2, None, None, z.ctypes.data_as(dp), None, None) == -1   # range out of bounds
+    assert L.eicos_batch_set_warm_start(g._h, -1.0) == -1
+    assert L.eicos_solve(g._h, None) == -1                          # single-instance call on a batch of two
+    g.close()
