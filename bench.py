@@ -4,16 +4,22 @@
   python bench.py --gpus N --steps K --warmup W          (N=1 default)
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): per GPU a batch of 1024 instances on the
-MPC02 sparsity pattern (the MPC01 blob named by BASELINE.json is missing from the reference
-mount), strictly feasible (c,h,b) from eicos_amd.generate keyed by
-(seed, global instance index).  One "step" = one pass of the hot path over the batch with the
-raw inputs already resident in HBM: updateData (equilibrate + transposes, on device) followed
-by the batched cold-start solve.  Metric value = sum over instances of Information.iter / time.
-Multi-GPU: instances are independent -> each rank owns a contiguous shard (weak scaling,
-1024 per GPU), no data-path collective; only the timing/iteration counters are reduced.
+Workload: the MPC02 sparsity pattern (the MPC01 blob named by BASELINE.json is missing from the
+reference mount) with strictly feasible (c,h,b) from eicos_amd.generate keyed by (seed, GLOBAL
+instance index).  One "step" = one pass of the hot path over the batch with the raw inputs already resident in
+HBM: updateData (equilibrate + transposes, on device) followed by the batched cold-start solve.
+Metric value = sum over instances of Information.iter / time.
+
+  N = 1 : BASELINE.json configs[1] -- batch 1024 on one MI355X.
+  N > 1 : BASELINE.json configs[2] -- a FIXED total of 4096 instances in contiguous shards of 4096/N (512 per GPU
+          at N = 8): "scaling": "strong".  `--batch B` forces B instances per GPU instead (weak scaling).
+Instances are independent: no data-path collective; only the timing / iteration counters are reduced.
+
+The line also carries a "soc" object: the same step on the MPC-SOC variant of the pattern (332 second-order cones of
+dimension 3) with its own value and roofline, so that the metric's "SOCP" is what gets timed.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
+TOTAL_STRONG = 4096    # BASELINE.json configs[2]
 
 
 def usable_cores():
@@ -37,6 +44,16 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def kernel_source_hash():
+    """Identity of the kernels a PMC summary was taken on: sha256 over the device sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "eicos_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(dims, ia):
@@ -55,15 +72,147 @@ def algorithmic_bytes(dims, ia):
     return 8.0 * (f * per_factor + r * (per_solve + per_resid) + it * per_iter)
 
 
+def pmc_traffic(tag):
+    """HBM traffic of one launch from the committed summary of separate `rocprofv3 --pmc` passes (PMC counters cannot
+    be collected inside a timed run).  Only a summary taken on THESE kernel sources and THIS workload counts; anything
+    else would describe a different code state -> null."""
+    import glob
+    want = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if pm.get("kernel_source_sha256") == want and pm.get("workload") == tag and "traffic_bytes" in pm:
+            return float(pm["traffic_bytes"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
+class Job:
+    """One workload on this rank's GPU: inputs resident in HBM, solver handle, step()."""
+
+    def __init__(self, args, pat, sets, first, B, local_rank, soc=False):
+        import torch
+        import eicos_amd
+        from eicos_amd.generate import SEED, feasible_batch, mpc_soc_variant, perturbed_batch
+        self.torch, self.args, self.B, self.first = torch, args, B, first
+        self.pat = mpc_soc_variant(pat) if soc else pat
+        self.base = sets[0]
+        gen = perturbed_batch if args.perturb else feasible_batch
+        self.data = gen(self.pat, sets[0], first, B, SEED)
+        dev = f"cuda:{local_rank}"
+        self.devs = [{k: torch.from_numpy(v).to(dev) for k, v in self.data.items()}]
+        if args.resolve > 0:
+            rng = np.random.default_rng(SEED + 17 + first)
+            alt = dict(self.data)
+            alt["c"] = self.data["c"] * (1 + args.resolve * rng.uniform(-1, 1, self.data["c"].shape))
+            alt["h"] = self.data["h"] + args.resolve * (1 + np.abs(self.data["h"])) * rng.uniform(0, 1, self.data["h"].shape)
+            self.devs.append({k: torch.from_numpy(v).to(dev) for k, v in alt.items()})
+        self.step_no = 0
+        self.solver = eicos_amd.BatchSolver(self.pat, B, device=local_rank)
+        self.dims = self.solver.dims()
+        if args.warm > 0:
+            self.solver.set_warm_start(args.warm)
+
+    def step(self):
+        d = self.devs[self.step_no % len(self.devs)]
+        ptr = lambda k: d[k].data_ptr() if d[k].numel() else 0
+        self.solver.update_device(ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))
+        self.solver.solve_async()
+        self.step_no += 1
+
+    def run(self, dist, steps, warmup):
+        """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides."""
+        torch = self.torch
+
+        def fence():
+            if dist is not None:
+                dist.barrier()
+            self.solver.sync()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            self.step()
+        fence()
+        kernel_ms, update_ms = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+            # per-launch kernel duration from HIP events recorded on the solver's own stream
+            kernel_ms.append(self.solver.last_solve_ms())
+            update_ms.append(self.solver.last_update_ms())
+        fence()
+        dt = time.perf_counter() - t0
+        ia = self.solver.info_arrays()
+        dev = self.devs[0]["c"].device
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cnt = torch.tensor([int(ia["iter"].sum()), int((ia["exitcode"] == 0).sum()), self.B], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_iters, tot_ok, tot_B = (int(v) for v in cnt.tolist())
+        return dict(dt=float(t.item()), iters=tot_iters, ok=tot_ok, instances=tot_B, ia=ia,
+                    kernel_ms=float(np.mean(kernel_ms)), update_ms=float(np.mean(update_ms)))
+
+    def report(self, r, steps, tag):
+        dims, ia = self.dims, r["ia"]
+        abytes = algorithmic_bytes(dims, ia)
+        achieved = abytes / (r["kernel_ms"] * 1e-3) / 1e9
+        traffic, src = pmc_traffic(tag)
+        return {
+            "value": r["iters"] * steps / r["dt"], "unit": "iter/s", "ms_per_step": r["dt"] / steps * 1e3,
+            "solves_per_sec": r["instances"] * steps / r["dt"], "optimal": r["ok"], "instances": r["instances"],
+            "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"], "levels": dims["nlevels"], "cones": dims["ncones"],
+            "mean_iter": float(ia["iter"].mean()),
+            "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
+            "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
+            "update_kernel_ms": r["update_ms"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                         "kernel": "k_solve", "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": abytes},
+        }
+
+    def cpu_baseline(self, ia):
+        """CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload."""
+        from oracle import oracle as orc
+        data, pat, B = self.data, self.pat, self.B
+        cores = usable_cores()
+        sub = lambda k, a, b: data[k][a:b]
+        run = lambda a, b: orc.batch_solve(pat, sub("Gpr", a, b), sub("Apr", a, b), sub("c", a, b), sub("h", a, b), sub("b", a, b), cores)
+        # bounded sample: a pilot of one instance per core sizes the sample to ~15 s of CPU work (capped at four
+        # passes over the batch), so that small and large patterns are both timed over a comparable span
+        npil = int(min(B, cores))
+        r0 = run(0, npil)
+        per_inst_cpu = (r0["seconds"] + r0["update_seconds"]) * min(cores, npil) / npil
+        want = int(max(npil, min(4 * B, 15.0 / max(per_inst_cpu, 1e-9))))
+        reps, ns = (1, want) if want <= B else (min(4, -(-want // B)), B)
+        tot_iters, wall, match, maxdiff = 0, 0.0, True, 0
+        for _ in range(reps):
+            r = run(0, ns)
+            tot_iters += int(r["iters"].sum()); wall += r["seconds"] + r["update_seconds"]
+            diff = np.abs(r["iters"].astype(np.int64) - ia["iter"][:ns].astype(np.int64))
+            match = match and bool(diff.max() == 0)
+            maxdiff = max(maxdiff, int(diff.max()))
+        return {"value": float(tot_iters / wall), "unit": "iter/s", "cores": cores, "kind": "port",
+                "sample": f"first {ns} instances of the same batch x {reps} pass(es), one instance per thread at a time "
+                          f"(updateData+solve), {wall:.2f}s wall = {wall * cores:.0f} core-seconds",
+                # parity tolerance on iteration counts is +-1 (SURVEY.md 8d): rounding may move an exit by one pass
+                "iters_match_gpu": match, "iters_max_abs_diff_vs_gpu": maxdiff,
+                "per_core": float(tot_iters / wall / cores)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="instances PER GPU (weak scaling when N > 1).  Default: 1024 at "
+                    "N = 1 (BASELINE configs[1]); at N > 1 a fixed total of 4096 split over the ranks (configs[2], strong)")
+    ap.add_argument("--total", type=int, default=None, help="fixed total number of instances split over the ranks (strong scaling)")
     ap.add_argument("--pattern", default="MPC02", help="fixture name under tests/golden (BASELINE config 3: lp_*), a path to an EPB1 / ECOS data.h problem file, "
                     "or 'dense-front' (BASELINE config 4: n=2000, 32 cones x 64, generated)")
-    ap.add_argument("--soc", action="store_true", help="MPC-SOC variant (332 cones of dim 3)")
+    ap.add_argument("--soc", action="store_true", help="headline on the MPC-SOC variant (332 cones of dim 3) only")
+    ap.add_argument("--no-soc", action="store_true", help="skip the additional MPC-SOC run of the default workload")
     ap.add_argument("--perturb", action="store_true", help="LPnetlib-style batch: perturb c,h of the fixture "
                     "(SURVEY.md 8d config 4) instead of generating strictly feasible (c,h,b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +234,7 @@ def main():
 
     import torch
     import eicos_amd
-    from eicos_amd.generate import SEED, feasible_batch, mpc_soc_variant
+    from eicos_amd.generate import shard_range
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
@@ -105,149 +254,86 @@ def main():
         # reference's data_MPC01.hpp, which is not in the mount: SURVEY.md F4) -- drop it in to bench the real thing
         path = args.pattern if os.path.exists(args.pattern) else os.path.join(ROOT, "tests", "golden", args.pattern + ".epb")
         pat, sets = eicos_amd.read_problem(path)
-    if args.soc:
-        pat = mpc_soc_variant(pat)
-    B = args.batch
-    first = rank * B  # weak scaling: every rank owns instances [rank*B, (rank+1)*B)
-    if args.perturb:
-        from eicos_amd.generate import perturbed_batch
-        data = perturbed_batch(pat, sets[0], first, B, SEED)
-    else:
-        data = feasible_batch(pat, sets[0], first, B, SEED)
+
+    # ---- which instances does this rank own? ----
+    if args.batch is not None:                       # weak: B per GPU
+        B, first, scaling, total = args.batch, rank * args.batch, "weak", args.batch * world
+    else:                                            # strong: fixed total in contiguous shards
+        total = args.total if args.total is not None else (1024 if world == 1 else TOTAL_STRONG)
+        first, B = shard_range(total, rank, world)
+        scaling = "strong"
+    default_workload = args.pattern == "MPC02" and not args.perturb and args.resolve == 0
+
+    job = Job(args, pat, sets, first, B, local_rank, soc=args.soc)
     io_ms = {}
     if args.io == "root" and dist is not None and world > 1:
         # the batch originates on rank 0's GPU: scatter the shards (outside the timed region: inputs are resident in
-        # HBM when timing starts); every rank still knows its own data for the CPU cross-check below
-        from eicos_amd.dist_io import KEYS, scatter_batch
-        widths = {k: data[k].shape[1] for k in KEYS}
+        # HBM when timing starts), results gathered back after it; equal shards only
+        from eicos_amd.dist_io import KEYS, scatter_batch, gather_rows
+        from eicos_amd.generate import SEED, feasible_batch, perturbed_batch
+        assert total % world == 0, "--io root needs equal shards"
+        widths = {k: job.data[k].shape[1] for k in KEYS}
         full = None
         if rank == 0:
             gen = perturbed_batch if args.perturb else feasible_batch
-            allv = gen(pat, sets[0], 0, world * B, SEED)
+            allv = gen(job.pat, sets[0], 0, total, SEED)
             full = {k: torch.from_numpy(allv[k]).to(f"cuda:{local_rank}") for k in KEYS}
         dist.barrier(); torch.cuda.synchronize(); t_sc = time.perf_counter()
         dev = scatter_batch(full, widths, B, rank, world, f"cuda:{local_rank}", dist)
         torch.cuda.synchronize(); dist.barrier(); io_ms["scatter_ms"] = (time.perf_counter() - t_sc) * 1e3
         del full
-        assert all(torch.equal(dev[k].cpu(), torch.from_numpy(data[k])) for k in KEYS), "scattered shard differs"
-    else:
-        dev = {k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in data.items()}
-    devs = [dev]
-    if args.resolve > 0:
-        rng = np.random.default_rng(SEED + 17 + rank)
-        alt = dict(data)
-        alt["c"] = data["c"] * (1 + args.resolve * rng.uniform(-1, 1, data["c"].shape))
-        alt["h"] = data["h"] + args.resolve * (1 + np.abs(data["h"])) * rng.uniform(0, 1, data["h"].shape)
-        devs.append({k: torch.from_numpy(v).to(f"cuda:{local_rank}") for k, v in alt.items()})
-    step_no = [0]
-    ptr = lambda k: (lambda t: t.data_ptr() if t.numel() else 0)(devs[step_no[0] % len(devs)][k])
+        assert all(torch.equal(dev[k].cpu(), torch.from_numpy(job.data[k])) for k in KEYS), "scattered shard differs"
+        job.devs[0] = dev
 
-    solver = eicos_amd.BatchSolver(pat, B, device=local_rank)
-    dims = solver.dims()
-
-    if args.warm > 0:
-        solver.set_warm_start(args.warm)
-
-    def step():
-        solver.update_device(ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))
-        solver.solve_async()
-        step_no[0] += 1
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        solver.sync()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # per-launch kernel duration from HIP events recorded on the solver's own stream
-        kernel_ms.append(solver.last_solve_ms())
-    fence()
-    dt = time.perf_counter() - t0
+    res = job.run(dist, args.steps, args.warmup)
 
     if io_ms:  # results back to the root: x [B, n] straight from the instance slabs, then one gather
-        from eicos_amd.dist_io import gather_rows
         torch.cuda.synchronize(); dist.barrier(); t_g = time.perf_counter()
-        xl = torch.from_numpy(solver.solution()).to(f"cuda:{local_rank}")
+        xl = torch.from_numpy(job.solver.solution()).to(f"cuda:{local_rank}")
         xall = gather_rows(xl, rank, world, dist)
         torch.cuda.synchronize(); dist.barrier(); io_ms["gather_ms"] = (time.perf_counter() - t_g) * 1e3
         if rank == 0:
-            assert xall.shape == (world * B, dims["n"])
-    ia = solver.info_arrays()
-    iters = int(ia["iter"].sum())
-    ok = int((ia["exitcode"] == 0).sum())
-    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    cnt = torch.tensor([iters, ok, B], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dt_max = float(t.item())
-    tot_iters, tot_ok, tot_B = (int(v) for v in cnt.tolist())
+            assert xall.shape == (total, job.dims["n"])
+
+    # ---- the SOC variant of the same workload, timed the same way (its own solver handle; the LP one is released) ----
+    soc_rep = None
+    if default_workload and not args.soc and not args.no_soc:
+        main_rep = job.report(res, args.steps, f"MPC02 batch={B}") if rank == 0 else None
+        cpu = job.cpu_baseline(res["ia"]) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        job.solver.close()
+        sjob = Job(args, pat, sets, first, B, local_rank, soc=True)
+        sres = sjob.run(dist, args.steps, args.warmup)
+        if rank == 0:
+            soc_rep = sjob.report(sres, args.steps, f"MPC02-SOC batch={B}")
+            soc_rep["workload"] = (f"MPC-SOC variant: rows 3000.. of G regrouped into {sjob.dims['ncones']} second-order cones of dimension 3 "
+                                   f"(l={sjob.pat.l}), same A/G values, generated strictly feasible (c,h,b), same instances and step")
+            if world == 1 and not args.no_cpu_baseline:
+                soc_rep["cpu_baseline"] = sjob.cpu_baseline(sres["ia"])
+        sjob.solver.close()
+    else:
+        main_rep = job.report(res, args.steps, f"{args.pattern}{'-SOC' if args.soc else ''} batch={B}") if rank == 0 else None
+        cpu = job.cpu_baseline(res["ia"]) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     if rank == 0:
-        ms_step = dt_max / args.steps * 1e3
-        value = tot_iters * args.steps / dt_max
-        k_ms = float(np.mean(kernel_ms))
-        abytes = algorithmic_bytes(dims, ia)
-        achieved = abytes / (k_ms * 1e-3) / 1e9
-        # HBM traffic of one launch: PMC counters cannot be collected inside a timed run, so the figure comes from
-        # the committed summary of separate `rocprofv3 --pmc` passes over this same command (default workload only)
-        traffic, traffic_src = None, None
-        if args.pattern == "MPC02" and not args.soc and not args.perturb and B == 1024:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
-                pm = json.load(open(f))
-                if "traffic_bytes" in pm:
-                    traffic, traffic_src = float(pm["traffic_bytes"]), os.path.relpath(f, ROOT)
-                    break
+        dims = job.dims
+        roof = main_rep.pop("roofline")
         out = {
-            "metric": "ipm_iterations_per_sec", "value": value, "unit": "iter/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU x {world} GPU, {args.pattern}{'-SOC' if args.soc else ''} pattern "
-                                   f"(n={dims['n']} m={dims['m']} p={dims['p']} cones={dims['ncones']}), strictly feasible "
-                                   f"generated (c,h,b), updateData+solve per step",
-                       "batch_per_gpu": B, "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"],
-                       "levels": dims["nlevels"], "mean_iter": float(ia["iter"].mean()),
-                       "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
-                       "solves_per_sec": tot_B * args.steps / dt_max, "optimal": tot_ok, "instances": tot_B, "generator": "perturbed" if args.perturb else "feasible",
-                       "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
+            "metric": "ipm_iterations_per_sec", "value": main_rep.pop("value"), "unit": main_rep.pop("unit"),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rep.pop("ms_per_step"),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{total} instances total = {B}/GPU x {world} GPU ({scaling}), {args.pattern}{'-SOC' if args.soc else ''} pattern "
+                                   f"(n={dims['n']} m={dims['m']} p={dims['p']} cones={dims['ncones']}), "
+                                   f"{'perturbed (c,h)' if args.perturb else 'strictly feasible generated (c,h,b)'}, updateData+solve per step",
+                       "batch_per_gpu": B, "total_instances": total, **main_rep,
+                       "generator": "perturbed" if args.perturb else "feasible",
                        "io": ("root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms,
                        **({"resolve_eps": args.resolve, "warm_shift": args.warm} if args.resolve > 0 else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (host cores are shared by all ranks)
-            # CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload
-            from oracle import oracle as orc
-            cores = usable_cores()
-            sub = lambda k, a, b: data[k][a:b]
-            run = lambda a, b: orc.batch_solve(pat, sub("Gpr", a, b), sub("Apr", a, b), sub("c", a, b), sub("h", a, b), sub("b", a, b), cores)
-            # bounded sample: a pilot of one instance per core sizes the sample to ~15 s of CPU work (capped at four
-            # passes over the batch), so that small and large patterns are both timed over a comparable span
-            npil = int(min(B, cores))
-            r0 = run(0, npil)
-            per_inst_cpu = (r0["seconds"] + r0["update_seconds"]) * min(cores, npil) / npil
-            want = int(max(npil, min(4 * B, 15.0 / max(per_inst_cpu, 1e-9))))
-            reps, ns = (1, want) if want <= B else (min(4, -(-want // B)), B)
-            tot_iters, wall, match = 0, 0.0, True
-            for _ in range(reps):
-                r = run(0, ns)
-                tot_iters += int(r["iters"].sum()); wall += r["seconds"] + r["update_seconds"]
-                match = match and bool(np.array_equal(r["iters"], ia["iter"][:ns]))
-            out["cpu_baseline"] = {"value": float(tot_iters / wall), "unit": "iter/s", "cores": cores,
-                                   "kind": "port", "sample": f"first {ns} instances of the same batch x {reps} pass(es), one "
-                                   f"instance per thread at a time (updateData+solve), {wall:.2f}s wall = "
-                                   f"{wall * cores:.0f} core-seconds",
-                                   "iters_match_gpu": match,
-                                   "per_core": float(tot_iters / wall / cores)}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if soc_rep is not None:
+            out["soc"] = soc_rep
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -88,8 +88,12 @@ def _lib():
         L.eicos_debug_factor.argtypes = [vp, C.c_int, dp, dp]
         L.eicos_debug_pattern.argtypes = [vp, ip, ip, ip]
         L.eicos_debug_trace.argtypes = [vp, C.c_int, dp]
+        L.eicos_debug_kkt.argtypes = [vp, C.c_int, ip, ip, dp]
+        L.eicos_debug_scalings.argtypes = [vp, C.c_int, dp, dp, dp, ip]
         L.eicos_debug_host_check.restype = C.c_double
         L.eicos_debug_host_check.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
+        L.eicos_debug_host_check_tiles.restype = C.c_double
+        L.eicos_debug_host_check_tiles.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
         for f in ("create", "update", "update_device", "solve", "solve_async", "sync", "solution", "duals", "info",
                   "solution_device", "dims", "set_stream", "last_solve_ms", "last_update_ms", "destroy"):
             getattr(L, "eicos_batch_" + f).restype = C.c_int
@@ -233,6 +237,22 @@ class BatchSolver:
         _chk(_lib().eicos_debug_trace(self._h, inst, _dp(out)))
         return out if iters is None else out[: iters + 1]
 
+    def debug_kkt(self, inst: int = 0):
+        """Upper triangle of the instance's KKT matrix as the factorisation reads it: (rows, cols, vals)."""
+        d = self.dims()
+        r, c, v = np.zeros(max(d["nnzK"], 1), np.int32), np.zeros(max(d["nnzK"], 1), np.int32), np.zeros(max(d["nnzK"], 1))
+        _chk(_lib().eicos_debug_kkt(self._h, inst, _ip(r), _ip(c), _dp(v)))
+        return r[: d["nnzK"]], c[: d["nnzK"]], v[: d["nnzK"]]
+
+    def debug_scalings(self, s, z, inst: int = 0):
+        """The solver's updateScalings + updateKKTScalings stage for (s, z): (ran, scaling block of K)."""
+        pat = self.pat
+        nV = pat.l + int(sum(3 * int(q) + 1 for q in pat.q))
+        s, z = np.ascontiguousarray(s, np.float64), np.ascontiguousarray(z, np.float64)
+        V, ran = np.zeros(max(nV, 1)), np.zeros(1, np.int32)
+        _chk(_lib().eicos_debug_scalings(self._h, inst, _dp(s), _dp(z), _dp(V), _ip(ran)))
+        return bool(ran[0]), V[:nV]
+
     def debug_pattern(self):
         d = self.dims()
         perm, Lp, Li = np.zeros(max(d["dim_K"], 1), np.int32), np.zeros(d["dim_K"] + 1, np.int32), np.zeros(max(d["nnzL"], 1), np.int32)
@@ -249,6 +269,17 @@ class BatchSolver:
             self.close()
         except Exception:
             pass
+
+
+def host_check_tiles(pat, seed: int = 1, order_mode: int = -1):
+    """Host-only check of the tile (dense-front) plan (no GPU): returns (relative residual, stats dict)."""
+    q, Gjc, Gir, Ajc, Air = [np.ascontiguousarray(a, dtype=np.int32) for a in (pat.q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)]
+    st = np.zeros(8, np.int32)
+    r = _lib().eicos_debug_host_check_tiles(pat.n, pat.m, pat.p, pat.ncones, _ip(q) if pat.ncones else None,
+                                            _ip(Gjc) if pat.m else None, _ip(Gir) if pat.m else None,
+                                            _ip(Ajc) if pat.p else None, _ip(Air) if pat.p else None, seed, order_mode, _ip(st))
+    keys = ("dim_K", "nnzK", "nnzL", "block_levels", "tile_pairs", "order_mode", "blocks", "tiles")
+    return float(r), dict(zip(keys, (int(v) for v in st)))
 
 
 def host_check(pat, seed: int = 1, order_mode: int = -1):

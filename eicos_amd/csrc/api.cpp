@@ -19,6 +19,7 @@
 #include "launch.hpp"
 #include "symbolic.hpp"
 #include "plans.hpp"
+#include "tiles.hpp"
 
 using namespace eicos;
 
@@ -44,13 +45,17 @@ struct eicos_batch {
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     int *d_queue = nullptr; // instance queue of the solve kernel (reset per launch)
+    double *d_stage = nullptr; size_t stage_doubles = 0; // host-pointer updateData: persistent staging buffer (one chunk)
+    int *d_flag = nullptr;   // debug hooks
     double warm_shift = 0.; // > 0: warm start (eicos_batch_set_warm_start)
     double dyn_delta = 0., dyn_eps = 0.; // > 0: dynamic regularisation (eicos_batch_set_dynamic_regularization)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
     bool solve_timed = false, update_timed = false;
+    bool in_chunked_update = false; // eicos_batch_update records ev_u0/ev_u1 around ALL of its chunks
     int64_t npairs = 0;
     std::vector<int> posB; // CSC entry of L -> slot in the backward value array
+    TilePlan tiles;        // tile mode (Symbolic::tile): the dense-front plan
 };
 
 namespace {
@@ -87,7 +92,7 @@ int eicos_device_count(void) {
     return n;
 }
 
-int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
+int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
                        const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                        int batch, int device, eicos_batch **out) {
     if (!out) return fail(EICOS_E_INVALID, "out is NULL");
@@ -97,6 +102,13 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     const bool haveG = Gjc && Gir, haveA = Ajc && Air;
     if (!haveG) { m = 0; ncones = 0; } // reference: groups given as NULL are empty (src/eicos.cpp:103-117)
     if (!haveA) p = 0;
+    // The reference ignores `l` and derives it as m - sum(q) (src/eicos.cpp:91,155).  l < 0 means "derive"; a caller that
+    // does pass l (ECOS convention: l + sum(q) = m) and gets it wrong would silently solve a different cone split.
+    if (haveG && l >= 0) {
+        long long qs = 0;
+        for (int c = 0; c < ncones; c++) qs += q[c];
+        if ((long long)l + qs != (long long)m) return fail(EICOS_E_INVALID, "l + sum(q) != m (pass l < 0 to derive l as the reference does)");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(EICOS_E_NOGPU, "no HIP device visible: the solver has no CPU fallback");
@@ -122,7 +134,8 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
         };
         if (haveG) take(Gjc, Gir, m, P.Gjc, P.Gir, "G"); else P.Gjc.assign(n + 1, 0);
         if (haveA) take(Ajc, Air, p, P.Ajc, P.Air, "A"); else P.Ajc.assign(n + 1, 0);
-        h->sym = analyze(P, -1);
+        { const char *tv = getenv("EICOS_TILES"); h->sym = analyze(P, -1, tv ? atoi(tv) : -1); }
+        if (h->sym.tile) h->tiles = build_tile_plan(h->sym);
     } catch (const std::invalid_argument &e) { delete h; return fail(EICOS_E_INVALID, e.what()); }
     catch (const std::runtime_error &e) { delete h; return fail(EICOS_E_UNSUPPORTED, e.what()); }
     catch (const std::exception &e) { delete h; return fail(EICOS_E_INVALID, e.what()); }
@@ -132,7 +145,12 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     h->batch = batch; h->device = device; h->npairs = S.npairs;
     if (S.npairs >= (int64_t)1 << 31) { delete h; return fail(EICOS_E_UNSUPPORTED, "factor program exceeds 2^31 pairs"); }
     DevPat &D = h->dp;
-    D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = S.N; D.mt = S.mt; D.nV = S.nV;
+    const bool tile = S.tile != 0;
+    const TilePlan &TP = h->tiles;
+    // NV = length of the KKT-space vectors on the device: dim_K in elimination order, or (tile mode) the blocks padded to 16
+    const int NV = tile ? TP.N16 : S.N;
+    auto posK = [&](int old) { return tile ? TP.slot[S.iperm[old]] : S.iperm[old]; }; // KKT index -> device slot
+    D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = NV; D.mt = S.mt; D.nV = S.nV;
     D.nnzA = S.nnzA; D.nnzG = S.nnzG; D.nnzL = S.nnzL; D.nlev = S.nlev;
 
     auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
@@ -176,28 +194,28 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     for (size_t sl = 0; sl < pcag.src.size(); sl++) {
         const int e = pcag.src[sl];
         cag_src[sl] = e < 0 ? -1 : cag_val[e];
-        cag_idx_k[sl] = e < 0 ? S.N : S.iperm[cag_k[e]];                         // elimination order; padding -> zero slot N
+        cag_idx_k[sl] = e < 0 ? NV : posK(cag_k[e]);                         // elimination order; padding -> zero slot N
         cag_idx_yz[sl] = e < 0 ? 0 : (cag_yz[e] >= 0 ? cag_yz[e] : (D.i_z - D.i_y) + (-1 - cag_yz[e])); // offset from y
     }
     std::vector<int> rA_idx(prA.src.size()), rA_src(prA.src.size()), rG_idx(prG.src.size()), rG_src(prG.src.size());
     std::vector<int> rA_idx_k(prA.src.size()), rG_idx_k(prG.src.size());
-    for (size_t sl = 0; sl < prA.src.size(); sl++) { const int e = prA.src[sl]; rA_src[sl] = e < 0 ? -1 : S.At_pos[e]; rA_idx[sl] = e < 0 ? 0 : S.At_col[e]; rA_idx_k[sl] = e < 0 ? S.N : S.iperm[S.At_col[e]]; }
-    for (size_t sl = 0; sl < prG.src.size(); sl++) { const int e = prG.src[sl]; rG_src[sl] = e < 0 ? -1 : gv_rel + S.Gt_pos[e]; rG_idx[sl] = e < 0 ? 0 : S.Gt_col[e]; rG_idx_k[sl] = e < 0 ? S.N : S.iperm[S.Gt_col[e]]; }
+    for (size_t sl = 0; sl < prA.src.size(); sl++) { const int e = prA.src[sl]; rA_src[sl] = e < 0 ? -1 : S.At_pos[e]; rA_idx[sl] = e < 0 ? 0 : S.At_col[e]; rA_idx_k[sl] = e < 0 ? NV : posK(S.At_col[e]); }
+    for (size_t sl = 0; sl < prG.src.size(); sl++) { const int e = prG.src[sl]; rG_src[sl] = e < 0 ? -1 : gv_rel + S.Gt_pos[e]; rG_idx[sl] = e < 0 ? 0 : S.Gt_col[e]; rG_idx_k[sl] = e < 0 ? NV : posK(S.Gt_col[e]); }
     std::vector<int> ipx(S.n), ipy(S.p), ipz(S.m), ipv(S.nc), ipu(S.nc);
-    for (int j = 0; j < S.n; j++) ipx[j] = S.iperm[j];
-    for (int r = 0; r < S.p; r++) ipy[r] = S.iperm[S.n + r];
-    for (int i = 0; i < S.m; i++) ipz[i] = S.iperm[S.n + S.p + zexp0[i]];
-    for (int c = 0; c < S.nc; c++) { const int e0 = S.n + S.p + S.cone_off[c] + 2 * c + S.q[c]; ipv[c] = S.iperm[e0]; ipu[c] = S.iperm[e0 + 1]; }
+    for (int j = 0; j < S.n; j++) ipx[j] = posK(j);
+    for (int r = 0; r < S.p; r++) ipy[r] = posK(S.n + r);
+    for (int i = 0; i < S.m; i++) ipz[i] = posK(S.n + S.p + zexp0[i]);
+    for (int c = 0; c < S.nc; c++) { const int e0 = S.n + S.p + S.cone_off[c] + 2 * c + S.q[c]; ipv[c] = posK(e0); ipu[c] = posK(e0 + 1); }
     D.inst_stride = L.size;
     SlabLayout Wl;
     D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m); D.w_blam = Wl.add(S.m);
-    D.w_rx = Wl.add(S.n); D.w_ry = Wl.add(S.p); D.w_rz = Wl.add(S.m); D.w_rhs1 = Wl.add((size_t)S.N + 16); D.w_rhs2 = Wl.add((size_t)S.N + 16); // elimination order
+    D.w_rx = Wl.add(S.n); D.w_ry = Wl.add(S.p); D.w_rz = Wl.add(S.m); D.w_rhs1 = Wl.add((size_t)NV + 16); D.w_rhs2 = Wl.add((size_t)NV + 16); // elimination order
     D.w_rhs1k = Wl.add((size_t)S.n + S.p + S.m); D.w_rhs2k = Wl.add((size_t)S.n + S.p + S.m);       // [x | y | z] order
     D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
-    D.w_xk = Wl.add((size_t)S.N + 16); D.w_ek = Wl.add((size_t)S.N + 16); D.w_dxr = Wl.add(S.N);
-    D.w_D = Wl.add(S.N); D.w_invD = Wl.add(S.N); // w_UF / w_UB are added once the slice plans are known
+    D.w_xk = Wl.add((size_t)NV + 16); D.w_ek = Wl.add((size_t)NV + 16); D.w_dxr = Wl.add(NV);
+    D.w_D = Wl.add(NV); D.w_invD = Wl.add(NV); // w_UF / w_UB are added once the slice plans are known
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
 
     // ---- pattern arrays ----
@@ -227,14 +245,25 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
 
 
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
-    TriPlan planF = build_tri_plan(S, h->threads, true), planB = build_tri_plan(S, h->threads, false);
+    // (tile mode: the sweeps and the factorisation run over the tile plan instead; the scalar plans stay empty)
+    TriPlan planF, planB;
+    if (!tile) { planF = build_tri_plan(S, h->threads, true); planB = build_tri_plan(S, h->threads, false); }
+    else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nUF = planF.slots; D.nUB = planB.slots;
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     h->posB = planB.pos;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
-    FactorPlan planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
+    FactorPlan planX;
+    if (!tile) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
+    else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); }
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
-    D.w_Kt = Wl.add(planX.target.size() + 8); // KKT entries in target order: the factor's only per-target value stream
+    // KKT entries in target order: the factor's only per-target value stream; tile mode: the dense tile image
+    D.w_Kt = Wl.add((tile ? (size_t)(TP.nb + TP.nt) * 256 : planX.target.size()) + 8);
+    D.tile = tile ? 1 : 0; D.nb = TP.nb; D.nt = TP.nt; D.nblev = TP.nblev;
+    if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), inverse diagonal tiles both ways (DC, DR)
+        D.w_LC = Wl.add((size_t)TP.nt * 256 + 8); D.w_LR = Wl.add((size_t)TP.nt * 256 + 8);
+        D.w_DC = Wl.add((size_t)TP.nb * 256); D.w_DR = Wl.add((size_t)TP.nb * 256);
+    }
     D.work_stride = Wl.size;
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
     std::vector<int> col_of(S.nnzL);
@@ -275,10 +304,10 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     };
     const std::vector<int> f_o16 = lane_offsets(planF.sl, D.f_d16), b_o16 = lane_offsets(planB.sl, D.b_d16);
     const std::vector<int> cag_o16 = lane_offsets(pcag.sl, D.cag_d16), rA_o16 = lane_offsets(prA.sl, D.rA_d16), rG_o16 = lane_offsets(prG.sl, D.rG_d16);
-    const std::vector<int> f_w16 = pack16(planF.sl, f_o16, D.f_d16, planF.idx, S.N), b_w16 = pack16(planB.sl, b_o16, D.b_d16, planB.idx, S.N);
-    const std::vector<int> cag_k_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_k, S.N), cag_yz_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_yz, 0);
-    const std::vector<int> rA_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx, 0), rA_k_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx_k, S.N);
-    const std::vector<int> rG_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx, 0), rG_k_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx_k, S.N);
+    const std::vector<int> f_w16 = pack16(planF.sl, f_o16, D.f_d16, planF.idx, NV), b_w16 = pack16(planB.sl, b_o16, D.b_d16, planB.idx, NV);
+    const std::vector<int> cag_k_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_k, NV), cag_yz_w16 = pack16(pcag.sl, cag_o16, D.cag_d16, cag_idx_yz, 0);
+    const std::vector<int> rA_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx, 0), rA_k_w16 = pack16(prA.sl, rA_o16, D.rA_d16, rA_idx_k, NV);
+    const std::vector<int> rG_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx, 0), rG_k_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx_k, NV);
     // factor program: the (pa, pb) slot pairs of a lane, 16 bytes per lane and slice (pa words then pb words)
     const std::vector<int> x_o16 = lane_offsets(planX.sl, D.fac_d16);
     std::vector<int> fac_w16;
@@ -327,6 +356,26 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     std::vector<int> v2t(std::max(S.nV, 1), D.fac_nt); // entries that are no target (none by construction) -> spare slot
     for (size_t t = 0; t < planX.target.size(); t++)
         if (fac_src[t] >= D.i_Vv && fac_src[t] < D.i_Vv + S.nV) v2t[fac_src[t] - D.i_Vv] = (int)t;
+    // ---- tile mode: where every KKT entry lands in the dense tile image, pivot signs, the tile program ----
+    std::vector<int> img_dst, img_src, psign(tile ? NV : 0, 1);
+    if (tile) {
+        for (int j = 0; j < S.N; j++) {
+            img_dst.push_back(TP.D_img[j]); img_src.push_back(srcoff(S.Dkind[j], S.Dsrc[j]));
+            if (S.Dkind[j] == SRC_V) v2t[S.Dsrc[j]] = TP.D_img[j];
+            psign[TP.slot[j]] = pivot_positive(j) ? 1 : -1;
+        }
+        for (int e = 0; e < S.nnzL; e++) {
+            if (S.Lkind[e] == SRC_ZERO) continue; // fill: stays 0 in the image
+            img_dst.push_back(TP.Le_img[e]); img_src.push_back(srcoff(S.Lkind[e], S.Lsrc[e]));
+            if (S.Lkind[e] == SRC_V) v2t[S.Lsrc[e]] = TP.Le_img[e];
+        }
+        for (int d : TP.pad_img) { img_dst.push_back(d); img_src.push_back(D.i_cst + 3); } // padding nodes: identity rows
+    }
+    D.tl_nimg = (int)img_dst.size();
+    put(D.tl_img_dst, img_dst); put(D.tl_img_src, img_src); put(D.tl_psign, psign);
+    put(D.tl_blev, TP.blev_ptr); put(D.tl_tgt_lev, TP.tgt_lev_ptr); put(D.tl_tgt, TP.tgt); put(D.tl_tp, TP.tp_ptr);
+    put(D.tl_pa, TP.pa); put(D.tl_pb, TP.pb); put(D.tl_pk, TP.pk); put(D.tl_fin_lev, TP.fin_lev_ptr); put(D.tl_fin, TP.fin);
+    put(D.tl_trow, TP.t_row); put(D.tl_tcol, TP.t_col); put(D.tl_tc_ptr, TP.tc_ptr); put(D.tl_tr_ptr, TP.tr_ptr); put(D.tl_tr_tile, TP.tr_tile);
     put(D.v2t, v2t);
     const int *fac_sl_p = nullptr;
     put(fac_sl_p, fac_sl_i);
@@ -346,33 +395,36 @@ int eicos_batch_create(int n, int m, int p, int /*l*/, int ncones, const int *q,
     // launch shape: env overrides are for experiments (bench sweeps); defaults chosen from measurements
     // KKT-space vectors (solve vector, current solution, refinement residual) live in LDS when they fit:
     // 160 KiB per CU minus the static block (reductions + scalar state)
-    D.Npad = (S.N + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding
+    D.Npad = (NV + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding
     {
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
         const size_t lds_static = 2048; // struct Sh of kernels.hip (reductions + scalar state), rounded up
+        // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
+        const size_t scratch = tile ? (size_t)(h->threads / 64) * TILE_SCR * sizeof(double) : 0;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
         const int wgs_by_regs = (h->threads == 256 ? 3 : 4) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
-            return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + lds_static)));
+            return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + scratch + lds_static)));
         };
         // the factor program's table goes to LDS too when it is small and does not cost a resident workgroup
         if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total) && env_int("EICOS_FAC_LDS", 1)) {
             D.lm_fac = D.lm_total; D.lm_total += D.fac_ns;
         } else D.lm_fac = -1;
-        const size_t meta = (size_t)D.lm_total * sizeof(PackedSlice);
+        const size_t meta = (size_t)D.lm_total * sizeof(PackedSlice) + scratch;
         // NLDS >= 1 also stages both slice tables in LDS; if they do not fit beside one vector the
         // all-global variant (NLDS = 0, plain __syncthreads between levels) is used
         // KKT-space vectors in LDS: E (rhs / residual / solve vector) and X (current solution), + both slice tables
         int fit = 0;
-        if (S.N > 0 && meta + vec <= avail) fit = (meta + 2 * vec <= avail) ? 2 : 1;
+        if (NV > 0 && meta + vec <= avail) fit = (meta + 2 * vec <= avail) ? 2 : 1;
         // more instances than CUs: keep only E in LDS so that several workgroups share a CU (measured)
         int want = fit;
         if (batch > prop.multiProcessorCount && fit == 2 && 2 * (vec + meta + 4096) <= 160 * 1024) want = 1;
         h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want)));
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
-        h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : 0;
+        h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : scratch;
+        D.tl_scratch = h->nlds >= 1 ? h->nlds * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
     }
     HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
     int bpc = 1;
@@ -433,7 +485,8 @@ int eicos_create(int n, int m, int p, int l, int ncones, const int *q, const dou
     const bool haveG = Gpr && Gjc && Gir, haveA = Apr && Ajc && Air; // NULL groups as in src/eicos.cpp:103-117
     if (n > 0 && !c) return fail(EICOS_E_INVALID, "c is NULL");
     eicos_batch *hd = nullptr;
-    int rc = eicos_batch_create(n, m, p, l, ncones, q, haveG ? Gjc : nullptr, haveG ? Gir : nullptr,
+    (void)l; // ignored exactly as by the reference's constructor (src/eicos.cpp:91): derived as m - sum(q)
+    int rc = eicos_batch_create(n, m, p, -1, ncones, q, haveG ? Gjc : nullptr, haveG ? Gir : nullptr,
                                 haveA ? Ajc : nullptr, haveA ? Air : nullptr, 1, device, &hd);
     if (rc != EICOS_OK) return rc;
     rc = eicos_batch_update(hd, 0, 1, haveG ? Gpr : nullptr, haveA ? Apr : nullptr, c, haveG ? h : nullptr, haveA ? b : nullptr);
@@ -455,14 +508,15 @@ int eicos_destroy(eicos_batch *hd) { return eicos_batch_destroy(hd); }
 int eicos_batch_destroy(eicos_batch *h) {
     if (!h) return EICOS_OK;
     (void)hipSetDevice(h->device);
+    // in-flight work may sit on a caller stream (eicos_batch_set_stream): wait for it before the slabs go away
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
     for (hipEvent_t e : {h->ev_s0, h->ev_s1, h->ev_u0, h->ev_u1}) if (e) (void)hipEventDestroy(e);
-    if (h->d_pattern) (void)hipFree(h->d_pattern);
+    for (void *ptr : {(void *)h->d_pattern, (void *)h->d_inst, (void *)h->d_work, (void *)h->d_queue, (void *)h->d_scratch,
+                      (void *)h->d_stage, (void *)h->d_flag})
+        if (ptr) (void)hipFree(ptr);
+    // the constant-memory descriptor slot is handed out again only after nothing can read it any more
     if (h->pslot >= 0) { std::lock_guard<std::mutex> lk(g_slot_mu); g_slot_used[h->device % 16][h->pslot] = false; }
-    if (h->d_inst) (void)hipFree(h->d_inst);
-    if (h->d_work) (void)hipFree(h->d_work);
-    if (h->d_queue) (void)hipFree(h->d_queue);
-    if (h->d_scratch) (void)hipFree(h->d_scratch);
     delete h;
     return EICOS_OK;
 }
@@ -492,10 +546,9 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     if (dG && !dh && h->dp.m > 0) return fail(EICOS_E_INVALID, "Gpr given without h");
     if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+    if (!h->in_chunked_update) HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
     HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
-    HIP_TRY(hipEventRecord(h->ev_u1, h->stream));
-    h->update_timed = true;
+    if (!h->in_chunked_update) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
     return EICOS_OK;
 }
 
@@ -509,9 +562,18 @@ int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, co
     HIP_TRY(hipSetDevice(h->device));
     const int chunk = 256;
     const size_t per = (size_t)D.nnzG + D.nnzA + D.n + D.m + D.p + 5 * 8;
-    double *stage = nullptr;
-    HIP_TRY(hipMalloc(&stage, (size_t)std::min(count > 0 ? count : 1, chunk) * per * sizeof(double)));
+    // persistent staging buffer (one chunk), grown on demand and freed with the handle: no hipMalloc/hipFree (a
+    // device-wide synchronisation) on the MPC closed-loop path
+    const size_t need = (size_t)std::min(count > 0 ? count : 1, chunk) * per;
+    if (need > h->stage_doubles) {
+        if (h->d_stage) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_stage); h->d_stage = nullptr; h->stage_doubles = 0; }
+        HIP_TRY(hipMalloc(&h->d_stage, need * sizeof(double)));
+        h->stage_doubles = need;
+    }
+    double *stage = h->d_stage;
     int rc = EICOS_OK;
+    HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+    h->in_chunked_update = true;
     for (int o = 0; o < count && rc == EICOS_OK; o += chunk) {
         const int cnt = std::min(chunk, count - o);
         double *dG = stage, *dA = dG + (size_t)cnt * D.nnzG + 8, *dc = dA + (size_t)cnt * D.nnzA + 8;
@@ -528,9 +590,11 @@ int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, co
         if (e != hipSuccess) { rc = fail(EICOS_E_HIP, hipGetErrorString(e)); break; }
         rc = eicos_batch_update_device(h, first + o, cnt, G ? dG : nullptr, A ? dA : nullptr, c ? dc : nullptr,
                                        G ? dh : nullptr, A ? db : nullptr);
+        // the staging buffer is reused by the next chunk, and the caller may reuse its host arrays on return
         if (rc == EICOS_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(EICOS_E_HIP, "stream sync failed in update");
     }
-    (void)hipFree(stage);
+    h->in_chunked_update = false;
+    if (rc == EICOS_OK) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
     return rc;
 }
 
@@ -642,14 +706,91 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(launch_debug_factor(h->pslot, h->d_inst, h->d_work, inst, h->threads, h->stream));
+    HIP_TRY(launch_debug_factor(h->pslot, h->d_inst, h->d_work, inst, h->threads, h->sym.tile ? h->dyn_lds : 0, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->dp.N * sizeof(double), hipMemcpyDeviceToHost));
+    const DevPat &P = h->dp;
+    if (h->sym.tile) { // tiles -> the scalar view (D per elimination position, U = L D per CSC entry of L)
+        const Symbolic &S = h->sym;
+        const TilePlan &TP = h->tiles;
+        std::vector<double> Dv((size_t)TP.N16), LR((size_t)TP.nt * 256 + 1), DR((size_t)TP.nb * 256);
+        HIP_TRY(hipMemcpy(Dv.data(), h->d_work + P.w_D, Dv.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (TP.nt) HIP_TRY(hipMemcpy(LR.data(), h->d_work + P.w_LR, (size_t)TP.nt * 256 * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(DR.data(), h->d_work + P.w_DR, DR.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (Dout) for (int j = 0; j < S.N; j++) Dout[j] = Dv[TP.slot[j]];
+        if (Uout) {
+            // the kernel keeps the INVERSE of every unit-lower diagonal tile; invert it back (16 x 16 forward substitution)
+            std::vector<double> Ld((size_t)TP.nb * 256, 0.0);
+            for (int J = 0; J < TP.nb; J++) {
+                const double *M = DR.data() + (size_t)J * 256; double *Lj = Ld.data() + (size_t)J * 256;
+                for (int c = 0; c < 16; c++)
+                    for (int r = c; r < 16; r++) { // L M = I, column c
+                        double sacc = (r == c) ? 1.0 : 0.0;
+                        for (int k = c; k < r; k++) sacc -= Lj[r * 16 + k] * M[k * 16 + c];
+                        Lj[r * 16 + c] = sacc; // M[c][c] = 1
+                    }
+            }
+            std::vector<int> colj(S.nnzL);
+            for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colj[e] = j;
+            for (int e = 0; e < S.nnzL; e++) {
+                const double lv = TP.Le_tile[e] >= 0 ? LR[(size_t)TP.Le_tile[e] * 256 + TP.Le_rc[e]] : Ld[(size_t)(-1 - TP.Le_tile[e]) * 256 + TP.Le_rc[e]];
+                Uout[e] = lv * Dv[TP.slot[colj[e]]];
+            }
+        }
+        return EICOS_OK;
+    }
+    if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->sym.N * sizeof(double), hipMemcpyDeviceToHost));
     if (Uout) {
         std::vector<double> ub((size_t)h->dp.nUB + 1);
         HIP_TRY(hipMemcpy(ub.data(), h->d_work + h->dp.w_UB, (size_t)h->dp.nUB * sizeof(double), hipMemcpyDeviceToHost));
         for (int e = 0; e < h->dp.nnzL; e++) Uout[e] = ub[h->posB[e]];
     }
+    return EICOS_OK;
+}
+
+int eicos_debug_kkt(eicos_batch *h, int inst, int *rows, int *cols, double *vals) {
+    if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
+    const Symbolic &S = h->sym;
+    const DevPat &D = h->dp;
+    if (rows) std::copy(S.K_row.begin(), S.K_row.end(), rows);
+    if (cols) std::copy(S.K_col.begin(), S.K_col.end(), cols);
+    if (vals) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::vector<double> slab(D.inst_stride);
+        HIP_TRY(hipMemcpy(slab.data(), h->d_inst + (size_t)inst * D.inst_stride, D.inst_stride * sizeof(double), hipMemcpyDeviceToHost));
+        for (int e = 0; e < S.nnzK; e++) {
+            int off;
+            switch (S.K_kind[e]) { // same sources as the factor's value stream (srcoff in eicos_batch_create)
+            case SRC_A: off = D.i_Av + S.K_src[e]; break;
+            case SRC_G: off = D.i_Gv + S.K_src[e]; break;
+            case SRC_V: off = D.i_Vv + S.K_src[e]; break;
+            case SRC_POSDELTA: off = D.i_cst + 0; break;
+            case SRC_NEGDELTA: off = D.i_cst + 1; break;
+            default: off = D.i_cst + 2; break;
+            }
+            vals[e] = slab[off];
+        }
+    }
+    return EICOS_OK;
+}
+
+int eicos_debug_scalings(eicos_batch *h, int inst, const double *s, const double *z, double *V, int *ran) {
+    if (!h || inst < 0 || inst >= h->batch || !s || !z) return fail(EICOS_E_INVALID, "bad argument");
+    const DevPat &D = h->dp;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 16 * sizeof(int)));
+    double *I = h->d_inst + (size_t)inst * D.inst_stride;
+    if (D.m > 0) {
+        HIP_TRY(hipMemcpy(I + D.i_s, s, (size_t)D.m * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(I + D.i_z, z, (size_t)D.m * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(launch_debug_scalings(h->pslot, h->d_inst, h->d_work, inst, h->d_flag, h->threads, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int ok = 0;
+    HIP_TRY(hipMemcpy(&ok, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (ran) *ran = ok;
+    if (V && D.nV > 0) HIP_TRY(hipMemcpy(V, I + D.i_Vv, (size_t)D.nV * sizeof(double), hipMemcpyDeviceToHost));
     return EICOS_OK;
 }
 
@@ -809,6 +950,109 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
         double nr = 0, nb = 0;
         for (int i = 0; i < N; i++) { nr = std::max(nr, std::fabs(r[i])); nb = std::max(nb, std::fabs(rhs[i])); }
         return N ? nr / nb : 0.0;
+    } catch (const std::exception &e) { g_err = e.what(); return -2.0; }
+}
+
+
+// Host-only self check of the TILE path (no GPU needed): random quasi-definite values on the KKT pattern, the block
+// factorisation and the two tile sweeps executed exactly as the kernels index them (tile image, pair lists, finalise
+// lists, CSR / CSC tile views, column- / row-major tile copies, inverse diagonal tiles), then ||K x - b|| / ||b||.
+// stats[8] = {dim_K, nnzK, nnzL, block levels, tile pairs, order_mode, blocks, off-diagonal tiles}.
+double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                    const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats) {
+    try {
+        ProblemPattern P;
+        P.n = n; P.m = m; P.p = p; P.nc = ncones; P.q.assign(q, q + ncones);
+        if (Gjc && Gir) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else { P.Gjc.assign(n + 1, 0); P.m = 0; P.nc = 0; P.q.clear(); }
+        if (Ajc && Air) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else { P.Ajc.assign(n + 1, 0); P.p = 0; }
+        Symbolic S = analyze(P, order_mode, 1);
+        TilePlan TP = build_tile_plan(S);
+        const int N = S.N, nb = TP.nb, nt = TP.nt, N16 = TP.N16;
+        if (stats) { stats[0] = N; stats[1] = S.nnzK; stats[2] = S.nnzL; stats[3] = TP.nblev; stats[4] = (int)std::min<int64_t>(TP.npairs, 2147483647); stats[5] = S.order_mode; stats[6] = nb; stats[7] = nt; }
+        unsigned long long st = seed * 2654435761ull + 12345;
+        auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return ((st >> 11) & 0xFFFFFFFFFFFFull) / (double)(1ull << 48); };
+        std::vector<double> Kv(S.nnzK);
+        for (int e = 0; e < S.nnzK; e++) {
+            const int r = S.K_row[e], c = S.K_col[e];
+            if (r == c) Kv[e] = (r < S.n ? 1.0 : -1.0) * (4.0 + rnd());
+            else Kv[e] = 0.2 * (rnd() - 0.5);
+        }
+        // the tile image of P K P' (what solve_instance scatters from the instance slab)
+        std::vector<double> img((size_t)(nb + nt) * 256, 0.0);
+        for (int e = 0; e < S.nnzK; e++) {
+            const int a = S.iperm[S.K_row[e]], b = S.iperm[S.K_col[e]];
+            if (a == b) img[TP.D_img[a]] = Kv[e];
+            else {
+                const int i = std::max(a, b), j = std::min(a, b);
+                auto it = std::lower_bound(S.Li.begin() + S.Lp[j], S.Li.begin() + S.Lp[j + 1], i);
+                if (it == S.Li.begin() + S.Lp[j + 1] || *it != i) return -4.0;
+                img[TP.Le_img[it - S.Li.begin()]] = Kv[e];
+            }
+        }
+        for (int d : TP.pad_img) img[d] = 1.0;
+        std::vector<double> LC((size_t)nt * 256 + 1, 0.0), LR((size_t)nt * 256 + 1, 0.0), DC((size_t)nb * 256, 0.0), DR((size_t)nb * 256, 0.0), D(N16, 0.0), invD(N16, 0.0);
+        for (int v = 0; v < TP.nblev; v++) {
+            for (int qi = TP.tgt_lev_ptr[v]; qi < TP.tgt_lev_ptr[v + 1]; qi++) { // phase 1
+                const int tg = TP.tgt[qi];
+                double Tt[16][16];
+                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) Tt[r][c] = img[(size_t)tg * 256 + r * 16 + c];
+                for (int e = TP.tp_ptr[qi]; e < TP.tp_ptr[qi + 1]; e++) {
+                    const double *A = LC.data() + (size_t)TP.pa[e] * 256, *B = LC.data() + (size_t)TP.pb[e] * 256, *d = D.data() + TP.pk[e] * 16;
+                    for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { double sacc = 0; for (int k = 0; k < 16; k++) sacc += A[k * 16 + r] * (B[k * 16 + c] * d[k]); Tt[r][c] -= sacc; }
+                }
+                if (tg >= nb) { double *o = LC.data() + (size_t)(tg - nb) * 256; for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) o[c * 16 + r] = Tt[r][c]; continue; }
+                const int J = tg;
+                for (int j = 0; j < 16; j++) {
+                    const double dj = Tt[j][j];
+                    for (int c = j + 1; c < 16; c++) for (int r = c; r < 16; r++) Tt[r][c] -= (Tt[r][j] / dj) * Tt[c][j];
+                    for (int r = j + 1; r < 16; r++) Tt[r][j] /= dj;
+                }
+                for (int c = 0; c < 16; c++) {
+                    D[J * 16 + c] = Tt[c][c]; invD[J * 16 + c] = 1.0 / Tt[c][c];
+                    double mc[16];
+                    for (int r = 0; r < 16; r++) { double sacc = (r == c) ? 1.0 : 0.0; for (int k = 0; k < r; k++) sacc -= Tt[r][k] * mc[k]; mc[r] = (r < c) ? 0.0 : sacc; }
+                    for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + c * 16 + r] = mc[r]; DR[(size_t)J * 256 + r * 16 + c] = mc[r]; }
+                }
+            }
+            for (int qi = TP.fin_lev_ptr[v]; qi < TP.fin_lev_ptr[v + 1]; qi++) { // phase 2
+                const int t = TP.fin[qi], J = TP.t_col[t];
+                double Tt[16][16];
+                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) {
+                    double sacc = 0;
+                    for (int k = 0; k < 16; k++) sacc += LC[(size_t)t * 256 + k * 16 + r] * DC[(size_t)J * 256 + k * 16 + c]; // T[r][k] * Linv[c][k]
+                    Tt[r][c] = sacc * invD[J * 16 + c];
+                }
+                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { LR[(size_t)t * 256 + r * 16 + c] = Tt[r][c]; LC[(size_t)t * 256 + c * 16 + r] = Tt[r][c]; }
+            }
+        }
+        std::vector<double> rhs(N), ws(N16 + 1, 0.0);
+        for (int i = 0; i < N; i++) rhs[i] = rnd() - 0.5;
+        for (int i = 0; i < N; i++) ws[TP.slot[i]] = rhs[S.perm[i]];
+        auto block = [&](int B, const std::vector<int> &tiles_of, int e0, int e1, const std::vector<double> &val, const std::vector<double> &dia, bool fwd) {
+            double acc[16] = {0};
+            for (int e = e0; e < e1; e++) {
+                const int t = fwd ? tiles_of[e] : e, vb = fwd ? TP.t_col[t] : TP.t_row[t];
+                for (int c = 0; c < 16; c++) for (int k = 0; k < 16; k++) acc[c] += val[(size_t)t * 256 + k * 16 + c] * ws[vb * 16 + k];
+            }
+            double r[16], o[16] = {0};
+            for (int c = 0; c < 16; c++) r[c] = (fwd ? ws[B * 16 + c] : ws[B * 16 + c] * invD[B * 16 + c]) - acc[c];
+            for (int c = 0; c < 16; c++) for (int k = 0; k < 16; k++) o[c] += dia[(size_t)B * 256 + k * 16 + c] * r[k];
+            for (int c = 0; c < 16; c++) ws[B * 16 + c] = o[c];
+        };
+        for (int v = 0; v < TP.nblev; v++) for (int B = TP.blev_ptr[v]; B < TP.blev_ptr[v + 1]; B++) block(B, TP.tr_tile, TP.tr_ptr[B], TP.tr_ptr[B + 1], LC, DC, true);
+        for (int v = TP.nblev - 1; v >= 0; v--) for (int B = TP.blev_ptr[v]; B < TP.blev_ptr[v + 1]; B++) block(B, TP.tr_tile, TP.tc_ptr[B], TP.tc_ptr[B + 1], LR, DR, false);
+        std::vector<double> x(N);
+        for (int j = 0; j < N; j++) x[S.perm[j]] = ws[TP.slot[j]];
+        for (int s_ = 0; s_ < N16; s_++) { bool real = false; for (int j = 0; j < N && !real; j++) real = TP.slot[j] == s_; if (!real && ws[s_] != 0.0) return -5.0; if (N > 4000) break; } // padding slots stay 0
+        std::vector<double> r(rhs);
+        for (int e = 0; e < S.nnzK; e++) {
+            const int a = S.K_row[e], b = S.K_col[e];
+            r[a] -= Kv[e] * x[b];
+            if (a != b) r[b] -= Kv[e] * x[a];
+        }
+        double nr = 0, nbn = 0;
+        for (int i = 0; i < N; i++) { nr = std::max(nr, std::fabs(r[i])); nbn = std::max(nbn, std::fabs(rhs[i])); }
+        return N ? nr / nbn : 0.0;
     } catch (const std::exception &e) { g_err = e.what(); return -2.0; }
 }
 

@@ -109,6 +109,13 @@ struct DevPat {
     gint_p v2t;                    // [nV] scaling-block entry -> its target
     gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;
     gint_p fac_p16; int fac_d16; // idx16: per lane and slice the four (pa, pb) pairs as eight 16-bit slot numbers (16 bytes)
+    // ---- tile mode (dense fronts, tiles.hpp): L = block-sparse matrix of dense 16 x 16 tiles; D.N is then 16 * nb ----
+    int tile, nb, nt, nblev;       // 1 = tile path; blocks, off-diagonal tiles, block levels
+    int tl_nimg, tl_scratch;       // entries of the K image scatter; offset (doubles) of the per-wave LDS scratch
+    gint_p tl_blev, tl_tgt_lev, tl_tgt, tl_tp, tl_pa, tl_pb, tl_pk, tl_fin_lev, tl_fin; // levels, factor targets / pairs, finalise lists
+    gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view
+    gint_p tl_img_dst, tl_img_src, tl_psign; // K image scatter (slab offset -> image index); quasi-definite pivot sign per slot
+    int w_LC, w_LR, w_DC, w_DR;    // workspace: L tiles column- / row-major, inverse diagonal tiles column- / row-major
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets
@@ -118,12 +125,15 @@ struct DevPat {
     size_t inst_stride, work_stride; // in doubles
 };
 
+constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each
 constexpr int CSC_STRIDE = 20;     // doubles of scaling state per cone
 // per-cone scaling scalars (reference struct SOCone, include/eicos.hpp:81-95): CS_* committed,
 // CN_* candidates of the current updateScalings pass (committed only if no earlier cone failed)
 enum { CS_A = 0, CS_D1, CS_W, CS_ETA, CS_ETA2, CS_U0, CS_U1, CS_V1,
-       CN_A, CN_D1, CN_W, CN_ETA2, CN_U0, CN_U1, CN_V1, CN_SN, CN_ZN, CN_GAM };
+       CN_A, CN_D1, CN_W, CN_ETA2, CN_U0, CN_U1, CN_V1, CN_SN, CN_ZN, CN_GAM,
+       CN_MODE /* 0 = candidate complete, 2 = failed at the c2byu02 - d test (ref :460-463: eta, eta^2 and q are already new) */ };
+static_assert(CN_MODE < CSC_STRIDE, "per-cone scaling state");
 
 } // namespace eicos

@@ -564,6 +564,11 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
     double carry = 0.; // partial sum of targets cut into sub-slices
     const int ns = P.fac_ns;
+    if (ns == 0) { // empty problem (dim_K = 0): nothing to factorise, and no slice table to decode
+        if (tid == 0) wi.n_factor++;
+        __syncthreads();
+        return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
+    }
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
     // the loads that need them, so that their round trip is not on the path either
@@ -660,6 +665,181 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
     TICK_END(TK_FACTOR);
     if (g_S.fl[FL_FATAL]) return ST_DONE; // ref :901-905,1166-1170 (no backscale)
     return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
+}
+
+
+// ============================================================================================
+// Tile mode (dense fronts): L is a block-sparse matrix of dense 16 x 16 fp64 tiles (host: tiles.hpp).
+// One WAVEFRONT per tile operation; levels of the block dependency graph are separated by workgroup barriers.
+//   LC[t] : unit-lower L tile t = (I, J), column-major ((r, c) at 16 c + r)  -- forward sweep + both MFMA operands
+//   LR[t] : the same tile row-major ((r, c) at 16 r + c)                      -- backward sweep
+//   DC[J] / DR[J] : inverse of the unit-lower diagonal tile L_JJ, column- / row-major; D, invD per slot
+// v_mfma_f64_16x16x4_f64 lane maps (checked on gfx950, tools/dev/mfma_f64_layout.hip): operand A: lane l holds
+// A[row l&15][k l>>4], operand B: B[k l>>4][col l&15], result: C[row (l>>4) + 4 reg][col l&15].  A column-major tile is
+// therefore read as four fully coalesced 512-byte loads (element s*64 + l for K-step s), for A and for B alike.
+// ============================================================================================
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---------------- ST_FACTOR, tile mode: left-looking block LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
+template <int T, int NLDS>
+__device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int iter) {
+    STAGE_PROLOGUE
+    iter = uni(iter);
+    constexpr int NW = T / 64;
+    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, D = W + P.w_D, invD = W + P.w_invD;
+    gcdbl_p Kt = W + P.w_Kt;
+    double *scr = g_dyn + P.tl_scratch + uni(wave) * TILE_SCR; // wave-private 16 x 17 tile in LDS
+    const int nbk = P.nb, kq = lane >> 4, lc = lane & 15;
+    __syncthreads();
+    TICK_BEGIN;
+    for (int v = 0; v < P.nblev; v++) {
+        // ---- phase 1: T = K - sum_K L_IK D_K L_JK' for every target of the level; diagonal targets are factorised ----
+        const int q1 = P.tl_tgt_lev[v + 1];
+        for (int q = P.tl_tgt_lev[v] + uni(wave); q < q1; q += NW) {
+            const int tg = uni(P.tl_tgt[q]), p0 = uni(P.tl_tp[q]), p1 = uni(P.tl_tp[q + 1]);
+            d4_t acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = Kt[(size_t)tg * 256 + (kq + 4 * r) * 16 + lc]; // K image, row-major = result layout
+            double a[4], b[4], dd[4], na[4], nb_[4], nd[4];
+            auto load = [&](int e, double (&xa)[4], double (&xb)[4], double (&xd)[4]) {
+                const int ta = uni(P.tl_pa[e]), tb = uni(P.tl_pb[e]), K = uni(P.tl_pk[e]);
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    xa[st] = LC[(size_t)ta * 256 + st * 64 + lane];
+                    xb[st] = LC[(size_t)tb * 256 + st * 64 + lane];
+                    xd[st] = D[K * 16 + 4 * st + kq];
+                }
+            };
+            if (p0 < p1) load(p0, na, nb_, nd);
+            for (int e = p0; e < p1; e++) {
+#pragma unroll
+                for (int st = 0; st < 4; st++) { a[st] = na[st]; b[st] = nb_[st]; dd[st] = nd[st]; }
+                if (e + 1 < p1) load(e + 1, na, nb_, nd); // next pair's tiles in flight behind this pair's MFMAs
+#pragma unroll
+                for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[st], b[st] * dd[st], acc, 0, 0, 0);
+            }
+            if (tg >= nbk) { // off-diagonal target: park T column-major in its own L slot (phase 2 reads it as an MFMA operand)
+                const int t = tg - nbk;
+#pragma unroll
+                for (int r = 0; r < 4; r++) LC[(size_t)t * 256 + lc * 16 + kq + 4 * r] = acc[r];
+                continue;
+            }
+            // ---- diagonal target: dense LDL' of the 16 x 16 tile in LDS (lower triangle), then the inverse of L_JJ ----
+            const int J = tg;
+#pragma unroll
+            for (int r = 0; r < 4; r++) scr[(kq + 4 * r) * 17 + lc] = acc[r];
+            for (int j = 0; j < 16; j++) {
+                double dj = scr[j * 17 + j];
+                if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
+                    const double sg = (double)P.tl_psign[J * 16 + j];
+                    if (sg * dj <= g_S.dyn_eps) { dj = sg * g_S.dyn_delta; if (lane == 0) scr[j * 17 + j] = dj; }
+                }
+                if (dj == 0. && lane == 0) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { // trailing update of the lower triangle with the unscaled column j
+                    const int rr = kq + 4 * r;
+                    if (lc > j && rr >= lc) scr[rr * 17 + lc] -= (scr[rr * 17 + j] / dj) * scr[lc * 17 + j];
+                }
+                if (lane > j && lane < 16) scr[lane * 17 + j] = scr[lane * 17 + j] / dj; // column j of L
+            }
+            if (lane < 16) {
+                const double dv = scr[lane * 17 + lane];
+                D[J * 16 + lane] = dv; invD[J * 16 + lane] = 1. / dv;
+                // column `lane` of M = L_JJ^-1 by forward substitution (rows above the diagonal are zero)
+                double mcol[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    double sacc = (r == lane) ? 1. : 0.;
+#pragma unroll
+                    for (int k = 0; k < r; k++) sacc -= scr[r * 17 + k] * mcol[k];
+                    mcol[r] = (r < lane) ? 0. : sacc;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + lane * 16 + r] = mcol[r]; DR[(size_t)J * 256 + r * 16 + lane] = mcol[r]; }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: L_IJ = T_IJ L_JJ^-T D_J^-1 for the off-diagonal tiles of the level's block columns ----
+        const int f1 = P.tl_fin_lev[v + 1];
+        for (int q = P.tl_fin_lev[v] + uni(wave); q < f1; q += NW) {
+            const int t = uni(P.tl_fin[q]), J = uni(P.tl_tcol[t]);
+            double a[4], b[4];
+#pragma unroll
+            for (int st = 0; st < 4; st++) { a[st] = LC[(size_t)t * 256 + st * 64 + lane]; b[st] = DC[(size_t)J * 256 + st * 64 + lane]; }
+            const double idc = invD[J * 16 + lc];
+            d4_t acc = {0., 0., 0., 0.};
+#pragma unroll
+            for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], b[st], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double lv = acc[r] * idc;
+                LR[(size_t)t * 256 + (kq + 4 * r) * 16 + lc] = lv;
+                LC[(size_t)t * 256 + lc * 16 + kq + 4 * r] = lv;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) wi.n_factor++;
+    __syncthreads();
+    TICK_END(TK_FACTOR);
+    if (g_S.fl[FL_FATAL]) return ST_DONE; // ref :901-905,1166-1170 (no backscale)
+    return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
+}
+
+// ---------------- LDL' solve, tile mode: ws <- L^-T D^-1 L^-1 ws in the padded elimination order ----------------
+// Forward, block row I:  y_I = Linv_II (b_I - sum_K L_IK y_K);  backward, block column J:  x_J = Linv_JJ' (y_J / D_J - sum_I L_IJ' x_I).
+// A tile mat-vec: lane l multiplies the four tile elements s*64 + l (s = 0..3) by the vector entries 4 s + (l >> 4) and the
+// four lane groups are folded by two cross-lane adds: unit-stride 512-byte loads, no index arrays at all.
+template <int T, bool LDSBAR, class WS>
+__device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws) {
+    constexpr int NW = T / 64;
+    gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, invD = W + P.w_invD;
+    const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, lc = lane & 15;
+    auto bar = [&] { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); };
+    auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
+    // one block: acc = sum over its tiles (values from `val`, tile ids / vector blocks through tid_of / blk_of), then the diagonal tile
+    auto block = [&](int B, int e0, int e1, gcdbl_p val, gcdbl_p dia, auto &&tile_at, auto &&vecblk_at, bool scale) {
+        double acc = 0.;
+        double cv[4], nv[4];
+        int cb = 0, nbk = 0;
+        auto load = [&](int e, double (&x)[4], int &vb) {
+            const int t = uni(tile_at(e));
+            vb = uni(vecblk_at(t));
+#pragma unroll
+            for (int st = 0; st < 4; st++) x[st] = val[(size_t)t * 256 + st * 64 + lane];
+        };
+        if (e0 < e1) load(e0, nv, nbk);
+        for (int e = e0; e < e1; e++) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) cv[st] = nv[st];
+            cb = nbk;
+            if (e + 1 < e1) load(e + 1, nv, nbk);
+#pragma unroll
+            for (int st = 0; st < 4; st++) acc += cv[st] * ws[cb * 16 + 4 * st + kq];
+        }
+        double dg[4];
+#pragma unroll
+        for (int st = 0; st < 4; st++) dg[st] = dia[(size_t)B * 256 + st * 64 + lane];
+        const double own = ws[B * 16 + lc];
+        const double r = (scale ? own * invD[B * 16 + lc] : own) - fold(acc); // every lane: entry lc of the block's right-hand side
+        double o = 0.;
+#pragma unroll
+        for (int st = 0; st < 4; st++) o += dg[st] * __shfl(r, 4 * st + kq, 64);
+        o = fold(o);
+        if (lane < 16) ws[B * 16 + lane] = o;
+    };
+    for (int v = 0; v < P.nblev; v++) { // forward: block rows, levels up
+        const int b1 = P.tl_blev[v + 1];
+        for (int B = P.tl_blev[v] + wave; B < b1; B += NW)
+            block(B, P.tl_tr_ptr[B], P.tl_tr_ptr[B + 1], LC, DC, [&](int e) { return P.tl_tr_tile[e]; }, [&](int t) { return P.tl_tcol[t]; }, false);
+        bar();
+    }
+    for (int v = P.nblev - 1; v >= 0; v--) { // backward: block columns, levels down
+        const int b1 = P.tl_blev[v + 1];
+        for (int B = P.tl_blev[v] + wave; B < b1; B += NW)
+            block(B, P.tl_tc_ptr[B], P.tl_tc_ptr[B + 1], LR, DR, [&](int e) { return e; }, [&](int t) { return P.tl_trow[t]; }, true);
+        bar();
+    }
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
@@ -828,31 +1008,40 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
                 const double d1 = fmax(0., 0.5 * (a * a + ww * (1. - cc * cc / (1. + ww * dd))));
                 const double u0sq = a * a + ww - d1;
                 const double c2 = cc * cc / u0sq;
-                if (c2 - dd <= 0.) fail = true;
-                else if (ln == 0) {
-                    cs[CN_A] = a; cs[CN_D1] = d1; cs[CN_W] = ww; cs[CN_ETA2] = snorm / znorm;
-                    cs[CN_U0] = sqrt(u0sq); cs[CN_U1] = sqrt(c2); cs[CN_V1] = sqrt(c2 - dd);
-                    cs[CN_SN] = snorm; cs[CN_ZN] = znorm; cs[CN_GAM] = gam;
+                const bool late = (c2 - dd <= 0.); // ref :460-463: returns AFTER eta_square, eta (:440-441) and q (:448) were overwritten
+                if (late) fail = true;
+                if (ln == 0) {
+                    cs[CN_ETA2] = snorm / znorm; cs[CN_SN] = snorm; cs[CN_ZN] = znorm; cs[CN_GAM] = gam;
+                    cs[CN_MODE] = late ? 2. : 0.;
+                    if (!late) {
+                        cs[CN_A] = a; cs[CN_D1] = d1; cs[CN_W] = ww;
+                        cs[CN_U0] = sqrt(u0sq); cs[CN_U1] = sqrt(c2); cs[CN_V1] = sqrt(c2 - dd);
+                    }
                 }
-            }
+            } else if (ln == 0) cs[CN_MODE] = 1.; // left the cone: nothing of this cone was touched (ref :428-431)
             if (fail) firstfail = fmin(firstfail, (double)c);
         });
-        // index of the first cone that left the cone; 1e300 if none.  The reference returns at that
-        // cone (ref :428-431,460-463): earlier cones keep their new scalings, later ones their old
-        // ones, and lambda is not refreshed.
+        // index of the first cone that failed; 1e300 if none.  The reference returns at that cone (ref :428-431,
+        // :460-463): earlier cones keep their new scalings, later ones their old ones, lambda is not refreshed --
+        // and updateKKTScalings (ref :1162, return value of updateScalings ignored) then writes whatever the structs
+        // hold: for a cone that failed the LATE test that is the new eta^2 and q with the old d1, u0, u1, v1.
         firstfail = blk_reduce1<OpMin, T>(phase, firstfail);
         for_cones<T>(ps, [&](int c, auto G, int ln) { // phase 2: commit + updateKKTScalings
             constexpr int g = decltype(G)::value;
-            if ((double)c >= firstfail) return;
+            if ((double)c > firstfail) return;
             const int o = P.cone_off[c], d = P.cq[c];
             gdbl_p cs = csc + c * CSC_STRIDE;
+            const bool partial = ((double)c == firstfail);
+            if (partial && cs[CN_MODE] != 2.) return;
             gdbl_p v = Vv + P.cone_vbase[c];
             gint_p vt = P.v2t + P.cone_vbase[c];
-            const double a = cs[CN_A], d1 = cs[CN_D1], eta2 = cs[CN_ETA2], u0 = cs[CN_U0], u1 = cs[CN_U1], v1 = cs[CN_V1];
+            const double eta2 = cs[CN_ETA2];
+            const double d1 = partial ? cs[CS_D1] : cs[CN_D1], u0 = partial ? cs[CS_U0] : cs[CN_U0];
+            const double u1 = partial ? cs[CS_U1] : cs[CN_U1], v1 = partial ? cs[CS_V1] : cs[CN_V1];
             const double snorm = cs[CN_SN], znorm = cs[CN_ZN], gam = cs[CN_GAM];
             if (ln == 0) {
-                cs[CS_A] = a; cs[CS_D1] = d1; cs[CS_W] = cs[CN_W]; cs[CS_ETA2] = eta2; cs[CS_ETA] = sqrt(eta2);
-                cs[CS_U0] = u0; cs[CS_U1] = u1; cs[CS_V1] = v1;
+                cs[CS_ETA2] = eta2; cs[CS_ETA] = sqrt(eta2);
+                if (!partial) { cs[CS_A] = cs[CN_A]; cs[CS_D1] = d1; cs[CS_W] = cs[CN_W]; cs[CS_U0] = u0; cs[CS_U1] = u1; cs[CS_V1] = v1; }
             }
             // KKT scaling block, slot order of ref cacheIndices :1955-1986: D[d], vdiag, v[d-1], udiag, u[d]
             for (int k = ln; k < d; k += g) {
@@ -913,7 +1102,7 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
         // ---------------- solveKKT (ref :1471-1620) ----------------
         gcdbl_p bx = rhsk, by = rhsk + n, bz = rhsk + np;
         double nr = 0.;
-        for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{rhsp[i < N ? i : N - 1]}; }, [&](int i, const V1 &r) {
+        for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{rhsp[i < N ? i : max(N - 1, 0)]}; }, [&](int i, const V1 &r) { // N = 0 (empty problem): slot 0 of the N+16 allocation
             const double v = (i < N) ? r.a : 0.; // load the rhs; slots >= N stay 0
             SV[i] = v; nr = fmax(nr, fabs(v));
         });
@@ -927,6 +1116,10 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
             __syncthreads();
             // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
             const bool wave0 = uni(tid >> 6) == 0;
+            if (P.tile) { // dense fronts: tile mat-vecs over the block levels
+                if constexpr (NLDS >= 1) tile_solve<T, true>(P, W, SV); else tile_solve<T, false>(P, W, SV);
+                TICK_END(TK_FWD);
+            } else
             if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
                 tri_sweep<T, true, true, false, I16>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
                 if (wave0) {
@@ -1207,6 +1400,12 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         __syncthreads();
         { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
             gdbl_p Kt = W + P.w_Kt;
+            if (P.tile) { // dense tile image of K: zero, then scatter the structural entries (+ 1 on the padding diagonals)
+                const int nimg = (P.nb + P.nt) * 256;
+                FOR_T(t, nimg) Kt[t] = 0.;
+                __syncthreads();
+                for_t_pre<T, 8>(P.tl_nimg, [&](int e) { return IV1{P.tl_img_dst[e], I[P.tl_img_src[e]]}; }, [&](int e, const IV1 &r) { Kt[r.i] = r.a; });
+            } else
             for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[t] = r.a; });
         }
         {
@@ -1258,7 +1457,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         stage = ST_RESID; iter = 0;
     }
     while (stage != ST_DONE) {
-        if (stage == ST_FACTOR) stage = stage_factor<T, NLDS, I16>(ps, I, W, iter);
+        if (stage == ST_FACTOR) stage = c_pat[ps].tile ? stage_factor_tiles<T, NLDS>(ps, I, W, iter) : stage_factor<T, NLDS, I16>(ps, I, W, iter);
         else if (stage == ST_RESID) stage = stage_resid<T, NLDS, I16>(ps, I, W, iter);
         else {
             const int prev = stage;
@@ -1417,7 +1616,7 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
         // static-regularisation constants read by the factor program
         if (threadIdx.x == 0) {
             gdbl_p cst = I + P.i_cst;
-            cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 0.;
+            cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 1.; // [3]: diagonal of the padding nodes (tile mode)
             ginfo->equilibrated = 1;
         }
         __syncthreads();
@@ -1430,9 +1629,39 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
     const DevPat &P = c_pat[ps];
     if (threadIdx.x == 0) { g_S.fl[FL_FATAL] = 0; g_S.wi.n_factor = 0; g_S.dyn_delta = 0.; g_S.dyn_eps = 0.; for (int k = 0; k < 12; k++) g_S.tick[k] = 0; }
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
+    if (P.tile) { // launched with the solve kernel's dynamic LDS size: the per-wave scratch sits at the same offset
+        for (int t = threadIdx.x; t < (P.nb + P.nt) * 256; t += T) Kt[t] = 0.;
+        __syncthreads();
+        for (int e = threadIdx.x; e < P.tl_nimg; e += T) Kt[P.tl_img_dst[e]] = I[P.tl_img_src[e]];
+        __syncthreads();
+        stage_factor_tiles<T, 0>(ps, I, (gdbl_p)work, -1);
+        return;
+    }
     for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
     __syncthreads();
     stage_factor<T, 0, false>(ps, I, (gdbl_p)work, -1);
+}
+
+// Debug: the solver's own residual/scaling stage (updateScalings + updateKKTScalings, ref :1160-1162) on instance `i`
+// with the given (s, z) in its slab, x = y = 0, tau = kap = 1, as pass 0 of the main loop.  ok[0] = 1 if the stage went
+// on to the factorisation (i.e. the scalings were executed).  The cone state of workspace 0 persists between calls.
+template <int T>
+__global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps, double *inst, double *work, int i, int *ok) {
+    const DevPat &P = c_pat[ps];
+    gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride;
+    if (threadIdx.x == 0) {
+        g_S.wi = DevInfo{}; g_S.wi.tau = 1.; g_S.wi.kap = 1.; g_S.bi = g_S.wi;
+        for (int k = 0; k < SV_COUNT; k++) g_S.sv[k] = 1.;
+        g_S.sv[SV_PRESPREV] = DBL_MAX;
+        for (int k = 0; k < FL_COUNT; k++) g_S.fl[k] = 0;
+        for (int k = 0; k < 12; k++) g_S.tick[k] = 0;
+        g_S.dyn_delta = 0.; g_S.dyn_eps = 0.;
+    }
+    for (int j = threadIdx.x; j < P.n; j += T) I[P.i_x + j] = 0.;
+    for (int j = threadIdx.x; j < P.p; j += T) I[P.i_y + j] = 0.;
+    __syncthreads();
+    const int st = stage_resid<T, 0, false>(ps, I, (gdbl_p)work, 0);
+    if (threadIdx.x == 0) ok[0] = (st == ST_FACTOR) ? 1 : 0;
 }
 
 // ---- launchers (called from api.cpp) ----
@@ -1474,11 +1703,21 @@ hipError_t launch_update(int ps, double *inst, int first, int count, const doubl
     hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
     return hipGetLastError();
 }
-hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int threads, hipStream_t st) {
+hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int threads, size_t dyn_lds, hipStream_t st) {
+    auto big = [&](const void *fn) { if (dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds); };
     switch (threads) { // the factor program is built for the handle's workgroup size
-    case 128: hipLaunchKernelGGL(k_debug_factor<128>, dim3(1), dim3(128), 0, st, ps, inst, work, i); break;
-    case 256: hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), 0, st, ps, inst, work, i); break;
-    case 512: hipLaunchKernelGGL(k_debug_factor<512>, dim3(1), dim3(512), 0, st, ps, inst, work, i); break;
+    case 128: big((const void *)k_debug_factor<128>); hipLaunchKernelGGL(k_debug_factor<128>, dim3(1), dim3(128), dyn_lds, st, ps, inst, work, i); break;
+    case 256: big((const void *)k_debug_factor<256>); hipLaunchKernelGGL(k_debug_factor<256>, dim3(1), dim3(256), dyn_lds, st, ps, inst, work, i); break;
+    case 512: big((const void *)k_debug_factor<512>); hipLaunchKernelGGL(k_debug_factor<512>, dim3(1), dim3(512), dyn_lds, st, ps, inst, work, i); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_debug_scalings(int ps, double *inst, double *work, int i, int *ok, int threads, hipStream_t st) {
+    switch (threads) {
+    case 128: hipLaunchKernelGGL(k_debug_scalings<128>, dim3(1), dim3(128), 0, st, ps, inst, work, i, ok); break;
+    case 256: hipLaunchKernelGGL(k_debug_scalings<256>, dim3(1), dim3(256), 0, st, ps, inst, work, i, ok); break;
+    case 512: hipLaunchKernelGGL(k_debug_scalings<512>, dim3(1), dim3(512), 0, st, ps, inst, work, i, ok); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

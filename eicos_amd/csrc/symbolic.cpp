@@ -99,27 +99,53 @@ void etree_rows(int N, const std::vector<ivec> &up, ivec &parent, std::vector<iv
 
 } // namespace
 
-static Symbolic analyze_mode(const ProblemPattern &P, int order_mode);
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program);
 
 // order_mode < 0: try several slacks and keep the cheapest under a simple cost model:
 // every level costs the GPU one workgroup barrier + a dependent memory round trip, which is
 // priced here like LEVEL_COST entries of L.
-Symbolic analyze(const ProblemPattern &P, int order_mode) {
-    if (order_mode >= 0) return analyze_mode(P, order_mode);
+Symbolic analyze(const ProblemPattern &P, int order_mode, int tile) {
+    const std::vector<int> modes = order_mode >= 0 ? std::vector<int>{order_mode} : std::vector<int>{1, 2, 3, 4, 6};
     constexpr double LEVEL_COST = 64.0;
+    int best_mode = modes[0];
+    if (tile != 1) { // structure only (no factor program): pick the ordering, see how dense L is
+        double best_cost = -1;
+        long long best_nnzL = 0;
+        const int N = P.n + P.p + P.m + 2 * P.nc;
+        for (int mode : modes) {
+            Symbolic S = analyze_mode(P, mode, false, false);
+            const double cost = S.nnzL + LEVEL_COST * S.nlev;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_mode = mode; best_nnzL = S.nnzL; }
+        }
+        if (tile < 0) tile = (N > 0 && best_nnzL >= 16LL * N) ? 1 : 0; // ~16+ entries per column of L: dense fronts
+        if (tile == 0) return analyze_mode(P, best_mode, false, true);
+    }
+    // tile path: the cost is the number of 16 x 16 tiles (bytes streamed per solve) plus the block levels (barriers)
     Symbolic best;
     double best_cost = -1;
-    for (int mode : {1, 2, 3, 4, 6}) {
-        Symbolic S = analyze_mode(P, mode);
-        const double cost = S.nnzL + LEVEL_COST * S.nlev;
+    for (int mode : modes) {
+        Symbolic S = analyze_mode(P, mode, true, false);
+        long long nt = 0;
+        { // count the off-diagonal tiles of L
+            std::vector<int> blk(S.N);
+            for (int b = 0; b < S.nblk; b++) for (int k = S.blk_ptr[b]; k < S.blk_ptr[b + 1]; k++) blk[k] = b;
+            std::vector<int> last(S.nblk, -1);
+            for (int j = 0; j < S.N; j++)
+                for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
+                    const int I = blk[S.Li[e]], J = blk[j];
+                    if (I != J && last[I] != J) { last[I] = J; nt++; } // rows of a column ascend: one hit per (I, J) run
+                }
+        }
+        const double cost = (double)nt + (double)S.nblk + 4.0 * S.nblev;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = std::move(S); }
     }
     return best;
 }
 
-static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program) {
     Symbolic S;
     S.order_mode = order_mode;
+    S.tile = tile ? 1 : 0;
     S.n = P.n; S.p = P.p; S.m = P.m; S.nc = P.nc; S.q = P.q;
     int qsum = 0;
     for (int d : P.q) { if (d < 1) throw std::invalid_argument("cone dimension < 1"); qsum += d; }
@@ -169,27 +195,26 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
     ivec perm0 = order_min_degree(N, S.K_row, S.K_col, order_mode);
     ivec iperm0(N);
     for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
-    {
-        auto up = permuted_upper(N, S.K_row, S.K_col, iperm0);
-        ivec par; etree_rows(N, up, par, nullptr);
-        ivec level(N, 0);
-        for (int k = 0; k < N; k++) if (par[k] >= 0) level[par[k]] = std::max(level[par[k]], level[k] + 1);
-        ivec idx(N); std::iota(idx.begin(), idx.end(), 0);
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level[a] < level[b]; });
-        S.perm.resize(N); S.iperm.resize(N);
-        for (int k = 0; k < N; k++) { S.perm[k] = perm0[idx[k]]; S.iperm[S.perm[k]] = k; }
-        S.nlev = N ? level[idx[N - 1]] + 1 : 0;
-        S.lev_ptr.assign(S.nlev + 1, 0);
-        for (int k = 0; k < N; k++) S.lev_ptr[level[idx[k]] + 1]++;
-        for (int v = 0; v < S.nlev; v++) S.lev_ptr[v + 1] += S.lev_ptr[v];
-    }
-
-    // ---- L pattern under the final ordering ----
-    // Inside a level the numbering is free (any topological order of the tree gives the same
-    // fill): sort each level by decreasing row length of L so that the sliced-ELL structures of
-    // the GPU triangular solves (rows of one slice share a lanes-per-row factor) pad little.
     std::vector<ivec> rows;
-    {
+    if (!tile) {
+        {
+            auto up = permuted_upper(N, S.K_row, S.K_col, iperm0);
+            ivec par; etree_rows(N, up, par, nullptr);
+            ivec level(N, 0);
+            for (int k = 0; k < N; k++) if (par[k] >= 0) level[par[k]] = std::max(level[par[k]], level[k] + 1);
+            ivec idx(N); std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level[a] < level[b]; });
+            S.perm.resize(N); S.iperm.resize(N);
+            for (int k = 0; k < N; k++) { S.perm[k] = perm0[idx[k]]; S.iperm[S.perm[k]] = k; }
+            S.nlev = N ? level[idx[N - 1]] + 1 : 0;
+            S.lev_ptr.assign(S.nlev + 1, 0);
+            for (int k = 0; k < N; k++) S.lev_ptr[level[idx[k]] + 1]++;
+            for (int v = 0; v < S.nlev; v++) S.lev_ptr[v + 1] += S.lev_ptr[v];
+        }
+        // ---- L pattern under the final ordering ----
+        // Inside a level the numbering is free (any topological order of the tree gives the same
+        // fill): sort each level by decreasing row length of L so that the sliced-ELL structures of
+        // the GPU triangular solves (rows of one slice share a lanes-per-row factor) pad little.
         auto up = permuted_upper(N, S.K_row, S.K_col, S.iperm);
         etree_rows(N, up, S.parent, &rows);
         ivec idx(N); std::iota(idx.begin(), idx.end(), 0);
@@ -200,6 +225,72 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
         for (int k = 0; k < N; k++) perm2[k] = S.perm[idx[k]];
         S.perm = perm2;
         for (int k = 0; k < N; k++) S.iperm[S.perm[k]] = k;
+        auto up2 = permuted_upper(N, S.K_row, S.K_col, S.iperm);
+        etree_rows(N, up2, S.parent, &rows);
+    } else {
+        // ---- tile mode: postorder of the elimination tree (subtrees, hence supernodes, become contiguous), cut into
+        // blocks of <= 16 nodes at supernode boundaries, blocks renumbered by their level in the block dependency graph.
+        // Every step is a topological reordering of the elimination tree, so the fill of the min-degree order is kept.
+        ivec par;
+        { auto up = permuted_upper(N, S.K_row, S.K_col, iperm0); etree_rows(N, up, par, nullptr); }
+        ivec post; post.reserve(N);
+        {
+            std::vector<ivec> kids(N);
+            ivec roots;
+            for (int k = 0; k < N; k++) (par[k] >= 0 ? kids[par[k]] : roots).push_back(k);
+            ivec stack, it(N, 0);
+            for (int r : roots) {
+                stack.push_back(r);
+                while (!stack.empty()) {
+                    const int v = stack.back();
+                    if (it[v] < (int)kids[v].size()) stack.push_back(kids[v][it[v]++]);
+                    else { post.push_back(v); stack.pop_back(); }
+                }
+            }
+        }
+        ivec perm1(N), iperm1(N);
+        for (int k = 0; k < N; k++) { perm1[k] = perm0[post[k]]; iperm1[perm1[k]] = k; }
+        ivec par1;
+        { auto up = permuted_upper(N, S.K_row, S.K_col, iperm1); etree_rows(N, up, par1, &rows); }
+        std::vector<ivec> cols(N); // structure of column j of L (rows > j), ascending
+        for (int i = 0; i < N; i++) for (int j : rows[i]) cols[j].push_back(i);
+        // supernodes: node k joins node k-1 when struct(k-1) \ {k} == struct(k) (a chain of the tree: fundamental
+        // supernode) or struct(k-1) == struct(k) (siblings with one common front, e.g. the rows of one second-order cone)
+        auto joins = [&](int a, int b) {
+            const ivec &ca = cols[a], &cb = cols[b];
+            if (ca.size() == cb.size()) return ca == cb;
+            if (ca.size() == cb.size() + 1 && !ca.empty() && ca[0] == b) return std::equal(cb.begin(), cb.end(), ca.begin() + 1);
+            return false;
+        };
+        ivec blk_start; // first node of every block
+        for (int k = 0, run = 0; k < N; k++) {
+            if (k == 0 || !joins(k - 1, k) || run == 16) { blk_start.push_back(k); run = 0; }
+            run++;
+        }
+        const int nb = (int)blk_start.size();
+        blk_start.push_back(N);
+        ivec blk(N);
+        for (int b = 0; b < nb; b++) for (int k = blk_start[b]; k < blk_start[b + 1]; k++) blk[k] = b;
+        ivec blev(nb, 0);
+        for (int i = 0; i < N; i++)
+            for (int j : rows[i]) if (blk[j] != blk[i]) blev[blk[i]] = std::max(blev[blk[i]], blev[blk[j]] + 1); // blocks ascend
+        ivec bidx(nb); std::iota(bidx.begin(), bidx.end(), 0);
+        std::stable_sort(bidx.begin(), bidx.end(), [&](int a, int b) { return blev[a] < blev[b]; });
+        S.nblk = nb; S.nblev = nb ? blev[bidx[nb - 1]] + 1 : 0;
+        S.blk_ptr.assign(1, 0); S.blev_ptr.assign(S.nblev + 1, 0);
+        S.perm.resize(N); S.iperm.resize(N);
+        int pos = 0;
+        for (int q = 0; q < nb; q++) {
+            const int b = bidx[q];
+            for (int k = blk_start[b]; k < blk_start[b + 1]; k++) S.perm[pos++] = perm1[k];
+            S.blk_ptr.push_back(pos);
+            S.blev_ptr[blev[b] + 1] = q + 1;
+        }
+        for (int v = 0; v < S.nblev; v++) S.blev_ptr[v + 1] = std::max(S.blev_ptr[v + 1], S.blev_ptr[v]);
+        for (int k = 0; k < N; k++) S.iperm[S.perm[k]] = k;
+        S.nlev = S.nblev; // node ranges of the block levels
+        S.lev_ptr.assign(S.nlev + 1, 0);
+        for (int v = 0; v < S.nblev; v++) S.lev_ptr[v + 1] = S.blk_ptr[S.blev_ptr[v + 1]];
         auto up2 = permuted_upper(N, S.K_row, S.K_col, S.iperm);
         etree_rows(N, up2, S.parent, &rows);
     }
@@ -236,6 +327,12 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
         else { int pos = find_csc(std::max(a, b), std::min(a, b)); S.Lkind[pos] = S.K_kind[e]; S.Lsrc[pos] = S.K_src[e]; }
     }
 
+    if (tile || !program) { // tile mode has its own (tile-level) program, tiles.cpp; structure-only calls need none
+        int64_t np = 0;
+        for (int k = 0; k < N; k++) { int64_t c = S.Lp[k + 1] - S.Lp[k]; np += c * (c + 1) / 2; }
+        S.npairs = np; S.flops_factor = 3.0 * (double)np + N;
+        return S;
+    }
     // ---- factor program ----
     const int64_t NT = (int64_t)N + S.nnzL;
     S.tp.assign(NT + 1, 0);
@@ -253,7 +350,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode) {
     for (int k = 0; k < N; k++) { int64_t c = S.Lp[k + 1] - S.Lp[k]; np += c * (c + 1) / 2; }
     S.npairs = np;
     if (np > (int64_t)400 * 1000 * 1000)
-        throw std::runtime_error("symbolic: factor program too large (dense fronts need the supernodal path)");
+        throw std::runtime_error("symbolic: scalar factor program too large for a sparse pattern (> 4e8 multiply-subtract pairs)");
     for_each_pair([&](int64_t t, int, int, int) { S.tp[t + 1]++; });
     for (int64_t t = 0; t < NT; t++) S.tp[t + 1] += S.tp[t];
     S.pa.resize(np); S.pb.resize(np); S.pk.resize(np);

@@ -52,11 +52,19 @@ struct Symbolic {
     double flops_factor = 0;            // 2*npairs + divisions
     int max_row_len = 0, max_col_len = 0;
     int order_mode = 0;                 // slack+1 actually used
+    // ---- tile mode (patterns with dense fronts; tiles.hpp): the elimination order is an etree postorder cut into
+    // blocks of <= 16 consecutive nodes aligned with the supernodes, blocks renumbered by block level.  L is then a
+    // block-sparse matrix of dense 16 x 16 tiles; the scalar factor program (tp/pa/pb/pk, ftask) is not built.
+    int tile = 0;
+    int nblk = 0, nblev = 0;
+    std::vector<int> blk_ptr;           // nblk+1: node range of each block
+    std::vector<int> blev_ptr;          // nblev+1: block range of each block level
 };
 
 // order_mode: 0 = minimum degree, ties by index (sequential; deep trees)
 //             k>=1 = multiple independent elimination of nodes within k-1 of the minimum degree
 //             <0 = try several k, keep the best under a fill + tree-height cost model (default)
-Symbolic analyze(const ProblemPattern &P, int order_mode = -1);
+// tile: 0 = scalar (sliced-ELL) path, 1 = tile path, < 0 = choose: tiles when L is dense (nnz(L) >= 16 dim_K)
+Symbolic analyze(const ProblemPattern &P, int order_mode = -1, int tile = -1);
 
 } // namespace eicos

@@ -1,0 +1,105 @@
+// Host-side construction of the tile plan (see tiles.hpp).  Plain C++17, no GPU code.
+#include "tiles.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+
+namespace eicos {
+
+TilePlan build_tile_plan(const Symbolic &S) {
+    if (!S.tile) throw std::logic_error("tile plan requested for a scalar-mode analysis");
+    TilePlan T;
+    const int N = S.N, nb = S.nblk;
+    T.nb = nb; T.N16 = 16 * nb; T.nblev = S.nblev; T.blev_ptr = S.blev_ptr;
+    std::vector<int> blk(N), off(N);
+    T.slot.resize(N);
+    for (int b = 0; b < nb; b++) {
+        if (S.blk_ptr[b + 1] - S.blk_ptr[b] > 16 || S.blk_ptr[b + 1] <= S.blk_ptr[b]) throw std::logic_error("tile plan: bad block size");
+        for (int k = S.blk_ptr[b]; k < S.blk_ptr[b + 1]; k++) { blk[k] = b; off[k] = k - S.blk_ptr[b]; T.slot[k] = 16 * b + off[k]; }
+    }
+    // ---- tiles from the scalar pattern of L (CSC: column j, rows ascending) ----
+    std::vector<std::vector<int>> colrows(nb);
+    for (int j = 0; j < N; j++)
+        for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) if (blk[S.Li[e]] != blk[j]) colrows[blk[j]].push_back(blk[S.Li[e]]);
+    T.tc_ptr.assign(nb + 1, 0);
+    for (int J = 0; J < nb; J++) {
+        auto &v = colrows[J];
+        std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+        for (int I : v) { if (I <= J) throw std::logic_error("tile plan: tile above the diagonal"); T.t_row.push_back(I); T.t_col.push_back(J); }
+        T.tc_ptr[J + 1] = (int)T.t_row.size();
+    }
+    T.nt = (int)T.t_row.size();
+    auto tile_of = [&](int I, int J) { // id of tile (I, J), I > J; -1 if absent
+        auto b = T.t_row.begin() + T.tc_ptr[J], e = T.t_row.begin() + T.tc_ptr[J + 1];
+        auto it = std::lower_bound(b, e, I);
+        return (it == e || *it != I) ? -1 : (int)(it - T.t_row.begin());
+    };
+    T.tr_ptr.assign(nb + 1, 0);
+    for (int t = 0; t < T.nt; t++) T.tr_ptr[T.t_row[t] + 1]++;
+    for (int I = 0; I < nb; I++) T.tr_ptr[I + 1] += T.tr_ptr[I];
+    T.tr_tile.resize(T.nt);
+    { std::vector<int> next(T.tr_ptr.begin(), T.tr_ptr.end() - 1); for (int t = 0; t < T.nt; t++) T.tr_tile[next[T.t_row[t]]++] = t; } // CSC order => ascending column
+
+    // ---- block levels must be consistent with the tiles: every tile (I, J) has level(I) > level(J) ----
+    std::vector<int> lev(nb, 0);
+    for (int v = 0; v < T.nblev; v++) for (int b = T.blev_ptr[v]; b < T.blev_ptr[v + 1]; b++) lev[b] = v;
+    for (int t = 0; t < T.nt; t++) if (lev[T.t_row[t]] <= lev[T.t_col[t]]) throw std::logic_error("tile plan: level order violated");
+
+    // ---- factor program: pairs per target ----
+    // source block column K with tile rows R = [I1 < I2 < ...]: target (R[b], R[a]) for a <= b gets the pair
+    // (tile(R[b], K), tile(R[a], K)); a target tile that is structurally absent receives exact zeros only (every term has a
+    // structurally zero factor) and is skipped.
+    const int ntgt = nb + T.nt;
+    std::vector<int> cnt(ntgt + 1, 0);
+    auto for_each_pair = [&](auto &&fn) {
+        for (int K = 0; K < nb; K++) {
+            const int b0 = T.tc_ptr[K], b1 = T.tc_ptr[K + 1];
+            for (int a = b0; a < b1; a++) {
+                fn(T.t_row[a], a, a, K); // diagonal target of block row(a)
+                for (int b = a + 1; b < b1; b++) { const int t = tile_of(T.t_row[b], T.t_row[a]); if (t >= 0) fn(nb + t, b, a, K); }
+            }
+        }
+    };
+    for_each_pair([&](int tg, int, int, int) { cnt[tg + 1]++; });
+    for (int q = 0; q < ntgt; q++) cnt[q + 1] += cnt[q];
+    std::vector<int> pa0(cnt[ntgt]), pb0(cnt[ntgt]), pk0(cnt[ntgt]);
+    { std::vector<int> next(cnt.begin(), cnt.end() - 1); for_each_pair([&](int tg, int a, int b, int K) { const int d = next[tg]++; pa0[d] = a; pb0[d] = b; pk0[d] = K; }); }
+    T.npairs = cnt[ntgt];
+    // execution order: per level, the diagonal and off-diagonal targets of its block columns, longest first
+    T.tgt_lev_ptr.assign(1, 0); T.fin_lev_ptr.assign(1, 0); T.tp_ptr.assign(1, 0);
+    for (int v = 0; v < T.nblev; v++) {
+        const size_t start = T.tgt.size();
+        for (int J = T.blev_ptr[v]; J < T.blev_ptr[v + 1]; J++) {
+            T.tgt.push_back(J);
+            for (int t = T.tc_ptr[J]; t < T.tc_ptr[J + 1]; t++) { T.tgt.push_back(nb + t); T.fin.push_back(t); }
+        }
+        std::stable_sort(T.tgt.begin() + start, T.tgt.end(), [&](int a, int b) { return cnt[a + 1] - cnt[a] > cnt[b + 1] - cnt[b]; });
+        T.tgt_lev_ptr.push_back((int)T.tgt.size());
+        T.fin_lev_ptr.push_back((int)T.fin.size());
+    }
+    for (int tg : T.tgt) {
+        for (int d = cnt[tg]; d < cnt[tg + 1]; d++) { T.pa.push_back(pa0[d]); T.pb.push_back(pb0[d]); T.pk.push_back(pk0[d]); }
+        T.tp_ptr.push_back((int)T.pa.size());
+    }
+
+    // ---- where every scalar entry lives ----
+    T.Le_img.resize(S.nnzL); T.Le_tile.resize(S.nnzL); T.Le_rc.resize(S.nnzL); T.D_img.resize(N);
+    for (int j = 0; j < N; j++) {
+        T.D_img[j] = blk[j] * 256 + off[j] * 16 + off[j];
+        for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
+            const int i = S.Li[e], I = blk[i], J = blk[j];
+            if (I == J) { T.Le_tile[e] = -1 - J; T.Le_rc[e] = off[i] * 16 + off[j]; T.Le_img[e] = J * 256 + off[i] * 16 + off[j]; }
+            else {
+                const int t = tile_of(I, J);
+                if (t < 0) throw std::logic_error("tile plan: entry without a tile");
+                T.Le_tile[e] = t; T.Le_rc[e] = off[i] * 16 + off[j]; T.Le_img[e] = (nb + t) * 256 + off[i] * 16 + off[j];
+            }
+        }
+    }
+    for (int b = 0; b < nb; b++)
+        for (int o = S.blk_ptr[b + 1] - S.blk_ptr[b]; o < 16; o++) T.pad_img.push_back(b * 256 + o * 16 + o);
+    return T;
+}
+
+} // namespace eicos

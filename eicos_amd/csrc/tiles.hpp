@@ -1,0 +1,46 @@
+// Tile plan of the dense-front path: L as a block-sparse matrix of dense 16 x 16 fp64 tiles.
+//
+// Replaces, for patterns whose factor is dense (second-order cones of large dimension create dense fronts through
+// the two expansion columns per cone, reference src/eicos.cpp:1848-1876), the scalar sliced-ELL programs of plans.hpp:
+//   * numeric LDL' (reference ldlt.factorize, src/eicos.cpp:900,1164) = left-looking block factorisation; every
+//     update  T_IJ -= L_IK D_K L_JK'  is a 16 x 16 x 16 product = four v_mfma_f64_16x16x4_f64;
+//   * the two triangular sweeps (reference ldlt.solve, :1477,1599) = dense 16 x 16 tile mat-vecs, level-scheduled over
+//     the BLOCK dependency graph (an order of magnitude fewer levels than the scalar elimination tree).
+// Blocks hold <= 16 consecutive elimination positions (Symbolic::blk_ptr) and are padded to 16: padding nodes are
+// identity rows (D = 1, no coupling), so kernels never see ragged tiles.  KKT-space vectors live in the padded order:
+// slot(node k of block b at offset o) = 16 b + o.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "symbolic.hpp"
+
+namespace eicos {
+
+struct TilePlan {
+    int nb = 0, nt = 0, nblev = 0; // blocks, off-diagonal tiles, block levels
+    int N16 = 0;                   // 16 * nb: length of the KKT-space vectors in padded elimination order
+    std::vector<int> slot;         // elimination position -> slot in the padded order
+    std::vector<int> blev_ptr;     // nblev+1: block range per level (copy of Symbolic::blev_ptr)
+    // off-diagonal tiles, CSC by block column (rows ascending); tile t = (t_row[t], t_col[t])
+    std::vector<int> tc_ptr, t_row, t_col;
+    // CSR view for the forward sweep: tiles of block row I, ascending block column
+    std::vector<int> tr_ptr, tr_tile;
+    // factor program.  Targets in execution order, level by level, longest pair list first inside a level:
+    // tgt[q] < nb: diagonal tile of block tgt[q]; otherwise off-diagonal tile tgt[q] - nb.
+    std::vector<int> tgt, tgt_lev_ptr /* nblev+1 */, tp_ptr /* ntgt+1 */;
+    std::vector<int> pa, pb, pk;   // pair: T -= L(pa) D(pk) L(pb)' with tiles pa = (I,K), pb = (J,K), source block pk = K
+    // off-diagonal targets of every level again (second phase: L_IJ = T_IJ Linv_JJ' / D_J), level ranges in fin_lev_ptr
+    std::vector<int> fin, fin_lev_ptr;
+    // KKT entries -> dense image Kt = [nb diagonal tiles | nt off-diagonal tiles], 256 doubles each, ROW-major
+    // (row, col) = (r, c) at 16 r + c; only the lower triangle of diagonal tiles is filled.
+    // Per permuted entry: L entry e (CSC order of Symbolic) -> Le_img[e]; diagonal j -> D_img[j]; padding diagonals (value 1)
+    std::vector<int> Le_img, D_img, pad_img;
+    // scalar entry of L (CSC e) -> its tile value position: tile id and in-tile (r, c); for the debug hooks
+    std::vector<int> Le_tile, Le_rc;
+    int64_t npairs = 0;
+};
+
+TilePlan build_tile_plan(const Symbolic &S);
+
+} // namespace eicos

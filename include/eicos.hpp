@@ -111,7 +111,7 @@ namespace EiCOS
                     const int *Gjc, const int *Gir, const int *Ajc, const int *Air, int batch, int device = -1)
             : n_(n), m_(m), p_(p), batch_(batch)
         {
-            detail::check(eicos_batch_create(n, m, p, 0, ncones, q, Gjc, Gir, Ajc, Air, batch, device, &h_), "eicos_batch_create");
+            detail::check(eicos_batch_create(n, m, p, -1, ncones, q, Gjc, Gir, Ajc, Air, batch, device, &h_), "eicos_batch_create");
             eicos_dims d; eicos_batch_dims(h_, &d);
             n_ = d.n; m_ = d.m; p_ = d.p;
         }
@@ -174,12 +174,12 @@ namespace EiCOS
         {
             const bool haveG = Gpr && Gjc && Gir, haveA = Apr && Ajc && Air;
             if (!c) n = 0;
-            detail::check(eicos_batch_create(n, haveG ? m : 0, haveA ? p : 0, 0, haveG ? ncones : 0, q,
+            detail::check(eicos_batch_create(n, haveG ? m : 0, haveA ? p : 0, -1 /* derived, ref src/eicos.cpp:91 */, haveG ? ncones : 0, q,
                                              haveG ? Gjc : nullptr, haveG ? Gir : nullptr,
                                              haveA ? Ajc : nullptr, haveA ? Air : nullptr, 1, -1, &h_),
                           "eicos_batch_create");
             eicos_dims d; eicos_batch_dims(h_, &d);
-            x_.assign(d.n, 0.0);
+            resize_solution(d.n);
             // first data set: every group that exists must be supplied
             static double dummy = 0.0;
             detail::check(eicos_batch_update(h_, 0, 1, haveG ? Gpr : nullptr, haveA ? Apr : nullptr,
@@ -224,18 +224,22 @@ namespace EiCOS
             eicos_info raw;
             if (eicos_batch_info(h_, &raw) != EICOS_OK) return exitcode::fatal;
             info_ = Information::from(raw);
-            if (!x_.empty()) eicos_batch_solution(h_, x_.data());
+            if (x_.size() > 0) eicos_batch_solution(h_, x_.data());
             if (verbose)
                 std::printf("EiCOS(MI355X): exit %d after %d iterations, pcost %.9g dcost %.9g pres %.1e dres %.1e gap %.1e\n",
                             code, raw.iter, raw.pcost, raw.dcost, raw.pres, raw.dres, raw.gap);
             return static_cast<exitcode>(code);
         }
 
-        // reference returns const Eigen::VectorXd& (include/eicos.hpp:160); without Eigen a std::vector
-        const std::vector<double> &solution() const { return x_; }
+        // reference include/eicos.hpp:160: `const Eigen::VectorXd &solution() const` -- a reference to solver-owned
+        // storage, valid until the next solve() / destruction.  Same type when Eigen is available; without Eigen
+        // (raw-pointer callers only) the storage is a std::vector<double>.
 #ifdef EICOS_HAVE_EIGEN
-        Eigen::Map<const Eigen::VectorXd> solutionEigen() const { return {x_.data(), Eigen::Index(x_.size())}; }
+        using SolutionVector = Eigen::VectorXd;
+#else
+        using SolutionVector = std::vector<double>;
 #endif
+        const SolutionVector &solution() const { return x_; }
         Settings &getSettings() { return settings_; }
         const Information &getInfo() const { return info_; }
         // Extension (not in the reference, which cold-starts every solve): warm-start the next solves after updateData
@@ -246,7 +250,15 @@ namespace EiCOS
         eicos_batch *h_ = nullptr;
         Settings settings_;
         Information info_;
-        std::vector<double> x_;
+        SolutionVector x_;
+        void resize_solution(int n)
+        {
+#ifdef EICOS_HAVE_EIGEN
+            x_.setZero(n);
+#else
+            x_.assign((size_t)n, 0.0);
+#endif
+        }
     };
 
 } // namespace EiCOS

@@ -66,8 +66,10 @@ typedef struct eicos_dims {
 
 /* ---- construction: replaces Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)
  * (reference include/eicos.hpp:151-154, src/eicos.cpp:91-120) + build() (:132-187), for a
- * whole batch.  Pattern only; values arrive through eicos_batch_update*.  `l` is ignored as in
- * the reference (src/eicos.cpp:91); NULL Gjc/Gir (or Ajc/Air) mean "no G" ("no A").
+ * whole batch.  Pattern only; values arrive through eicos_batch_update*.  The reference ignores `l`
+ * and derives it as m - sum(q) (src/eicos.cpp:91,155): pass l < 0 for exactly that; l >= 0 is checked
+ * (l + sum(q) must equal m, else EICOS_E_INVALID).  The arrays are trusted to hold n+1 column pointers,
+ * jc[n] row indices and ncones cone sizes.  NULL Gjc/Gir (or Ajc/Air) mean "no G" ("no A").
  * device < 0 selects the current HIP device. */
 int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
                        const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
@@ -158,11 +160,23 @@ int eicos_debug_factor(eicos_batch *hd, int inst, double *D /*[dim_K], permuted*
  * kap/tau,mu,step,sigma,tau,kap,nitref3} per IPM pass (valid while batch <= resident workgroups). */
 int eicos_debug_trace(eicos_batch *hd, int inst, double *out);
 int eicos_debug_pattern(eicos_batch *hd, int *perm /*[dim_K]*/, int *Lp /*[dim_K+1]*/, int *Li /*[nnzL]*/);
+/* upper triangle of instance `inst`'s KKT matrix as the numeric factorisation reads it (equilibrated A/G values,
+ * scaling block, +-delta), coordinate form in the reference's column layout (src/eicos.cpp:1734-1890); each [nnzK] */
+int eicos_debug_kkt(eicos_batch *hd, int inst, int *rows, int *cols, double *vals);
+/* the solver's own updateScalings + updateKKTScalings stage (reference src/eicos.cpp:1160-1162) for a given (s, z):
+ * V[l + sum(3 q_i + 1)] = scaling block of K in the slot order of reference cacheIndices (:1944-1987); *ran = 1 if
+ * the stage reached the scalings.  The cone state persists between calls, as it does between iterations. */
+int eicos_debug_scalings(eicos_batch *hd, int inst, const double *s, const double *z, double *V, int *ran);
 
 /* Host-only self check of the symbolic analysis + factor/solve programs (no GPU needed):
  * returns ||K x - b||_inf / ||b||_inf for random quasi-definite values, < 0 on error. */
 double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
                               const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats);
+
+/* the same for the tile (dense-front) path: block factorisation over 16 x 16 tiles + tile sweeps emulated on the host
+ * with the device's index structures; stats = {dim_K, nnzK, nnzL, block levels, tile pairs, order_mode, blocks, tiles} */
+double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                    const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats);
 
 #ifdef __cplusplus
 }

@@ -973,6 +973,26 @@ void oracle_set_dynamic_regularization(void *s, double delta, double eps) {
 }
 void oracle_destroy(void *s) { delete static_cast<Solver *>(s); }
 
+/* Test hook: what solve() does at ref :1160-1162 for given (s, z): updateScalings (return value ignored) followed
+ * by updateKKTScalings; V_out receives the scaling block of K in the slot order of ref cacheIndices :1944-1987.
+ * The cone structs keep their state between calls, as they do between iterations.  Returns updateScalings' bool. */
+int oracle_debug_scalings(void *sv, const double *s_in, const double *z_in, double *V_out) {
+    Solver *S = static_cast<Solver *>(sv);
+    vec s(s_in, s_in + S->m), z(z_in, z_in + S->m), lam(S->m, 0.0);
+    const bool ok = S->update_scalings(s, z, lam);
+    S->update_kkt_scalings();
+    for (size_t k = 0; k < S->slotV.size(); k++) V_out[k] = S->K.val[S->slotV[k]];
+    return ok ? 1 : 0;
+}
+/* Test hook: the KKT matrix as it stands (upper triangle, CSC, reference column layout ref :1734-1890). */
+int oracle_debug_kkt(void *sv, int *Kp, int *Ki, double *Kx) {
+    Solver *S = static_cast<Solver *>(sv);
+    if (Kp) std::copy(S->K.ptr.begin(), S->K.ptr.end(), Kp);
+    if (Ki) std::copy(S->K.idx.begin(), S->K.idx.end(), Ki);
+    if (Kx) std::copy(S->K.val.begin(), S->K.val.end(), Kx);
+    return S->K.nnz();
+}
+
 double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,
                           const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                           int batch, const double *Gpr, const double *Apr,

@@ -51,6 +51,10 @@ void oracle_set_warm_start(void *s, double shift);
 /* N4 (not in the reference): ECOS-style dynamic regularisation of the LDL' pivots; delta = 0 switches it off */
 void oracle_set_dynamic_regularization(void *s, double delta, double eps);
 void oracle_destroy(void *s);
+/* test hooks: updateScalings + updateKKTScalings for a given (s, z) -> scaling block of K in cacheIndices order
+ * (ref :411-479, :1691-1732, :1944-1987); the KKT matrix as it stands (upper CSC; returns nnz) */
+int oracle_debug_scalings(void *s, const double *s_in, const double *z_in, double *V_out);
+int oracle_debug_kkt(void *s, int *Kp, int *Ki, double *Kx);
 
 /* CPU-baseline driver: solve `batch` instances that share one pattern, one instance at a
  * time per thread.  Each thread constructs its solver once (pattern setup, untimed), then all

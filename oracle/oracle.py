@@ -53,6 +53,10 @@ def lib():
         L.oracle_set_dynamic_regularization.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.oracle_get_trace.argtypes = [C.c_void_p, dp, C.c_int]
         L.oracle_get_trace.restype = C.c_int
+        L.oracle_debug_scalings.argtypes = [C.c_void_p, dp, dp, dp]
+        L.oracle_debug_scalings.restype = C.c_int
+        L.oracle_debug_kkt.argtypes = [C.c_void_p, ip, ip, dp]
+        L.oracle_debug_kkt.restype = C.c_int
         L.oracle_batch_solve.restype = C.c_double
         L.oracle_batch_solve.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_int] + [dp] * 5 + [C.c_int, ip, ip, dp, dp, dp,
                                                                                   C.POINTER(C.c_longlong)]
@@ -130,6 +134,22 @@ class OracleSolver:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         lib().oracle_get_dims(self._h, C.byref(a), C.byref(b), C.byref(c))
         return dict(dimK=a.value, nnzK=b.value, nnzL=c.value)
+
+    def debug_scalings(self, s, z):
+        """updateScalings + updateKKTScalings for (s, z): (ok, scaling block of K in cacheIndices order)."""
+        pat = self.pat
+        nV = pat.l + int(sum(3 * int(d) + 1 for d in pat.q))
+        s, z = np.ascontiguousarray(s, np.float64), np.ascontiguousarray(z, np.float64)
+        V = np.zeros(max(nV, 1))
+        ok = lib().oracle_debug_scalings(self._h, _dp(s), _dp(z), _dp(V))
+        return bool(ok), V[:nV]
+
+    def debug_kkt(self):
+        """Upper triangle of the KKT matrix as it stands (CSC: ptr, idx, val), reference column layout."""
+        d = self.dims()
+        Kp, Ki, Kx = np.zeros(d["dimK"] + 1, np.int32), np.zeros(max(d["nnzK"], 1), np.int32), np.zeros(max(d["nnzK"], 1))
+        nnz = lib().oracle_debug_kkt(self._h, _ip(Kp), _ip(Ki), _dp(Kx))
+        return Kp, Ki[:nnz], Kx[:nnz]
 
     def close(self):
         if self._h:

@@ -141,3 +141,32 @@ def test_product_never_references_the_oracle():
     import eicos_amd.binding as b
     src = open(b.__file__).read()
     assert "oracle" not in src
+
+
+def test_cpp_surfaces_compile_including_the_eigen_typed_overloads(tmp_path):
+    # include/eicos.hpp as every kind of caller sees it (compile + link against the library, nothing runs):
+    #  * raw-pointer callers without Eigen (examples/run_demo.cpp), solution() is a std::vector then;
+    #  * the ECOS shim runner (examples/ecos_runner.cpp over include/ecos.h);
+    #  * a caller shaped like the reference's src/run.cpp:11-50 using the Eigen-typed constructor / updateData and
+    #    `const Eigen::VectorXd &solution()` (reference include/eicos.hpp:138-148,160), against the stand-in
+    #    Eigen/Sparse of tests/eigen_standin (Eigen is not installed here) with -Wall -Wextra -Werror.
+    import os, subprocess
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "eicos_amd")
+    inc = os.path.join(ROOT, "include")
+    link = ["-L", lib, "-leicos_amd", "-Wl,-rpath," + lib] if os.path.exists(os.path.join(lib, "libeicos_amd.so")) else ["-c"]
+    base = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc]
+    subprocess.check_call(base + [os.path.join(ROOT, "examples", "run_demo.cpp"), "-o", str(tmp_path / "a")] + link)
+    subprocess.check_call(base + [os.path.join(ROOT, "examples", "ecos_runner.cpp"), "-o", str(tmp_path / "b")] + link)
+    subprocess.check_call(base + ["-I", os.path.join(ROOT, "tests", "eigen_standin"), os.path.join(ROOT, "tests", "cpp", "run_eigen_demo.cpp"),
+                                  "-o", str(tmp_path / "c")] + link)
+    # the return type really is the Eigen vector when Eigen is visible, and a std::vector when it is not
+    probe = tmp_path / "probe.cpp"
+    probe.write_text('#include <type_traits>\n#include "eicos.hpp"\n'
+                     '#ifdef EICOS_HAVE_EIGEN\n'
+                     'static_assert(std::is_same<decltype(std::declval<const EiCOS::Solver&>().solution()), const Eigen::VectorXd&>::value, "");\n'
+                     '#else\n'
+                     'static_assert(std::is_same<decltype(std::declval<const EiCOS::Solver&>().solution()), const std::vector<double>&>::value, "");\n'
+                     '#endif\nint main() { return 0; }\n')
+    subprocess.check_call(base + ["-fsyntax-only", str(probe)])
+    subprocess.check_call(base + ["-fsyntax-only", "-I", os.path.join(ROOT, "tests", "eigen_standin"), str(probe)])

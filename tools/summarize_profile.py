@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output of tools/dev/profile_r1.sh into profiles/<tag>_*.{csv,md}.
 
-usage: python tools/summarize_profile.py gpurun_out/prof_r1 profiles/r01
+usage: python tools/summarize_profile.py gpurun_out/prof_r1 profiles/r01 ["MPC02 batch=1024"]
+The optional third argument names the workload the passes were taken on; together with a hash of the kernel sources
+it is recorded in the JSON so that bench.py only quotes `roofline.traffic` from a summary of the SAME code and workload.
 Per-launch averages of the PMC counters for the solve kernel; FETCH_SIZE/WRITE_SIZE are reported in
 bytes (rocprofv3 reports KiB).  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE counts
 128-B requests of streaming reads at 64 B; tools/dev/calib_fetch.hip (profiles/r01_fetch_calibration.md) confirms
@@ -17,6 +19,9 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "MPC02 batch=1024"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_hash
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 if stats:
@@ -43,6 +48,11 @@ if "SQ_WAVE_CYCLES" in out:
     lines.append(f"wait fraction SQ_WAIT_ANY/SQ_WAVE_CYCLES: {out['SQ_WAIT_ANY']/out['SQ_WAVE_CYCLES']:.3f}")
 if "TCC_HIT_sum" in out:
     lines.append(f"L2 hit rate: {out['TCC_HIT_sum']/(out['TCC_HIT_sum']+out['TCC_MISS_sum']):.3f}")
+out["kernel_source_sha256"] = kernel_source_hash()
+out["workload"] = workload
+lines += ["", f"workload: {workload}", f"kernel sources sha256[:16]: {out['kernel_source_sha256']}",
+          "note: the read factor 2 is calibrated on unit-stride streams only (r01_fetch_calibration.md); k_solve also issues scattered",
+          "8-byte gathers, for which the factor is between 1 and 2 -- read traffic is an upper bound."]
 open(dst + "_pmc.md", "w").write("\n".join(lines) + "\n")
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
 print("\n".join(lines))
