@@ -375,6 +375,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     put(D.tl_img_dst, img_dst); put(D.tl_img_src, img_src); put(D.tl_psign, psign);
     put(D.tl_blev, TP.blev_ptr); put(D.tl_tgt_lev, TP.tgt_lev_ptr); put(D.tl_tgt, TP.tgt); put(D.tl_tp, TP.tp_ptr);
     put(D.tl_pa, TP.pa); put(D.tl_pb, TP.pb); put(D.tl_pk, TP.pk); put(D.tl_fin_lev, TP.fin_lev_ptr); put(D.tl_fin, TP.fin);
+    TileSweeps TSW;
+    if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_PF);
+    put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
+    put(D.tl_ident, TP.ident);
     put(D.tl_trow, TP.t_row); put(D.tl_tcol, TP.t_col); put(D.tl_tc_ptr, TP.tc_ptr); put(D.tl_tr_ptr, TP.tr_ptr); put(D.tl_tr_tile, TP.tr_tile);
     put(D.v2t, v2t);
     const int *fac_sl_p = nullptr;
@@ -395,7 +399,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // launch shape: env overrides are for experiments (bench sweeps); defaults chosen from measurements
     // KKT-space vectors (solve vector, current solution, refinement residual) live in LDS when they fit:
     // 160 KiB per CU minus the static block (reductions + scalar state)
-    D.Npad = (NV + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding
+    D.Npad = tile ? NV + 16 : (NV + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding (tile mode: a whole zero block)
     {
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
@@ -722,17 +726,18 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
             std::vector<double> Ld((size_t)TP.nb * 256, 0.0);
             for (int J = 0; J < TP.nb; J++) {
                 const double *M = DR.data() + (size_t)J * 256; double *Lj = Ld.data() + (size_t)J * 256;
-                for (int c = 0; c < 16; c++)
-                    for (int r = c; r < 16; r++) { // L M = I, column c
+                for (int r = 0; r < 16; r++)
+                    for (int c = r; c >= 0; c--) { // (L M)[r][c] = sum_{k=c..r} L[r][k] M[k][c] = delta_rc with M[c][c] = 1: columns right to left
                         double sacc = (r == c) ? 1.0 : 0.0;
-                        for (int k = c; k < r; k++) sacc -= Lj[r * 16 + k] * M[k * 16 + c];
-                        Lj[r * 16 + c] = sacc; // M[c][c] = 1
+                        for (int k = c + 1; k <= r; k++) sacc -= Lj[r * 16 + k] * M[tile_res(k, c)];
+                        Lj[r * 16 + c] = sacc;
                     }
             }
             std::vector<int> colj(S.nnzL);
             for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colj[e] = j;
             for (int e = 0; e < S.nnzL; e++) {
-                const double lv = TP.Le_tile[e] >= 0 ? LR[(size_t)TP.Le_tile[e] * 256 + TP.Le_rc[e]] : Ld[(size_t)(-1 - TP.Le_tile[e]) * 256 + TP.Le_rc[e]];
+                const int rr = TP.Le_rc[e] >> 4, cc = TP.Le_rc[e] & 15;
+                const double lv = TP.Le_tile[e] >= 0 ? LR[(size_t)TP.Le_tile[e] * 256 + tile_res(rr, cc)] : Ld[(size_t)(-1 - TP.Le_tile[e]) * 256 + rr * 16 + cc];
                 Uout[e] = lv * Dv[TP.slot[colj[e]]];
             }
         }
@@ -967,6 +972,7 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
         if (Ajc && Air) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else { P.Ajc.assign(n + 1, 0); P.p = 0; }
         Symbolic S = analyze(P, order_mode, 1);
         TilePlan TP = build_tile_plan(S);
+        if (getenv("EICOS_PLAN_STATS")) (void)build_tile_sweeps(TP, 8, TILE_PF);
         const int N = S.N, nb = TP.nb, nt = TP.nt, N16 = TP.N16;
         if (stats) { stats[0] = N; stats[1] = S.nnzK; stats[2] = S.nnzL; stats[3] = TP.nblev; stats[4] = (int)std::min<int64_t>(TP.npairs, 2147483647); stats[5] = S.order_mode; stats[6] = nb; stats[7] = nt; }
         unsigned long long st = seed * 2654435761ull + 12345;
@@ -995,12 +1001,12 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
             for (int qi = TP.tgt_lev_ptr[v]; qi < TP.tgt_lev_ptr[v + 1]; qi++) { // phase 1
                 const int tg = TP.tgt[qi];
                 double Tt[16][16];
-                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) Tt[r][c] = img[(size_t)tg * 256 + r * 16 + c];
+                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) Tt[r][c] = img[(size_t)tg * 256 + tile_res(r, c)];
                 for (int e = TP.tp_ptr[qi]; e < TP.tp_ptr[qi + 1]; e++) {
                     const double *A = LC.data() + (size_t)TP.pa[e] * 256, *B = LC.data() + (size_t)TP.pb[e] * 256, *d = D.data() + TP.pk[e] * 16;
-                    for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { double sacc = 0; for (int k = 0; k < 16; k++) sacc += A[k * 16 + r] * (B[k * 16 + c] * d[k]); Tt[r][c] -= sacc; }
+                    for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { double sacc = 0; for (int k = 0; k < 16; k++) sacc += A[tile_op(r, k)] * (B[tile_op(c, k)] * d[k]); Tt[r][c] -= sacc; }
                 }
-                if (tg >= nb) { double *o = LC.data() + (size_t)(tg - nb) * 256; for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) o[c * 16 + r] = Tt[r][c]; continue; }
+                if (tg >= nb) { double *o = LC.data() + (size_t)(tg - nb) * 256; for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) o[tile_op(r, c)] = Tt[r][c]; continue; }
                 const int J = tg;
                 for (int j = 0; j < 16; j++) {
                     const double dj = Tt[j][j];
@@ -1011,7 +1017,7 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
                     D[J * 16 + c] = Tt[c][c]; invD[J * 16 + c] = 1.0 / Tt[c][c];
                     double mc[16];
                     for (int r = 0; r < 16; r++) { double sacc = (r == c) ? 1.0 : 0.0; for (int k = 0; k < r; k++) sacc -= Tt[r][k] * mc[k]; mc[r] = (r < c) ? 0.0 : sacc; }
-                    for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + c * 16 + r] = mc[r]; DR[(size_t)J * 256 + r * 16 + c] = mc[r]; }
+                    for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + tile_op(r, c)] = mc[r]; DR[(size_t)J * 256 + tile_res(r, c)] = mc[r]; }
                 }
             }
             for (int qi = TP.fin_lev_ptr[v]; qi < TP.fin_lev_ptr[v + 1]; qi++) { // phase 2
@@ -1019,10 +1025,10 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
                 double Tt[16][16];
                 for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) {
                     double sacc = 0;
-                    for (int k = 0; k < 16; k++) sacc += LC[(size_t)t * 256 + k * 16 + r] * DC[(size_t)J * 256 + k * 16 + c]; // T[r][k] * Linv[c][k]
+                    for (int k = 0; k < 16; k++) sacc += LC[(size_t)t * 256 + tile_op(r, k)] * DC[(size_t)J * 256 + tile_op(c, k)]; // T[r][k] * Linv[c][k]
                     Tt[r][c] = sacc * invD[J * 16 + c];
                 }
-                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { LR[(size_t)t * 256 + r * 16 + c] = Tt[r][c]; LC[(size_t)t * 256 + c * 16 + r] = Tt[r][c]; }
+                for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { LR[(size_t)t * 256 + tile_res(r, c)] = Tt[r][c]; LC[(size_t)t * 256 + tile_op(r, c)] = Tt[r][c]; }
             }
         }
         std::vector<double> rhs(N), ws(N16 + 1, 0.0);
@@ -1032,11 +1038,13 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
             double acc[16] = {0};
             for (int e = e0; e < e1; e++) {
                 const int t = fwd ? tiles_of[e] : e, vb = fwd ? TP.t_col[t] : TP.t_row[t];
-                for (int c = 0; c < 16; c++) for (int k = 0; k < 16; k++) acc[c] += val[(size_t)t * 256 + k * 16 + c] * ws[vb * 16 + k];
+                // forward: LC in operand order, out[r] += L[r][k] y[k]; backward: LR in result order read as the transposed operand, out[c] += L[r][c] x[r]
+                for (int c = 0; c < 16; c++) for (int k = 0; k < 16; k++) acc[c] += val[(size_t)t * 256 + tile_op(c, k)] * ws[vb * 16 + k];
             }
             double r[16], o[16] = {0};
             for (int c = 0; c < 16; c++) r[c] = (fwd ? ws[B * 16 + c] : ws[B * 16 + c] * invD[B * 16 + c]) - acc[c];
-            for (int c = 0; c < 16; c++) for (int k = 0; k < 16; k++) o[c] += dia[(size_t)B * 256 + k * 16 + c] * r[k];
+            if (TP.ident[B]) { for (int c = 0; c < 16; c++) ws[B * 16 + c] = r[c]; return; } // identity diagonal tile: skipped by the kernel
+            for (int c = 0; c < 16; c++) for (int k = 0; k < 16; k++) o[c] += dia[(size_t)B * 256 + tile_op(c, k)] * r[k];
             for (int c = 0; c < 16; c++) ws[B * 16 + c] = o[c];
         };
         for (int v = 0; v < TP.nblev; v++) for (int B = TP.blev_ptr[v]; B < TP.blev_ptr[v + 1]; B++) block(B, TP.tr_tile, TP.tr_ptr[B], TP.tr_ptr[B + 1], LC, DC, true);

@@ -114,6 +114,8 @@ struct DevPat {
     int tl_nimg, tl_scratch;       // entries of the K image scatter; offset (doubles) of the per-wave LDS scratch
     gint_p tl_blev, tl_tgt_lev, tl_tgt, tl_tp, tl_pa, tl_pb, tl_pk, tl_fin_lev, tl_fin; // levels, factor targets / pairs, finalise lists
     gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view
+    gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op
+    gint_p tl_ident;               // per block: 1 = the diagonal tile of L is the identity (skipped by the sweeps)
     gint_p tl_img_dst, tl_img_src, tl_psign; // K image scatter (slab offset -> image index); quasi-definite pivot sign per slot
     int w_LC, w_LR, w_DC, w_DR;    // workspace: L tiles column- / row-major, inverse diagonal tiles column- / row-major
     // instance slab offsets
@@ -125,6 +127,16 @@ struct DevPat {
     size_t inst_stride, work_stride; // in doubles
 };
 
+// Tile-internal element order (tile mode): a 16 x 16 tile is stored so that lane l of a wavefront owns the four
+// consecutive doubles 4 l .. 4 l + 3 (two 16-byte loads per lane, 2 KB contiguous per wavefront):
+//   operand order (LC, DC): element (row r, column k) at tile_op(r, k)  -- lane (k&3)*16 + r holds K-step k>>2: exactly what
+//     lane l of v_mfma_f64_16x16x4_f64 needs as A[r = l&15][4 s + (l>>4)] (and, for the transposed factor, as B);
+//   result order (LR, DR, the K image): element (r, c) at tile_res(r, c) = tile_op(c, r) -- lane (r&3)*16 + c, register r>>2:
+//     exactly the MFMA result layout C[(l>>4) + 4 reg][l&15], so an accumulator tile is stored with one 32-byte store per lane.
+constexpr int tile_op(int r, int k) { return (((k & 3) * 16 + r) << 2) + (k >> 2); }
+constexpr int tile_res(int r, int c) { return (((r & 3) * 16 + c) << 2) + (r >> 2); }
+constexpr int TOP_DIAG = 1, TOP_IDENT = 2; // tile sweep op flags: closes its block (diagonal tile) / that diagonal tile is the identity (no load)
+constexpr int TILE_PF = 6;          // tile loads in flight per wavefront in the tile sweeps (op lists are padded to a multiple)
 constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each

@@ -679,6 +679,17 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
 // therefore read as four fully coalesced 512-byte loads (element s*64 + l for K-step s), for A and for B alike.
 // ============================================================================================
 typedef double d4_t __attribute__((ext_vector_type(4)));
+// Workgroup-uniform reads of the (read-only) pattern arrays through the CONSTANT address space: s_load into SGPRs.  As a
+// vector load the descriptor of the next tile operation would sit in the in-order vmcnt queue BEHIND the tile loads issued
+// before it, and waiting for it would drain the whole prefetch queue at every operation.
+typedef const int __attribute__((address_space(4))) *cint_p;
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef const i4_t __attribute__((address_space(4))) *cint4_p;
+__device__ __forceinline__ cint_p as_const(gint_p p) { return (cint_p)(unsigned long long)p; }
+typedef const d4_t EICOS_GLOBAL *gcd4_p;
+typedef d4_t EICOS_GLOBAL *gd4_p;
+// the four doubles of lane `lane` of tile `t` (tile-internal order of device_types.hpp: two 16-byte loads)
+__device__ __forceinline__ d4_t tile_ld(gcdbl_p base, int t, int lane) { return *reinterpret_cast<gcd4_p>(base + (size_t)t * 256 + lane * 4); }
 
 // ---------------- ST_FACTOR, tile mode: left-looking block LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
 template <int T, int NLDS>
@@ -690,38 +701,34 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
     gcdbl_p Kt = W + P.w_Kt;
     double *scr = g_dyn + P.tl_scratch + uni(wave) * TILE_SCR; // wave-private 16 x 17 tile in LDS
     const int nbk = P.nb, kq = lane >> 4, lc = lane & 15;
+    cint_p c_tgt = as_const(P.tl_tgt), c_tp = as_const(P.tl_tp), c_pa = as_const(P.tl_pa), c_pb = as_const(P.tl_pb), c_pk = as_const(P.tl_pk);
+    cint_p c_fin = as_const(P.tl_fin), c_tcol = as_const(P.tl_tcol), c_tl = as_const(P.tl_tgt_lev), c_fl = as_const(P.tl_fin_lev);
     __syncthreads();
     TICK_BEGIN;
     for (int v = 0; v < P.nblev; v++) {
         // ---- phase 1: T = K - sum_K L_IK D_K L_JK' for every target of the level; diagonal targets are factorised ----
-        const int q1 = P.tl_tgt_lev[v + 1];
-        for (int q = P.tl_tgt_lev[v] + uni(wave); q < q1; q += NW) {
-            const int tg = uni(P.tl_tgt[q]), p0 = uni(P.tl_tp[q]), p1 = uni(P.tl_tp[q + 1]);
-            d4_t acc;
+        const int q1 = c_tl[v + 1];
+        for (int q = c_tl[v] + uni(wave); q < q1; q += NW) {
+            const int tg = c_tgt[q], p0 = c_tp[q], p1 = c_tp[q + 1];
+            d4_t acc = tile_ld(Kt, tg, lane); // the K image is stored in the MFMA result order
+            d4_t na, nb_, nd;
+            auto load = [&](int e, d4_t &xa, d4_t &xb, d4_t &xd) {
+                const int ta = c_pa[e], tb = c_pb[e], K = c_pk[e];
+                xa = tile_ld(LC, ta, lane); xb = tile_ld(LC, tb, lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = Kt[(size_t)tg * 256 + (kq + 4 * r) * 16 + lc]; // K image, row-major = result layout
-            double a[4], b[4], dd[4], na[4], nb_[4], nd[4];
-            auto load = [&](int e, double (&xa)[4], double (&xb)[4], double (&xd)[4]) {
-                const int ta = uni(P.tl_pa[e]), tb = uni(P.tl_pb[e]), K = uni(P.tl_pk[e]);
-#pragma unroll
-                for (int st = 0; st < 4; st++) {
-                    xa[st] = LC[(size_t)ta * 256 + st * 64 + lane];
-                    xb[st] = LC[(size_t)tb * 256 + st * 64 + lane];
-                    xd[st] = D[K * 16 + 4 * st + kq];
-                }
+                for (int st = 0; st < 4; st++) xd[st] = D[K * 16 + 4 * st + kq];
             };
             if (p0 < p1) load(p0, na, nb_, nd);
             for (int e = p0; e < p1; e++) {
-#pragma unroll
-                for (int st = 0; st < 4; st++) { a[st] = na[st]; b[st] = nb_[st]; dd[st] = nd[st]; }
-                if (e + 1 < p1) load(e + 1, na, nb_, nd); // next pair's tiles in flight behind this pair's MFMAs
+                const d4_t a = na, b = nb_, dd = nd;
+                load(min(e + 1, p1 - 1), na, nb_, nd); // next pair's tiles in flight behind this pair's MFMAs (unconditional: see tile_solve)
 #pragma unroll
                 for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[st], b[st] * dd[st], acc, 0, 0, 0);
             }
-            if (tg >= nbk) { // off-diagonal target: park T column-major in its own L slot (phase 2 reads it as an MFMA operand)
+            if (tg >= nbk) { // off-diagonal target: park T in operand order in its own L slot (phase 2 reads it as an MFMA operand)
                 const int t = tg - nbk;
 #pragma unroll
-                for (int r = 0; r < 4; r++) LC[(size_t)t * 256 + lc * 16 + kq + 4 * r] = acc[r];
+                for (int r = 0; r < 4; r++) LC[(size_t)t * 256 + tile_op(kq + 4 * r, lc)] = acc[r];
                 continue;
             }
             // ---- diagonal target: dense LDL' of the 16 x 16 tile in LDS (lower triangle), then the inverse of L_JJ ----
@@ -755,27 +762,23 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
                     mcol[r] = (r < lane) ? 0. : sacc;
                 }
 #pragma unroll
-                for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + lane * 16 + r] = mcol[r]; DR[(size_t)J * 256 + r * 16 + lane] = mcol[r]; }
+                for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + tile_op(r, lane)] = mcol[r]; DR[(size_t)J * 256 + tile_res(r, lane)] = mcol[r]; }
             }
         }
         __syncthreads();
         // ---- phase 2: L_IJ = T_IJ L_JJ^-T D_J^-1 for the off-diagonal tiles of the level's block columns ----
-        const int f1 = P.tl_fin_lev[v + 1];
-        for (int q = P.tl_fin_lev[v] + uni(wave); q < f1; q += NW) {
-            const int t = uni(P.tl_fin[q]), J = uni(P.tl_tcol[t]);
-            double a[4], b[4];
-#pragma unroll
-            for (int st = 0; st < 4; st++) { a[st] = LC[(size_t)t * 256 + st * 64 + lane]; b[st] = DC[(size_t)J * 256 + st * 64 + lane]; }
+        const int f1 = c_fl[v + 1];
+        for (int q = c_fl[v] + uni(wave); q < f1; q += NW) {
+            const int t = c_fin[q], J = c_tcol[t];
+            const d4_t a = tile_ld(LC, t, lane), b = tile_ld(DC, J, lane);
             const double idc = invD[J * 16 + lc];
             d4_t acc = {0., 0., 0., 0.};
 #pragma unroll
             for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], b[st], acc, 0, 0, 0);
+            acc *= idc;
+            *reinterpret_cast<gd4_p>(LR + (size_t)t * 256 + lane * 4) = acc; // result order = the accumulator as it stands
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double lv = acc[r] * idc;
-                LR[(size_t)t * 256 + (kq + 4 * r) * 16 + lc] = lv;
-                LC[(size_t)t * 256 + lc * 16 + kq + 4 * r] = lv;
-            }
+            for (int r = 0; r < 4; r++) LC[(size_t)t * 256 + tile_op(kq + 4 * r, lc)] = acc[r];
         }
         __syncthreads();
     }
@@ -788,8 +791,9 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
 
 // ---------------- LDL' solve, tile mode: ws <- L^-T D^-1 L^-1 ws in the padded elimination order ----------------
 // Forward, block row I:  y_I = Linv_II (b_I - sum_K L_IK y_K);  backward, block column J:  x_J = Linv_JJ' (y_J / D_J - sum_I L_IJ' x_I).
-// A tile mat-vec: lane l multiplies the four tile elements s*64 + l (s = 0..3) by the vector entries 4 s + (l >> 4) and the
-// four lane groups are folded by two cross-lane adds: unit-stride 512-byte loads, no index arrays at all.
+// A tile mat-vec: lane l multiplies its four tile elements by the vector entries 4 s + (l >> 4), s = 0..3, and the four
+// lane groups are folded by two cross-lane adds: 2 KB contiguous per wavefront and tile, no index arrays at all.
+// The loads of TILE_PF tiles are in flight per wavefront; blocks whose diagonal tile is the identity skip its product.
 template <int T, bool LDSBAR, class WS>
 __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws) {
     constexpr int NW = T / 64;
@@ -797,49 +801,56 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws) {
     const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, lc = lane & 15;
     auto bar = [&] { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); };
     auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
-    // one block: acc = sum over its tiles (values from `val`, tile ids / vector blocks through tid_of / blk_of), then the diagonal tile
-    auto block = [&](int B, int e0, int e1, gcdbl_p val, gcdbl_p dia, auto &&tile_at, auto &&vecblk_at, bool scale) {
-        double acc = 0.;
-        double cv[4], nv[4];
-        int cb = 0, nbk = 0;
-        auto load = [&](int e, double (&x)[4], int &vb) {
-            const int t = uni(tile_at(e));
-            vb = uni(vecblk_at(t));
+
+    // One sweep: per level every wavefront walks ITS flat list of tile operations (host: build_tile_sweeps) -- the tiles
+    // of its blocks, each block closed by its diagonal operation -- with the tile loads of the next TILE_PF operations in
+    // flight across block boundaries (they do not depend on ws).
+    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gcdbl_p val, gcdbl_p dia, bool scale) {
+        cint4_p ops = (cint4_p)(unsigned long long)ops_i;
+        cint_p ptr = as_const(ptr_g);
+        for (int v = 0; v < P.nblev; v++) {
+            const int o0 = ptr[v * NW + wave], o1 = ptr[v * NW + wave + 1]; // (o1 - o0) is a multiple of TILE_PF
+            d4_t qv[TILE_PF];
+            // unconditional: a conditional load would force s_waitcnt vmcnt(0) at every join and serialise the queue
+            auto load = [&](int o, d4_t &x) {
+                const i4_t op = ops[min(o, o1 - 1)];
+                x = tile_ld((op.w & TOP_DIAG) ? dia : val, op.x, lane);
+            };
+            double acc = 0.;
+            if (o0 < o1) {
 #pragma unroll
-            for (int st = 0; st < 4; st++) x[st] = val[(size_t)t * 256 + st * 64 + lane];
-        };
-        if (e0 < e1) load(e0, nv, nbk);
-        for (int e = e0; e < e1; e++) {
+                for (int u = 0; u < TILE_PF; u++) load(o0 + u, qv[u]);
+            }
+            for (int o = o0; o < o1; o += TILE_PF) {
 #pragma unroll
-            for (int st = 0; st < 4; st++) cv[st] = nv[st];
-            cb = nbk;
-            if (e + 1 < e1) load(e + 1, nv, nbk);
+                for (int u = 0; u < TILE_PF; u++) {
+                    const i4_t op = ops[o + u];
+                    const d4_t cv = qv[u];
+                    load(o + u + TILE_PF, qv[u]);
+                    const int fl = op.w, vb = op.y;
+                    if (!(fl & TOP_DIAG)) {
 #pragma unroll
-            for (int st = 0; st < 4; st++) acc += cv[st] * ws[cb * 16 + 4 * st + kq];
+                        for (int st = 0; st < 4; st++) acc += cv[st] * ws[vb * 16 + 4 * st + kq];
+                    } else { // close block vb: r = b_B - acc, then the diagonal tile
+                        const double own = ws[vb * 16 + lc];
+                        const double r = (scale ? own * invD[vb * 16 + lc] : own) - fold(acc);
+                        acc = 0.;
+                        double res = r;
+                        if (!(fl & TOP_IDENT)) {
+                            double oo = 0.;
+#pragma unroll
+                            for (int st = 0; st < 4; st++) oo += cv[st] * __shfl(r, 4 * st + kq, 64);
+                            res = fold(oo);
+                        }
+                        if (lane < 16) ws[vb * 16 + lane] = res;
+                    }
+                }
+            }
+            bar();
         }
-        double dg[4];
-#pragma unroll
-        for (int st = 0; st < 4; st++) dg[st] = dia[(size_t)B * 256 + st * 64 + lane];
-        const double own = ws[B * 16 + lc];
-        const double r = (scale ? own * invD[B * 16 + lc] : own) - fold(acc); // every lane: entry lc of the block's right-hand side
-        double o = 0.;
-#pragma unroll
-        for (int st = 0; st < 4; st++) o += dg[st] * __shfl(r, 4 * st + kq, 64);
-        o = fold(o);
-        if (lane < 16) ws[B * 16 + lane] = o;
     };
-    for (int v = 0; v < P.nblev; v++) { // forward: block rows, levels up
-        const int b1 = P.tl_blev[v + 1];
-        for (int B = P.tl_blev[v] + wave; B < b1; B += NW)
-            block(B, P.tl_tr_ptr[B], P.tl_tr_ptr[B + 1], LC, DC, [&](int e) { return P.tl_tr_tile[e]; }, [&](int t) { return P.tl_tcol[t]; }, false);
-        bar();
-    }
-    for (int v = P.nblev - 1; v >= 0; v--) { // backward: block columns, levels down
-        const int b1 = P.tl_blev[v + 1];
-        for (int B = P.tl_blev[v] + wave; B < b1; B += NW)
-            block(B, P.tl_tc_ptr[B], P.tl_tc_ptr[B + 1], LR, DR, [&](int e) { return e; }, [&](int t) { return P.tl_trow[t]; }, true);
-        bar();
-    }
+    sweep(P.tl_fops, P.tl_fptr, LC, DC, false); // forward: block rows, levels up
+    sweep(P.tl_bops, P.tl_bptr, LR, DR, true);  // backward: block columns, levels down
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------

@@ -2,6 +2,8 @@
 #include "tiles.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -84,22 +86,73 @@ TilePlan build_tile_plan(const Symbolic &S) {
     }
 
     // ---- where every scalar entry lives ----
+    T.ident.assign(nb, 1);
     T.Le_img.resize(S.nnzL); T.Le_tile.resize(S.nnzL); T.Le_rc.resize(S.nnzL); T.D_img.resize(N);
     for (int j = 0; j < N; j++) {
-        T.D_img[j] = blk[j] * 256 + off[j] * 16 + off[j];
+        T.D_img[j] = blk[j] * 256 + tile_res(off[j], off[j]);
         for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
             const int i = S.Li[e], I = blk[i], J = blk[j];
-            if (I == J) { T.Le_tile[e] = -1 - J; T.Le_rc[e] = off[i] * 16 + off[j]; T.Le_img[e] = J * 256 + off[i] * 16 + off[j]; }
+            if (I == J) { T.Le_tile[e] = -1 - J; T.Le_rc[e] = off[i] * 16 + off[j]; T.Le_img[e] = J * 256 + tile_res(off[i], off[j]); T.ident[J] = 0; }
             else {
                 const int t = tile_of(I, J);
                 if (t < 0) throw std::logic_error("tile plan: entry without a tile");
-                T.Le_tile[e] = t; T.Le_rc[e] = off[i] * 16 + off[j]; T.Le_img[e] = (nb + t) * 256 + off[i] * 16 + off[j];
+                T.Le_tile[e] = t; T.Le_rc[e] = off[i] * 16 + off[j]; T.Le_img[e] = (nb + t) * 256 + tile_res(off[i], off[j]);
             }
         }
     }
     for (int b = 0; b < nb; b++)
-        for (int o = S.blk_ptr[b + 1] - S.blk_ptr[b]; o < 16; o++) T.pad_img.push_back(b * 256 + o * 16 + o);
+        for (int o = S.blk_ptr[b + 1] - S.blk_ptr[b]; o < 16; o++) T.pad_img.push_back(b * 256 + tile_res(o, o));
     return T;
+}
+
+TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
+    TileSweeps W;
+    W.NW = NW;
+    auto build = [&](bool fwd, std::vector<int> &ops, std::vector<int> &ptr) {
+        ptr.assign(1, 0);
+        for (int step = 0; step < T.nblev; step++) {
+            const int v = fwd ? step : T.nblev - 1 - step;
+            const int b0 = T.blev_ptr[v], b1 = T.blev_ptr[v + 1];
+            auto ntiles = [&](int B) { return fwd ? T.tr_ptr[B + 1] - T.tr_ptr[B] : T.tc_ptr[B + 1] - T.tc_ptr[B]; };
+            std::vector<int> order(b1 - b0);
+            std::iota(order.begin(), order.end(), b0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ntiles(a) > ntiles(b); });
+            std::vector<std::vector<int>> mine(NW);
+            std::vector<long> load(NW, 0);
+            for (int B : order) { // longest first onto the least loaded wavefront
+                const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                mine[w].push_back(B); load[w] += ntiles(B) + 2;
+            }
+            for (int w = 0; w < NW; w++) {
+                for (int B : mine[w]) {
+                    if (fwd) for (int e = T.tr_ptr[B]; e < T.tr_ptr[B + 1]; e++) { const int t = T.tr_tile[e]; ops.insert(ops.end(), {t, T.t_col[t], B, 0}); }
+                    else for (int t = T.tc_ptr[B]; t < T.tc_ptr[B + 1]; t++) ops.insert(ops.end(), {t, T.t_row[t], B, 0});
+                    // identity diagonal tile: nothing to multiply; its (unconditional) load is pointed at diagonal tile 0, which stays cached
+                    ops.insert(ops.end(), {T.ident[B] ? 0 : B, B, B, TOP_DIAG | (T.ident[B] ? TOP_IDENT : 0)});
+                }
+                // pad to a multiple of `pf` operations with products against the all-zero vector block nb: the kernel's software
+                // pipeline then has no conditional around its loads (a conditional load defeats the s_waitcnt counting)
+                while (((int)ops.size() / 4 - ptr.back()) % pf) ops.insert(ops.end(), {0, T.nb, 0, 0});
+                ptr.push_back((int)ops.size() / 4);
+            }
+        }
+    };
+    build(true, W.fops, W.fptr);
+    build(false, W.bops, W.bptr);
+    if (getenv("EICOS_PLAN_STATS")) { // developer aid: per level, blocks and the op count of the busiest / the average wavefront
+        for (int pass = 0; pass < 2; pass++) {
+            const std::vector<int> &ptr = pass ? W.bptr : W.fptr;
+            fprintf(stderr, "[tile sweeps NW=%d] %s:", NW, pass ? "backward" : "forward");
+            for (int st = 0; st < T.nblev; st++) {
+                int mx = 0, tot = 0;
+                for (int w = 0; w < NW; w++) { const int c = ptr[st * NW + w + 1] - ptr[st * NW + w]; mx = std::max(mx, c); tot += c; }
+                const int v = pass ? T.nblev - 1 - st : st;
+                fprintf(stderr, " L%d[%d blk: max %d / avg %.1f]", v, T.blev_ptr[v + 1] - T.blev_ptr[v], mx, (double)tot / NW);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+    return W;
 }
 
 } // namespace eicos

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "device_types.hpp"
 #include "symbolic.hpp"
 
 namespace eicos {
@@ -32,14 +33,27 @@ struct TilePlan {
     std::vector<int> pa, pb, pk;   // pair: T -= L(pa) D(pk) L(pb)' with tiles pa = (I,K), pb = (J,K), source block pk = K
     // off-diagonal targets of every level again (second phase: L_IJ = T_IJ Linv_JJ' / D_J), level ranges in fin_lev_ptr
     std::vector<int> fin, fin_lev_ptr;
-    // KKT entries -> dense image Kt = [nb diagonal tiles | nt off-diagonal tiles], 256 doubles each, ROW-major
-    // (row, col) = (r, c) at 16 r + c; only the lower triangle of diagonal tiles is filled.
+    // KKT entries -> dense image Kt = [nb diagonal tiles | nt off-diagonal tiles], 256 doubles each, element (r, c) at
+    // tile_res(r, c) (device_types.hpp: the MFMA result order); only the lower triangle of diagonal tiles is filled.
     // Per permuted entry: L entry e (CSC order of Symbolic) -> Le_img[e]; diagonal j -> D_img[j]; padding diagonals (value 1)
     std::vector<int> Le_img, D_img, pad_img;
     // scalar entry of L (CSC e) -> its tile value position: tile id and in-tile (r, c); for the debug hooks
-    std::vector<int> Le_tile, Le_rc;
+    std::vector<int> Le_tile, Le_rc;   // Le_rc = 16 r + c
+    std::vector<int> ident;            // per block: 1 = its diagonal tile of L is the identity (no coupling inside the block)
     int64_t npairs = 0;
 };
+
+// Per-wavefront schedules of the two tile sweeps for a workgroup of NW wavefronts: the blocks of a level are dealt to the
+// wavefronts longest-first, and every wavefront gets ONE flat list of tile operations per level -- the off-diagonal tiles of
+// its blocks, each block closed by its diagonal operation -- so that its loads can run ahead across block boundaries.
+// op = {tile id (diagonal op: the block), vector block the tile multiplies, block being accumulated, flags}
+// flags TOP_DIAG / TOP_IDENT: device_types.hpp
+struct TileSweeps {
+    int NW = 0;
+    std::vector<int> fops, bops;       // 4 ints per op
+    std::vector<int> fptr, bptr;       // [nblev * NW + 1]: op range of (level, wave), levels in sweep order (forward: up, backward: down)
+};
+TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf /* list lengths are padded to a multiple of pf */);
 
 TilePlan build_tile_plan(const Symbolic &S);
 

@@ -154,10 +154,13 @@ def test_dense_front_socp():
 
 
 @pytest.mark.parametrize("env", [{"EICOS_NLDS": "0"}, {"EICOS_NLDS": "1"}, {"EICOS_NLDS": "2"}, {"EICOS_THREADS": "128"},
-                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_IDX16": "0"}, {"EICOS_IDX16": "0", "EICOS_NLDS": "0"}])
+                                 {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_IDX16": "0"}, {"EICOS_IDX16": "0", "EICOS_NLDS": "0"},
+                                 {"EICOS_TILES": "1"}, {"EICOS_TILES": "1", "EICOS_NLDS": "0"}, {"EICOS_TILES": "1", "EICOS_THREADS": "128", "EICOS_NLDS": "2"},
+                                 {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
-    # or in the workspace slab, 128/256/512 threads) through an LP, an SOC and an infeasible fixture
+    # or in the workspace slab, 128/256/512 threads, 16-/32-bit gather indices, and the tile (dense-front) factor/solve
+    # path, which is normally taken only when L is dense) through an LP, an SOC and an infeasible fixture
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for name in ("lp_bandm", "issue98", "infeasible1", "update_data"):
@@ -264,15 +267,23 @@ def test_update_keep_semantics_and_ranges():
     g.close()
 
 
-@pytest.mark.parametrize("name,soc", [("lp_afiro", False), ("issue98", False), ("MPC02", False), ("MPC02", True)])
-def test_ldl_factor_against_dense(name, soc):
+@pytest.mark.parametrize("name,soc,tiles", [("lp_afiro", False, False), ("issue98", False, False), ("MPC02", False, False), ("MPC02", True, False),
+                                            ("lp_afiro", False, True), ("issue98", False, True), ("dense-front", False, True)])
+def test_ldl_factor_against_dense(name, soc, tiles, monkeypatch):
     # numeric LDL' of one instance against the matrix it factorises: the componentwise backward error of an LDL'
     # without pivoting, |L D L' - P K P'| <= c eps |L||D||L'| (+ 1e-14 max|K|; a plain norm bound does not hold at the
     # last IPM pass of a degenerate SOC problem, where pivots of 1e-10 sit next to entries of order 1), with K
     # assembled independently of the factor program from the instance's own values (equilibrated A/G, scaling block
     # of the last iteration, +-delta) in the reference's layout (src/eicos.cpp:1734-1890) -- SURVEY.md section 7 step 3
     from scipy.sparse import coo_matrix, csc_matrix, diags, identity
-    pat, sets = load_fixture(name)
+    if tiles:  # the tile (dense-front, MFMA) factorisation; forced on the sparse fixtures, chosen by itself for dense fronts
+        monkeypatch.setenv("EICOS_TILES", "1")
+    if name == "dense-front":
+        pat, base = dense_front_pattern(n=150, k=4, d=40)
+        d = feasible_batch(pat, base, 0, 1)
+        sets = [Values(d["Gpr"][0], d["Apr"][0], d["c"][0], d["h"][0], d["b"][0])]
+    else:
+        pat, sets = load_fixture(name)
     if soc:
         pat = mpc_soc_variant(pat, sets[0])
         d = feasible_batch(pat, sets[0], 0, 1)
@@ -296,8 +307,14 @@ def test_ldl_factor_against_dense(name, soc):
     R = abs(L @ diags(D) @ L.T - K)
     bound = 64 * np.finfo(float).eps * (abs(L) @ diags(np.abs(D)) @ abs(L).T)
     excess = (R - bound).tocoo()
-    assert excess.data.max() <= 1e-14 * np.abs(K.data).max(), (name, excess.data.max(), np.abs(K.data).max())
-    if name != "issue98":  # well-scaled instances also meet the plain norm bound
+    if tiles:
+        # tile path: off-diagonal tiles are formed with the explicit inverse of the 16 x 16 unit-lower diagonal tile (one
+        # MFMA product instead of a 16-step substitution) and this hook inverts that inverse back on the host; both cost a
+        # factor cond(L_JJ) on top of the componentwise bound -> normwise bound against the scale of |L||D||L'|
+        assert excess.data.max() <= 1e-11 * bound.tocoo().data.max() / (64 * np.finfo(float).eps) , (name, excess.data.max(), bound.tocoo().data.max())
+    else:
+        assert excess.data.max() <= 1e-14 * np.abs(K.data).max(), (name, excess.data.max(), np.abs(K.data).max())
+    if name not in ("issue98", "dense-front"):  # well-scaled instances also meet the plain norm bound
         assert R.tocoo().data.max() <= 1e-12 * np.abs(K.data).max()
     # quasi-definite signs: + for the x block and the u-expansion of every cone, - elsewhere
     pos = np.zeros(N, bool); pos[: pat.n] = True

@@ -7,7 +7,11 @@ from eicos_amd.generate import feasible_batch
 name = sys.argv[1] if len(sys.argv) > 1 else "MPC02"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-pat, sets = read_epb(f'tests/golden/{name}.epb')
+if name == 'dense-front':
+    from eicos_amd.generate import dense_front_pattern
+    pat, base = dense_front_pattern(2000, 32, 64); sets = [base]
+else:
+    pat, sets = read_epb(f'tests/golden/{name}.epb')
 d = feasible_batch(pat, sets[0], 0, min(B, 256))
 tile = lambda a: np.tile(a, ((B + a.shape[0] - 1) // a.shape[0], 1))[:B]
 g = BatchSolver(pat, B)
