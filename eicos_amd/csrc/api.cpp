@@ -38,6 +38,8 @@ struct eicos_batch {
     Symbolic sym;
     DevPat dp{};
     int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
+    int ki = 1;               // instances per workgroup solved in lock-step (DevPat::w_split)
+    size_t dyn_lds1 = 0; int nlds1 = 0; // launch shape of the single-instance kernel on the same workspace (warm start)
     int *d_pattern = nullptr;
     int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
     size_t dyn_lds = 0;
@@ -163,9 +165,15 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device < 0 ? 0 : device) == hipSuccess) n_cu = pr.multiProcessorCount; }
         // (sparse factors only: with ~50 entries per row of L -- the dense-front config -- 512 threads stay ahead)
         const bool throughput_bound = batch > n_cu && (long long)S.nnzL < 16LL * S.N;
-        const int dflt = dimK < 400 ? 128 : ((dimK < 2000 || throughput_bound) ? 256 : 512);
+        // lock-step pairs (see the LDS sizing below): wanted when there are more instances than CUs and two sweep vectors
+        // (+ ~24 KB of tables) fit the 160 KB of LDS; they run as ONE 512-thread workgroup per CU
+        int ki_want = 1; // measured: pairs do not pay on the MPC pattern -> opt-in through EICOS_KI=2
+        ki_want = env_int("EICOS_KI", ki_want);
+        h->ki = (ki_want == 2 && !S.tile && batch >= 2) ? 2 : 1;
+        const int dflt = h->ki == 2 ? 512 : (dimK < 400 ? 128 : ((dimK < 2000 || throughput_bound) ? 256 : 512));
         const int t = env_int("EICOS_THREADS", dflt);
         h->threads = (t == 128 || t == 256 || t == 512) ? t : dflt;
+        if (h->threads < 256) h->ki = 1;
     }
     // ---- slab layouts ----
     SlabLayout L;
@@ -214,9 +222,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
+    D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
+    // ---- from here on: arrays shared KI-interleaved by the instances of a lock-step workgroup (DevPat::w_split) ----
+    D.w_split = (int)Wl.size;
     D.w_xk = Wl.add((size_t)NV + 16); D.w_ek = Wl.add((size_t)NV + 16); D.w_dxr = Wl.add(NV);
     D.w_D = Wl.add(NV); D.w_invD = Wl.add(NV); // w_UF / w_UB are added once the slice plans are known
-    D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
 
     // ---- pattern arrays ----
     IntPool pool;
@@ -404,11 +414,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
-        const size_t lds_static = 2048; // struct Sh of kernels.hip (reductions + scalar state), rounded up
+        const size_t lds_static = 4096; // struct Sh + the per-instance states of kernels.hip (reductions + scalar state), rounded up
         // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
         const size_t scratch = tile ? (size_t)(h->threads / 64) * TILE_SCR * sizeof(double) : 0;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
-        const int wgs_by_regs = (h->threads == 256 ? 3 : 4) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
+        const int wgs_by_regs = h->ki == 2 ? 1 : (h->threads == 256 ? 3 : 4) * 4 / (h->threads / 64); // waves_per_eu<T, KI>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
             return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + scratch + lds_static)));
         };
@@ -426,13 +436,24 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         int want = fit;
         if (batch > prop.multiProcessorCount && fit == 2 && 2 * (vec + meta + 4096) <= 160 * 1024) want = 1;
         h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want)));
+        // Lock-step pairs: with more instances than CUs, one 512-thread workgroup per CU solves TWO
+        // instances at once -- slice decoding, index loads, barriers and the dependent chain of the sparse sweeps are shared,
+        // values / gathers are 16-byte accesses over interleaved arrays.  Needs both sweep vectors in LDS.
+        int ki = h->ki; // wanted (decided with the workgroup size, above); needs both vectors + the tables in LDS
+        if (ki != 2 || tile || fit < 2 || h->threads < 256 || batch < 2) ki = 1;
+        h->ki = ki;
+        // the single-instance kernel on the same workspace (warm start; debug hooks): one vector in LDS
+        h->nlds1 = h->nlds; h->dyn_lds1 = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : scratch;
+        if (ki == 2) { h->nlds = 1; h->nlds1 = 1; h->dyn_lds1 = vec + meta; }
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
-        h->dyn_lds = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : scratch;
+        h->dyn_lds = h->nlds >= 1 ? (size_t)ki * h->nlds * vec + meta : scratch;
         D.tl_scratch = h->nlds >= 1 ? h->nlds * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
     }
-    HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
+    D.group_stride = (size_t)h->ki * D.work_stride;
+    HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds));
+    if (h->ki > 1) HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds1, h->dp.idx16, 1, h->dyn_lds1));
     int bpc = 1;
-    HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
+    HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds, &bpc));
     bpc = std::max(1, std::min(bpc, 8));
     {
         // Workgroups per CU for this batch.  A workgroup slows down by about half of its stand-alone time per
@@ -440,8 +461,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // partly filled round still costs more than half a round; pick the cheapest estimate (e.g. batch 1024 on
         // 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3 per CU, batch >= 1536 takes 3 per CU).
         double best = 1e300; int best_r = 1;
+        const double groups = std::ceil((double)batch / h->ki);
         for (int r = 1; r <= bpc; r++) {
-            const double rounds = (double)batch / ((double)prop.multiProcessorCount * r);
+            const double rounds = groups / ((double)prop.multiProcessorCount * r);
             const double full = std::floor(rounds), f = rounds - full;
             const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
             if (cost < best - 1e-12) { best = cost; best_r = r; }
@@ -450,7 +472,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
     const int resident = prop.multiProcessorCount * bpc;
-    h->grid = std::min(batch, resident);
+    h->grid = std::min((batch + h->ki - 1) / h->ki, resident);
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
     h->pattern_ints = pool.data.size();
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
@@ -468,8 +490,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     HIP_TRY_H(upload_pattern(h->pslot, h->dp));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
-    HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
-    HIP_TRY_H(hipMemset(h->d_work, 0, (size_t)h->grid * D.work_stride * sizeof(double)));
+    HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.group_stride * sizeof(double)));
+    HIP_TRY_H(hipMemset(h->d_work, 0, (size_t)h->grid * D.group_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_queue, (16 + (size_t)batch) * sizeof(int))); // [0] queue head, [16..] longest-first order
     HIP_TRY_H(hipMalloc(&h->d_scratch, (size_t)h->upd_grid * (size_t)(S.n + S.p + S.m + 8) * sizeof(double)));
     HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -606,7 +628,11 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
+    // warm start decides per instance whether the initialisation solves are skipped: members of a lock-step group could
+    // then be in different stages, so warm-started handles run the single-instance kernel (same workspace slabs)
+    const bool single = h->ki == 1 || h->warm_shift > 0.;
+    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, single ? h->nlds1 : h->nlds,
+                         h->dp.idx16, single ? 1 : h->ki, h->warm_shift, h->dyn_delta, h->dyn_eps, single ? h->dyn_lds1 : h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     return EICOS_OK;
@@ -691,7 +717,7 @@ int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     o->factor_pairs = S.npairs;
     o->inst_bytes = h->dp.inst_stride * sizeof(double); o->work_bytes = h->dp.work_stride * sizeof(double);
     o->pattern_bytes = h->pattern_ints * sizeof(int);
-    o->threads_per_block = h->threads; o->resident_blocks = h->grid; o->lds_bytes = (int)h->dyn_lds;
+    o->threads_per_block = h->threads; o->resident_blocks = h->grid * h->ki; o->lds_bytes = (int)h->dyn_lds; o->instances_per_block = h->ki;
     return EICOS_OK;
 }
 
@@ -801,10 +827,11 @@ int eicos_debug_scalings(eicos_batch *h, int inst, const double *s, const double
 
 int eicos_debug_trace(eicos_batch *h, int inst, double *out) {
     if (!h || !out || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
-    if (h->batch > h->grid) return fail(EICOS_E_INVALID, "trace is per workspace slot: needs batch <= resident workgroups");
+    const int kis = (h->ki == 1 || h->warm_shift > 0.) ? 1 : h->ki; // instances per workgroup of the kernel that ran
+    if (h->batch > h->grid * kis) return fail(EICOS_E_INVALID, "trace is per workspace slot: needs batch <= resident instances");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)inst * h->dp.work_stride + h->dp.w_trace,
+    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)(inst / kis) * h->dp.group_stride + (size_t)(inst % kis) * h->dp.w_split + h->dp.w_trace,
                       (size_t)TRACE_ROWS * TRACE_COLS * sizeof(double), hipMemcpyDeviceToHost));
     return EICOS_OK;
 }

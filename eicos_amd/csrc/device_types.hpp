@@ -124,7 +124,12 @@ struct DevPat {
     int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2, w_rhs1k, w_rhs2k;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
     int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_UF, w_UB, w_D, w_invD, w_trace;
+    // Workspace of a workgroup that solves KI instances in lock-step (KI = 1: one instance): the arrays at offsets below
+    // w_split are per instance (instance k at k * w_split + offset), the arrays at or above it -- the factor, its value
+    // stream Kt and the KKT-space vectors -- are shared KI-interleaved (element i of instance k at KI * offset + i * KI + k).
+    int w_split;
     size_t inst_stride, work_stride; // in doubles
+    size_t group_stride;             // workspace of one resident workgroup = (instances per workgroup of the handle) * work_stride
 };
 
 // Tile-internal element order (tile mode): a 16 x 16 tile is stored so that lane l of a wavefront owns the four

@@ -49,7 +49,8 @@ constexpr int EX_NOT_CONVERGED = -87;
 // two workgroups per CU), 256 threads -> 3 (168 VGPRs, three workgroups per CU: three 48 KB solve vectors are what
 // the 160 KB of LDS hold), 128 threads -> 4 (small patterns, up to eight workgroups per CU).  The AMDGPU
 // attributor propagates the kernel's budget to the non-inlined stage functions.
-template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : 4; }
+// Lock-step pairs (KI = 2) run as ONE workgroup per CU (both sweep vectors in LDS): 512 threads = 2 waves per SIMD -> 256 VGPRs.
+template <int T, int KI = 1> constexpr int waves_per_eu() { return KI == 2 ? T / 256 : (T == 256 ? 3 : 4); }
 
 constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values per reduction
 
@@ -64,20 +65,36 @@ enum { ACT_CONTINUE = 0, ACT_BREAK = 1 };
 constexpr int MAX_PATTERNS = 64;
 __constant__ DevPat c_pat[MAX_PATTERNS];
 
-struct Sh {
-    double red[2 * RED_SLOTS];
+// Per-instance scalar state.  g_S is the state of the instance the per-instance stages are working on.  A workgroup that
+// solves KI > 1 instances in lock-step keeps every instance's state in g_Sk[k] and swaps it in and out of g_S around the
+// per-instance stages; the lock-step stages (factorisation, KKT solves) address g_Sk[k] directly (inst_state).
+struct ShI {
     DevInfo wi, bi;
     double sv[SV_COUNT];
-    double dyn_delta, dyn_eps; // dynamic regularisation of the pivots (extension; 0 = off), set by k_solve
     int fl[FL_COUNT];
-    int next; // next instance of this workgroup (k_solve's queue)
+    int kref, done; // refinement steps of the last KKT solve; 1 = this instance has finished (lock-step groups)
     unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
 };
+struct Sh : ShI {
+    double red[2 * RED_SLOTS];
+    double dyn_delta, dyn_eps; // dynamic regularisation of the pivots (extension; 0 = off), set by k_solve
+    int next; // next instance of this workgroup (k_solve's queue)
+};
+constexpr int KI_MAX = 2; // instances per workgroup in lock-step
 enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT, TK_FA = 8, TK_FW1, TK_FB, TK_FW2 }; // 8..11: inside the factor
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
-static_assert(sizeof(Sh) <= 2048, "api.cpp budgets 2 KB of static LDS per workgroup");
+static_assert(sizeof(Sh) + KI_MAX * sizeof(ShI) <= 4096, "api.cpp budgets 4 KB of static LDS per workgroup");
 __shared__ Sh g_S;
+__shared__ ShI g_Sk[KI_MAX];
+template <int KI> __device__ __forceinline__ ShI &inst_state(int k) { if constexpr (KI == 1) return g_S; else return g_Sk[k]; }
+// swap the per-instance state of instance k into / out of g_S (all threads call; ends with a barrier)
+template <int KI> __device__ __forceinline__ void state_in(int k) {
+    if constexpr (KI > 1) { __syncthreads(); if (threadIdx.x == 0) static_cast<ShI &>(g_S) = g_Sk[k]; __syncthreads(); }
+}
+template <int KI> __device__ __forceinline__ void state_out(int k) {
+    if constexpr (KI > 1) { __syncthreads(); if (threadIdx.x == 0) g_Sk[k] = static_cast<ShI &>(g_S); __syncthreads(); }
+}
 extern __shared__ double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | slice tables of both sweeps
 
 // Arguments of non-inlined device functions arrive in VGPRs; the values below are workgroup-uniform,
@@ -97,6 +114,35 @@ template <class Ptr> __device__ __forceinline__ Ptr uni_ptr(Ptr p) {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return (Ptr)(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- KI-interleaved arrays: element (i, k) of an array shared by the KI instances of a workgroup sits at i * KI + k, so the
+// KI values of one slot are ONE load / store of 8 KI bytes (KI = 2: 16 bytes per lane, the width the memory system likes best).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <class P> struct vec2_of;
+template <> struct vec2_of<double *> { typedef d2_t *type; };
+template <> struct vec2_of<const double *> { typedef const d2_t *type; };
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> struct vec2_of<gdbl_p> { typedef d2_t EICOS_GLOBAL *type; };
+template <> struct vec2_of<gcdbl_p> { typedef const d2_t EICOS_GLOBAL *type; };
+#endif
+template <int KI, class P> __device__ __forceinline__ void ldK(P base, int i, double (&o)[KI]) {
+    if constexpr (KI == 1) o[0] = base[i];
+    else { static_assert(KI == 2, "KI"); const d2_t v = reinterpret_cast<typename vec2_of<P>::type>(base)[i]; o[0] = v.x; o[1] = v.y; }
+}
+template <int KI, class P> __device__ __forceinline__ void stK(P base, int i, const double (&o)[KI]) {
+    if constexpr (KI == 1) base[i] = o[0];
+    else { static_assert(KI == 2, "KI"); reinterpret_cast<typename vec2_of<P>::type>(base)[i] = d2_t{o[0], o[1]}; }
+}
+// global array, 32-bit byte offset addressing (ld_u32), optionally non-temporal
+template <int KI, bool NT> __device__ __forceinline__ void ldK_g(gcdbl_p base, int i, double (&o)[KI]) {
+    if constexpr (KI == 1) o[0] = NT ? ld_u32_nt(base, i) : ld_u32(base, i);
+    else {
+        static_assert(KI == 2, "KI");
+        const d2_t EICOS_GLOBAL *b2 = reinterpret_cast<const d2_t EICOS_GLOBAL *>(base);
+        const d2_t v = NT ? ld_u32_nt(b2, i) : ld_u32(b2, i);
+        o[0] = v.x; o[1] = v.y;
+    }
 }
 
 // Sum over an aligned group of g = 1<<lg adjacent lanes, result valid in the group's lane 0.
@@ -187,6 +233,7 @@ struct V1 { double a; };
 struct V2 { double a, b; };
 struct V3 { double a, b, c; };
 struct V4 { double a, b, c, d; };
+template <int KI> struct VKI { double v[KI]; };
 struct IV1 { int i; double a; };
 struct IV2 { int i; double a, b; };
 template <int T, int U = 4, class L, class F>
@@ -278,6 +325,71 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
     }
 }
 
+// Lock-step form of ell_dots for KI instances of one workgroup: the slice descriptors and gather indices are shared, the
+// matrix values come from the KI instance slabs (eval[k]), the gathered vector x is KI-interleaved; `pre(k, row)` /
+// `epi(k, row, sum, pre)` get the instance number.
+template <int T, bool I16, int KI, class SM, class X, class Pre, class Epi>
+__device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, const gcdbl_p (&eval)[KI], X x, int dummy_slot,
+                                           Pre &&pre, Epi &&epi) {
+    if (ns == 0) return; // no rows
+    const int t = threadIdx.x;
+    using R = decltype(pre(0, 0));
+    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX][KI]; R qr[ELL_DEPTH][KI];
+    auto meta = [&](int s) { return slice_at(sm, s); };
+    double carry[KI]; // partial sum of rows cut into sub-slices (SliceMeta::more / cont)
+#pragma unroll
+    for (int k = 0; k < KI; k++) carry[k] = 0.;
+    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX][KI], R (&nr)[KI]) {
+        const Sl nm = meta(s);
+        const int lanes = nm.cnt << nm.lg;
+        const bool act = t < lanes;
+        load_indices<I16>(ni, eidx, eidx16, act, nm.K, nm.off, lanes, t, dummy_slot, nm.off16, d16);
+#pragma unroll
+        for (int kk = 0; kk < ELL_KMAX; kk++) {
+            const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
+#pragma unroll
+            for (int k = 0; k < KI; k++) nv[kk][k] = ld_u32_nt(eval[k], slot); // streamed once per pass: keep the shared index arrays in L2
+        }
+#pragma unroll
+        for (int k = 0; k < KI; k++) nr[k] = pre(k, act ? nm.row0 + (t >> nm.lg) : 0);
+    };
+#pragma unroll
+    for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
+    for (int s0 = 0; s0 < ns; s0 += ELL_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < ELL_DEPTH; d++) {
+            const int s = s0 + d;
+            const Sl m = meta(s);
+            int ci[ELL_KMAX]; double cv[ELL_KMAX][KI]; R cr[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) cr[k] = qr[d][k];
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) {
+                ci[kk] = qi[d][kk];
+#pragma unroll
+                for (int k = 0; k < KI; k++) cv[kk][k] = qv[d][kk][k];
+            }
+            load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
+            const int lanes = m.cnt << m.lg;
+            const bool act = t < lanes;
+            double xg[ELL_KMAX][KI];
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(x, ci[kk], xg[kk]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                double acc = 0.;
+#pragma unroll
+                for (int kk = 0; kk < ELL_KMAX; kk++) acc += cv[kk][k] * xg[kk][k];
+                acc = grp_reduce_to_lane0(acc, m.lg);
+                if (m.cont) acc += carry[k];
+                if (m.more) carry[k] = acc;
+                else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(k, m.row0 + (t >> m.lg), acc, cr[k]);
+            }
+        }
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  On gfx9-family parts loads and stores share
 // the vmcnt counter, so __syncthreads() (release fence) drains every outstanding global LOAD as
 // well -- which would serialise the software prefetch below behind each level barrier.  The
@@ -298,14 +410,16 @@ __device__ __forceinline__ void lds_barrier() {
 // SOLO: the narrow top of the elimination tree, laid out for 64 lanes and run by wavefront 0 alone -- no
 // workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
-template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, class SM, class WS>
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
+    // KI > 1: the workgroup sweeps KI instances in lock-step -- slice descriptors and gather indices are shared, the value
+    // arrays (eval, invD) and the sweep vector ws are KI-interleaved, so every value load / gather / store is one 8 KI-byte access
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
         int row0, lg, K, off, lanes, newlev, more, cont;
-        int idx[ELL_KMAX]; double val[ELL_KMAX]; double d, own;
+        int idx[ELL_KMAX]; double val[ELL_KMAX][KI]; double d[KI], own[KI];
     } q[TRI_DEPTH];
     // every slice issues the same number of global loads per lane (inactive lanes / padding read the plan's dummy
     // slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
@@ -319,11 +433,14 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
-            o.val[kk] = ld_u32_nt(eval, slot); // streamed once per sweep: do not displace the index arrays in L2
+            ldK_g<KI, true>(eval, slot, o.val[kk]); // streamed once per sweep: do not displace the index arrays in L2
         }
         const int r = act ? o.row0 + (t >> o.lg) : 0;
-        o.d = FORWARD ? 0. : ld_u32(invD, r); // forward is L y = b with unit-lower L: no pivot needed
-        o.own = ws[r]; // rows of later slices are not written before their own slice runs
+        if constexpr (FORWARD) { // forward is L y = b with unit-lower L: no pivot needed
+#pragma unroll
+            for (int k = 0; k < KI; k++) o.d[k] = 0.;
+        } else ldK_g<KI, false>(invD, r, o.d);
+        ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
@@ -340,21 +457,31 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
                 else if (LDSBAR) lds_barrier();
                 else __syncthreads();
             }
-            double xg[ELL_KMAX]; // all gathers in flight before the first multiply (the scheduler would serialise them)
+            double xg[ELL_KMAX][KI]; // all gathers in flight before the first multiply (the scheduler would serialise them)
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) xg[kk] = ws[c.idx[kk]];
+            for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, c.idx[kk], xg[kk]);
             __builtin_amdgcn_sched_barrier(0);
-            double acc = 0.;
+            double acc[KI];
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) acc += c.val[kk] * xg[kk];
-            acc = grp_reduce_to_lane0(acc, c.lg);
+            for (int k = 0; k < KI; k++) {
+                double a = 0.;
+#pragma unroll
+                for (int kk = 0; kk < ELL_KMAX; kk++) a += c.val[kk][k] * xg[kk][k];
+                acc[k] = grp_reduce_to_lane0(a, c.lg);
+            }
             if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
                 const int r = c.row0 + (t >> c.lg);
                 // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
                 // (same lane, program order), and only the last one applies the pivot
-                const double v = (c.cont ? ws[r] : c.own) - acc;
-                if (FORWARD || c.more) ws[r] = v;              // y_i = b_i - sum_k L[i,k] y_k
-                else ws[r] = v * c.d;                          // x_j = (y_j - sum_i U[i,j] x_i) / D_j
+                double cur[KI], out[KI];
+                if (c.cont) ldK<KI>(ws, r, cur);
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const double v = (c.cont ? cur[k] : c.own[k]) - acc[k];
+                    out[k] = (FORWARD || c.more) ? v         // y_i = b_i - sum_k L[i,k] y_k
+                                                 : v * c.d[k]; // x_j = (y_j - sum_i U[i,j] x_i) / D_j
+                }
+                stK<KI>(ws, r, out);
             }
         }
     }
@@ -524,7 +651,7 @@ __device__ __forceinline__ void restore_scalars() { // w = w_best (scalars), cou
 }
 
 // Slice table `which` of the current pattern: the LDS copy (NLDS >= 1) or the one in global memory.
-#define LDS_TABLE(at) (reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)NLDS * P.Npad) + (at))
+#define LDS_TABLE(at) (reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)KI * NLDS * P.Npad) + (at))
 
 // states of the solve program
 enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KKT_AFF, ST_KKT_COMB, ST_DONE };
@@ -545,34 +672,33 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
     (void)n; (void)p; (void)m; (void)l; (void)N; (void)np; (void)lane; (void)wave; (void)phase; (void)wi;
 
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
-template <int T, int NLDS, bool I16>
-__device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
-    STAGE_PROLOGUE
-    iter = uni(iter);
-    gdbl_p UF = W + P.w_UF, U = W + P.w_UB, D = W + P.w_D, invD = W + P.w_invD; // pa/pb index UB slots
-    gcdbl_p Kt = W + P.w_Kt; // KKT entries in target order (solve prologue + updateKKTScalings)
+// KI > 1: KI instances in lock-step.  Wg = the group's workspace; the factor arrays (UF, UB, D, invD, Kt) are
+// KI-interleaved at KI * offset (device_types.hpp: DevPat::w_split), the pair / destination indices are shared.
+template <int T, int NLDS, bool I16, int KI>
+__device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
+    ps = uni(ps); Wg = uni_ptr(Wg);
+    const DevPat &P = c_pat[ps];
+    const int tid = threadIdx.x;
+    gdbl_p UF = Wg + (size_t)KI * P.w_UF, U = Wg + (size_t)KI * P.w_UB, D = Wg + (size_t)KI * P.w_D, invD = Wg + (size_t)KI * P.w_invD; // pa/pb index UB slots
+    gcdbl_p Kt = Wg + (size_t)KI * P.w_Kt; // KKT entries in target order (solve prologue + updateKKTScalings)
     __syncthreads();
-    TICK_BEGIN;
+    unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
+    const int ns = P.fac_ns;
+    if (ns > 0) { // (empty problem, dim_K = 0: nothing to factorise, and no slice table to decode)
     // Phase A of a level: target value = K entry - sum over pairs U[i,k] * L[j,k]  (U = UB slots, L = UF slots);
     // diagonal targets give D and 1/D, the others U[i,j].  Phase B (after a barrier, D of the level is known):
     // L[i,j] = U[i,j] / D[j] into the forward slots.  Slices of one level are independent.
     // Everything that does not depend on factor values (pair indices, the K entry, destinations) is loaded
     // FAC_DEPTH slices ahead, across the level barriers, so a level costs one dependent gather round trip
     // per phase instead of an index load + gather + source-index load + value load chain.
-    unsigned long long ft0 = (tid == 0) ? wall_clock64() : 0ull; // finer phase timers (thread 0's view)
-#define FTICK(slot) do { if (tid == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - ft0; ft0 = t1_; } } while (0)
-    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
-    double carry = 0.; // partial sum of targets cut into sub-slices
-    const int ns = P.fac_ns;
-    if (ns == 0) { // empty problem (dim_K = 0): nothing to factorise, and no slice table to decode
-        if (tid == 0) wi.n_factor++;
-        __syncthreads();
-        return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
-    }
+    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv[KI]; int dst; } q[FAC_DEPTH];
+    double carry[KI]; // partial sum of targets cut into sub-slices
+#pragma unroll
+    for (int k = 0; k < KI; k++) carry[k] = 0.;
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
     // the loads that need them, so that their round trip is not on the path either
-    auto fmeta = [&](int sidx) { return tab_lds ? slice_at(LDS_TABLE(P.lm_fac), sidx) : slice_at(P.fac_sl, sidx); };
+    auto fmeta = [&](int sidx) { return tab_lds ? slice_at(reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)KI * NLDS * P.Npad) + P.lm_fac, sidx) : slice_at(P.fac_sl, sidx); };
     auto fload = [&](const Sl &nm, FSlot &o) {
         o.row0 = nm.row0; o.cnt = nm.cnt; o.lg = nm.lg; o.K = nm.K; o.off = nm.off;
         o.newlev = nm.newlev; o.last = nm.last;
@@ -591,14 +717,14 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             }
         }
         const int t = act ? o.row0 + (tid >> o.lg) : 0;
-        o.kv = ld_u32(Kt, t);
+        ldK_g<KI, false>(Kt, t, o.kv);
         o.dst = ld_u32(P.fac_dst, t);
     };
 #pragma unroll
     for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(d, ns - 1)), q[d]);
     Sl pm = fmeta(min(FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
-    double gu[ELL_KMAX], gl[ELL_KMAX];
+    double gu[ELL_KMAX][KI], gl[ELL_KMAX][KI];
     bool have = false;
     for (int s0 = 0; s0 < ns; s0 += FAC_DEPTH) {
 #pragma unroll
@@ -615,58 +741,79 @@ __device__ __noinline__ int stage_factor(int ps, gdbl_p I, gdbl_p W, int iter) {
             // issued before this slice's arithmetic waits on its own (one L2 round trip per level, not per slice)
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = ld_u32((gcdbl_p)U, c.ia[u]); gl[u] = ld_u32((gcdbl_p)UF, c.ib[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, c.ia[u], gu[u]); ldK_g<KI, false>((gcdbl_p)UF, c.ib[u], gl[u]); }
             }
-            double cu[ELL_KMAX], cl[ELL_KMAX];
+            double cu[ELL_KMAX][KI], cl[ELL_KMAX][KI];
 #pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) { cu[u] = gu[u]; cl[u] = gl[u]; }
+            for (int u = 0; u < ELL_KMAX; u++)
+#pragma unroll
+                for (int k = 0; k < KI; k++) { cu[u][k] = gu[u][k]; cl[u][k] = gl[u][k]; }
             have = !c.last;
             if (have) {
                 const FSlot &nx = q[(d + 1) % FAC_DEPTH];
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { gu[u] = ld_u32((gcdbl_p)U, nx.ia[u]); gl[u] = ld_u32((gcdbl_p)UF, nx.ib[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, nx.ia[u], gu[u]); ldK_g<KI, false>((gcdbl_p)UF, nx.ib[u], gl[u]); }
             }
-            double acc = 0.;
+            double acc[KI];
 #pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) acc += cu[u] * cl[u];
-            acc = grp_reduce_to_lane0(acc, c.lg);
-            if (c.cont) acc += carry;
-            if (c.more) carry = acc;
-            else if (act && (tid & ((1 << c.lg) - 1)) == 0) {
-                double val = c.kv - acc;
+            for (int k = 0; k < KI; k++) {
+                double a = 0.;
+#pragma unroll
+                for (int u = 0; u < ELL_KMAX; u++) a += cu[u][k] * cl[u][k];
+                a = grp_reduce_to_lane0(a, c.lg);
+                if (c.cont) a += carry[k];
+                acc[k] = a;
+            }
+            if (c.more) {
+#pragma unroll
+                for (int k = 0; k < KI; k++) carry[k] = acc[k];
+            } else if (act && (tid & ((1 << c.lg) - 1)) == 0) {
+                double val[KI];
+#pragma unroll
+                for (int k = 0; k < KI; k++) val[k] = c.kv[k] - acc[k];
                 if (c.dst < 0) { // diagonal target: -(j+1), plus DIAG_POS when the quasi-definite sign of pivot j is +
                     const int e = -c.dst - 1, j = e & (DIAG_POS - 1);
-                    if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
-                        const double sg = (e & DIAG_POS) ? 1. : -1.;
-                        if (sg * val <= g_S.dyn_eps) val = sg * g_S.dyn_delta;
+                    double iv[KI];
+#pragma unroll
+                    for (int k = 0; k < KI; k++) {
+                        if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
+                            const double sg = (e & DIAG_POS) ? 1. : -1.;
+                            if (sg * val[k] <= g_S.dyn_eps) val[k] = sg * g_S.dyn_delta;
+                        }
+                        iv[k] = 1. / val[k];
+                        if (val[k] == 0.) inst_state<KI>(k).fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
                     }
-                    D[j] = val; invD[j] = 1. / val;
-                    if (val == 0.) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
-                } else U[c.dst] = val;
+                    stK<KI>(D, j, val); stK<KI>(invD, j, iv);
+                } else stK<KI>(U, c.dst, val);
             }
             if (c.last) {
-                FTICK(TK_FA);
                 __syncthreads();
-                FTICK(TK_FW1);
                 // phase B over the level's targets, four per thread in flight (index loads, then the two gathers)
-                struct PB { int dst, dstF; double u, d; };
+                struct PB { int dst, dstF; double u[KI], d[KI]; };
                 for_t_pre<T, 4>(lvl_t1 - lvl_t0, [&](int k) {
                     const int t = lvl_t0 + k, dst = P.fac_dst[t];
-                    return PB{dst, P.fac_dstF[t], U[max(dst, 0)], invD[P.fac_col[t]]};
-                }, [&](int k, const PB &r) { if (r.dst >= 0) UF[r.dstF] = r.u * r.d; });
-                FTICK(TK_FB);
+                    PB r; r.dst = dst; r.dstF = P.fac_dstF[t];
+                    ldK<KI>(U, max(dst, 0), r.u); ldK<KI>(invD, P.fac_col[t], r.d);
+                    return r;
+                }, [&](int k, const PB &r) {
+                    if (r.dst >= 0) {
+                        double o[KI];
+#pragma unroll
+                        for (int kk = 0; kk < KI; kk++) o[kk] = r.u[kk] * r.d[kk];
+                        stK<KI>(UF, r.dstF, o);
+                    }
+                });
                 __syncthreads();
-                FTICK(TK_FW2);
             }
         }
     }
-    if (tid == 0) wi.n_factor++;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < KI; k++) { ShI &st = inst_state<KI>(k); st.wi.n_factor++; st.tick[TK_FACTOR] += wall_clock64() - tk0_; }
+    }
     __syncthreads();
-    TICK_END(TK_FACTOR);
-    if (g_S.fl[FL_FATAL]) return ST_DONE; // ref :901-905,1166-1170 (no backscale)
-    return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
 }
-
 
 // ============================================================================================
 // Tile mode (dense fronts): L is a block-sparse matrix of dense 16 x 16 fp64 tiles (host: tiles.hpp).
@@ -854,8 +1001,11 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws) {
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
-template <int T, int NLDS, bool I16>
-__device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
+// One instance (state in g_S; slab I, workspace W = Wg + ki * w_split); the factor's K stream Kt is KI-interleaved.
+template <int T, int NLDS, bool I16, int KI>
+__device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int iter) {
+    Wg = uni_ptr(Wg); ki = uni(ki);
+    gdbl_p W = Wg + (size_t)ki * c_pat[uni(ps)].w_split;
     STAGE_PROLOGUE
     iter = uni(iter);
     gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
@@ -985,10 +1135,10 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     }
     // ---- updateScalings (ref :411-479) + updateKKTScalings (ref :1691-1732) ----
     // the scaling block goes to the instance slab (Vv) and to the factor's target-ordered value stream (Kt)
-    gdbl_p Kt = W + P.w_Kt;
+    gdbl_p Kt = Wg + (size_t)KI * P.w_Kt + ki; // element t of this instance at Kt[t * KI]
     for_t_pre<T, 4>(l, [&](int i) { return IV2{P.v2t[i], wsl[i], wz[i]}; }, [&](int i, const IV2 &r) {
         const double v = r.a / r.b;
-        lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; Kt[r.i] = -v - DELTASTAT;
+        lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; Kt[(size_t)r.i * KI] = -v - DELTASTAT;
     });
     double firstfail = 1e300;
     if (P.nc > 0) {
@@ -1057,13 +1207,13 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
             // KKT scaling block, slot order of ref cacheIndices :1955-1986: D[d], vdiag, v[d-1], udiag, u[d]
             for (int k = ln; k < d; k += g) {
                 const double qk = (k >= 1) ? (0.5 / gam) * (wsl[o + k] / snorm - wz[o + k] / znorm) : 0.;
-                if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[vt[d + k]] = e; }
+                if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[(size_t)vt[d + k] * KI] = e; }
                 const double e0 = (k == 0) ? -eta2 * d1 - DELTASTAT : -eta2 - DELTASTAT;
                 const double e2 = (k == 0) ? -eta2 * u0 : -eta2 * u1 * qk;
-                v[k] = e0; Kt[vt[k]] = e0;
-                v[2 * d + 1 + k] = e2; Kt[vt[2 * d + 1 + k]] = e2;
+                v[k] = e0; Kt[(size_t)vt[k] * KI] = e0;
+                v[2 * d + 1 + k] = e2; Kt[(size_t)vt[2 * d + 1 + k] * KI] = e2;
             }
-            if (ln == 0) { v[d] = -eta2; Kt[vt[d]] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[vt[2 * d]] = eta2 + DELTASTAT; }
+            if (ln == 0) { v[d] = -eta2; Kt[(size_t)vt[d] * KI] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[(size_t)vt[2 * d] * KI] = eta2 + DELTASTAT; }
         });
     }
     __syncthreads();
@@ -1072,20 +1222,35 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     return ST_FACTOR;
 }
 
-// ---------------- the KKT stages: pick rhs / outputs, solveKKT, post-process ----------------
-template <int T, int NLDS, bool I16>
-__device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
-    STAGE_PROLOGUE
-    stage = uni(stage);
-    gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
-    gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b;
-    gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
-    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
-    gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;     // elimination order (what the triangular sweeps consume)
-    gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k; // same values as [x | y | z] (what the residual reads)
-    gdbl_p dx1 = W + P.w_dx1, dy1 = W + P.w_dy1, dz1 = W + P.w_dz1, dx2 = W + P.w_dx2, dy2 = W + P.w_dy2, dz2 = W + P.w_dz2;
-    gdbl_p dsw = W + P.w_dsw, wdz = W + P.w_wdz, dsa = W + P.w_dsa, t1 = W + P.w_t1, t2 = W + P.w_t2;
-    gdbl_p lpw = W + P.w_lpw, lpv = W + P.w_lpv, csc = W + P.w_csc, qv = W + P.w_qv;
+// ---------------- the KKT stages, part 1: solveKKT (ref :1471-1620) for the KI instances of the workgroup in lock-step ----------------
+// Instance k: slab Ik, workspace Wg + k * w_split; the KKT-space vectors (sweep vector SV, iterate X, residual E, parked
+// iterate Xg, last correction dxr) and the factor are KI-interleaved.  Every instance keeps its own refinement state
+// (step count, previous error, done flag): the loop runs until all of them have stopped; an instance that has stopped
+// keeps its iterate while the others take further steps (its lanes still compute, the result is discarded).
+// amask: bit k set = instance k takes part (not finished, slot in use).
+template <int T, int NLDS, bool I16, int KI>
+__device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, int stage, int amask) {
+    ps = uni(ps); I0 = uni_ptr(I0); I1 = uni_ptr(I1); Wg = uni_ptr(Wg); stage = uni(stage); amask = uni(amask);
+    const DevPat &P = c_pat[ps];
+    const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
+    const int tid = threadIdx.x;
+    int phase = 0;
+    static_assert(KI == 1 || NLDS == 1, "lock-step groups keep one KKT-space vector per instance in LDS");
+    gdbl_p Ik[KI_MAX] = {I0, I1};
+    const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
+    const bool first = (stage == ST_KKT_INIT1 || stage == ST_KKT1);
+    gcdbl_p cagv[KI], rAv[KI], rGv[KI], rhsp[KI], bx[KI], by[KI], bz[KI], lpv[KI], csc[KI], qv[KI];
+    gdbl_p dx[KI], dy[KI], dz[KI];
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+        gdbl_p I = Ik[k], W = Wg + (size_t)k * P.w_split;
+        cagv[k] = I + P.i_cag; rAv[k] = I + P.i_rA; rGv[k] = I + P.i_rG;
+        rhsp[k] = W + (first ? P.w_rhs1 : P.w_rhs2);                   // elimination order (what the triangular sweeps consume)
+        gcdbl_p rhsk = W + (first ? P.w_rhs1k : P.w_rhs2k);            // same values as [x | y | z] (what the residual reads)
+        bx[k] = rhsk; by[k] = rhsk + n; bz[k] = rhsk + np;
+        lpv[k] = W + P.w_lpv; csc[k] = W + P.w_csc; qv[k] = W + P.w_qv;
+        dx[k] = W + (first ? P.w_dx1 : P.w_dx2); dy[k] = W + (first ? P.w_dy1 : P.w_dy2); dz[k] = W + (first ? P.w_dz1 : P.w_dz2);
+    }
     // KKT-space vectors, in elimination order: X = current solution, E = rhs / residual / solve vector.
     // Both in LDS (NLDS = 2) or both in the workspace slab (NLDS = 0, patterns too large for LDS).
     // Roles: SV = vector the triangular sweeps run on; X = solution the residual gathers from; E = where the
@@ -1093,115 +1258,142 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     // per CU): the LDS vector alternates between the sweep vector and X -- the ~25k gathers of a residual hit
     // LDS, its ~N scattered stores go to E in the workspace slab, and X is parked in the slab (Xg) only while a
     // further refinement step borrows the LDS vector.  NLDS = 0: everything in the workspace slab.
-    auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return W + P.w_ek; }();
-    auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return W + P.w_xk; }();
-    auto E = [&] { if constexpr (NLDS == 1) return W + P.w_ek; else return SV; }();
-    gdbl_p Xg = W + P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
-    auto tab_cag = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_cag); else return P.cag_sl; }();
-    auto tab_rA = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rA); else return P.rA_sl; }();
-    auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
-    gdbl_p dxr = W + P.w_dxr;
-    gdbl_p UF = W + P.w_UF, UB = W + P.w_UB, invD = W + P.w_invD;
+    auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return Wg + (size_t)KI * P.w_ek; }();
+    auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return Wg + (size_t)KI * P.w_xk; }();
+    auto E = [&] { if constexpr (NLDS == 1) return Wg + (size_t)KI * P.w_ek; else return SV; }();
+    gdbl_p Xg = Wg + (size_t)KI * P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
+    const PackedSlice *tabs = reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)KI * NLDS * P.Npad);
+    auto tab_cag = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_cag; else return P.cag_sl; }();
+    auto tab_rA = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rA; else return P.rA_sl; }();
+    auto tab_rG = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rG; else return P.rG_sl; }();
+    gdbl_p dxr = Wg + (size_t)KI * P.w_dxr;
+    gdbl_p UF = Wg + (size_t)KI * P.w_UF, UB = Wg + (size_t)KI * P.w_UB, invD = Wg + (size_t)KI * P.w_invD;
     __syncthreads();
-    TICK_BEGIN;
-    const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
-    const bool first = (stage == ST_KKT_INIT1 || stage == ST_KKT1);
-    gcdbl_p rhsp = first ? rhs1 : rhs2, rhsk = first ? rhs1k : rhs2k;
-    gdbl_p dx = first ? dx1 : dx2, dy = first ? dy1 : dy2, dz = first ? dz1 : dz2;
-    int kref;
+    unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
+    auto tick = [&](int slot) { // the lock-step time is booked on every participating instance
+        if (tid == 0) {
+            const unsigned long long t1_ = wall_clock64();
+#pragma unroll
+            for (int k = 0; k < KI; k++) if ((amask >> k) & 1) inst_state<KI>(k).tick[slot] += t1_ - tk0_;
+            tk0_ = t1_;
+        }
+    };
+    // per-instance refinement state (workgroup-uniform: every thread sees the same reduction results)
+    int kcnt[KI]; double nerr_prev[KI], thr[KI]; bool rdone[KI];
     {
-        // ---------------- solveKKT (ref :1471-1620) ----------------
-        gcdbl_p bx = rhsk, by = rhsk + n, bz = rhsk + np;
-        double nr = 0.;
-        for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{rhsp[i < N ? i : max(N - 1, 0)]}; }, [&](int i, const V1 &r) { // N = 0 (empty problem): slot 0 of the N+16 allocation
-            const double v = (i < N) ? r.a : 0.; // load the rhs; slots >= N stay 0
-            SV[i] = v; nr = fmax(nr, fabs(v));
+        double nr[KI];
+#pragma unroll
+        for (int k = 0; k < KI; k++) nr[k] = 0.;
+        for_t_pre<T, 6>(P.Npad, [&](int i) {
+            VKI<KI> r;
+#pragma unroll
+            for (int k = 0; k < KI; k++) r.v[k] = rhsp[k][i < N ? i : max(N - 1, 0)]; // N = 0 (empty problem): slot 0 of the N+16 allocation
+            return r;
+        }, [&](int i, const VKI<KI> &r) {
+            double v[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) { v[k] = (i < N) ? r.v[k] : 0.; nr[k] = fmax(nr[k], fabs(v[k])); } // load the rhs; slots >= N stay 0
+            stK<KI>(SV, i, v);
         });
-        nr = blk_reduce1<OpMax, T>(phase, nr);
-        const double thr = (1. + nr) * LINSYSACC;
-        double nerr_prev = DBL_MAX;
-        int k = -1;
-        for (;;) {
-            // -------- SV <- L^-T D^-1 L^-1 SV in elimination order (replaces ldlt.solve, ref :1477,1599) --------
-            TICK_END(TK_KRES);
-            __syncthreads();
-            // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
-            const bool wave0 = uni(tid >> 6) == 0;
-            if (P.tile) { // dense fronts: tile mat-vecs over the block levels
-                if constexpr (NLDS >= 1) tile_solve<T, true>(P, W, SV); else tile_solve<T, false>(P, W, SV);
-                TICK_END(TK_FWD);
-            } else
-            if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-                tri_sweep<T, true, true, false, I16>(LDS_TABLE(P.lm_f), P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
-                if (wave0) {
-                    tri_sweep<T, true, true, true, I16>(LDS_TABLE(P.lm_f) + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                    TICK_END(TK_FWD);
-                    tri_sweep<T, false, true, true, I16>(LDS_TABLE(P.lm_b), P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
-                }
-                __syncthreads();
-                tri_sweep<T, false, true, false, I16>(LDS_TABLE(P.lm_b) + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
-            } else {
-                tri_sweep<T, true, false, false, I16>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                if (wave0) {
-                    tri_sweep<T, true, false, true, I16>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                    tri_sweep<T, false, false, true, I16>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
-                }
-                __syncthreads();
-                tri_sweep<T, false, false, false, I16>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+        blk_reduce<OpMax, T, KI>(phase, nr);
+#pragma unroll
+        for (int k = 0; k < KI; k++) { thr[k] = (1. + nr[k]) * LINSYSACC; nerr_prev[k] = DBL_MAX; kcnt[k] = -1; rdone[k] = !((amask >> k) & 1); }
+    }
+    for (int pass = 0;; pass++) {
+        // -------- SV <- L^-T D^-1 L^-1 SV in elimination order (replaces ldlt.solve, ref :1477,1599) --------
+        tick(TK_KRES);
+        __syncthreads();
+        // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
+        const bool wave0 = uni(tid >> 6) == 0;
+        if (P.tile) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
+            if constexpr (KI == 1) { if constexpr (NLDS >= 1) tile_solve<T, true>(P, Wg, SV); else tile_solve<T, false>(P, Wg, SV); }
+        } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
+            tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
+            if (wave0) {
+                tri_sweep<T, true, true, true, I16, KI>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, true, true, I16, KI>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
-            if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
-                if (k >= 0) for_t_pre<T, 6>(N, [&](int i) { return V1{Xg[i]}; }, [&](int i, const V1 &r) { SV[i] = r.a + SV[i]; });
-            } else {
-                if (k < 0) for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{SV[i]}; }, [&](int i, const V1 &r) { X[i] = r.a; }); // x = first solve (slot N.. = 0)
-                else for_t_pre<T, 6>(N, [&](int i) { return V2{SV[i], X[i]}; }, [&](int i, const V2 &r) { dxr[i] = r.a; X[i] = r.b + r.a; }); // x += dx_ref (ref :1602)
-            }
-            if (tid == 0) wi.n_ldlsolve++;
             __syncthreads();
-            TICK_END(TK_LDL);
-            k++;
-            // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
-            double nex = 0., ney = 0., nez = 0.;
-            struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
-            ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots, [&](int j) { return PreK{ld_u32(bx, j), 0., ld_u32(P.ipx, j), 0}; },
-                        [&](int j, double s, const PreK &pr) {
-                const int o = pr.o;
-                const double e = pr.b - s - DELTASTAT * X[o]; // ex = bx - G'dz - A'dy - delta dx
-                E[o] = e; nex = fmax(nex, fabs(e));
+            tri_sweep<T, false, true, false, I16, KI>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+        } else {
+            tri_sweep<T, true, false, false, I16, KI>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+            if (wave0) {
+                tri_sweep<T, true, false, true, I16, KI>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, false, true, I16, KI>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            }
+            __syncthreads();
+            tri_sweep<T, false, false, false, I16, KI>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+        }
+        // x = first solve / x += dx_ref (ref :1602); an instance that has stopped keeps its iterate
+        if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
+            if (pass > 0) for_t_pre<T, 6>(N, [&](int i) { VKI<KI> r; ldK<KI>(Xg, i, r.v); return r; }, [&](int i, const VKI<KI> &r) {
+                double c[KI], o[KI];
+                ldK<KI>(SV, i, c);
+#pragma unroll
+                for (int k = 0; k < KI; k++) o[k] = rdone[k] ? r.v[k] : r.v[k] + c[k];
+                stK<KI>(SV, i, o);
             });
-            ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots, [&](int r) { return PreK{ld_u32(by, r), 0., ld_u32(P.ipy, r), 0}; },
-                        [&](int r, double s, const PreK &pr) {
-                const int o = pr.o;
-                const double e = pr.b - s + DELTASTAT * X[o]; // ey = by - A dx + delta dy
-                E[o] = e; ney = fmax(ney, fabs(e));
-            });
-            ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
-                        [&](int i) { return PreK{ld_u32(bz, i), ld_u32((gcdbl_p)lpv, i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i)}; },
-                        [&](int i, double s, const PreK &pr) {
-                const int o = pr.o;
-                const double xo = X[o];
-                double v = pr.b - s + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
-                if (i < l) { v += init ? xo : pr.w * xo; nez = fmax(nez, fabs(v)); } // ... + V dz (LP part)
-                E[o] = v;
-            });
-            if (P.nc > 0) {
-                __syncthreads();
-                // cone blocks (expanded): ez += dz_true (init) or scale2add (ref :1629-1662)
+        } else { // (KI = 1)
+            if (pass == 0) for_t_pre<T, 6>(P.Npad, [&](int i) { return V1{SV[i]}; }, [&](int i, const V1 &r) { X[i] = r.a; }); // x = first solve (slot N.. = 0)
+            else for_t_pre<T, 6>(N, [&](int i) { return V2{SV[i], X[i]}; }, [&](int i, const V2 &r) { dxr[i] = r.a; X[i] = r.b + r.a; });
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < KI; k++) if (!rdone[k]) inst_state<KI>(k).wi.n_ldlsolve++;
+        }
+#pragma unroll
+        for (int k = 0; k < KI; k++) if (!rdone[k]) kcnt[k]++;
+        __syncthreads();
+        tick(TK_LDL);
+        // ---- residual e = rhs - K~ x, matrix-free (ref :1511-1567), written in elimination order into E ----
+        double nex[KI], ney[KI], nez[KI];
+#pragma unroll
+        for (int k = 0; k < KI; k++) nex[k] = ney[k] = nez[k] = 0.;
+        struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
+        ell_dots_k<T, I16, KI>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
+                    [&](int k, int j) { return PreK{ld_u32(bx[k], j), 0., ld_u32(P.ipx, j), 0}; },
+                    [&](int k, int j, double s, const PreK &pr) {
+            const int o = pr.o;
+            const double e = pr.b - s - DELTASTAT * X[o * KI + k]; // ex = bx - G'dz - A'dy - delta dx
+            E[o * KI + k] = e; nex[k] = fmax(nex[k], fabs(e));
+        });
+        ell_dots_k<T, I16, KI>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
+                    [&](int k, int r) { return PreK{ld_u32(by[k], r), 0., ld_u32(P.ipy, r), 0}; },
+                    [&](int k, int r, double s, const PreK &pr) {
+            const int o = pr.o;
+            const double e = pr.b - s + DELTASTAT * X[o * KI + k]; // ey = by - A dx + delta dy
+            E[o * KI + k] = e; ney[k] = fmax(ney[k], fabs(e));
+        });
+        ell_dots_k<T, I16, KI>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
+                    [&](int k, int i) { return PreK{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i)}; },
+                    [&](int k, int i, double s, const PreK &pr) {
+            const int o = pr.o;
+            const double xo = X[o * KI + k];
+            double v = pr.b - s + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
+            if (i < l) { v += init ? xo : pr.w * xo; nez[k] = fmax(nez[k], fabs(v)); } // ... + V dz (LP part)
+            E[o * KI + k] = v;
+        });
+        if (P.nc > 0) {
+            __syncthreads();
+            // cone blocks (expanded): ez += dz_true (init) or scale2add (ref :1629-1662)
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
                 for_cones<T>(ps, [&](int c, auto G, int ln) {
                     constexpr int g = decltype(G)::value;
                     const int d = P.cq[c], o = P.cone_off[c];
-                    const int p1 = P.ipz[o], p3 = P.ipv[c], p4 = P.ipu[c];
+                    const int p1 = P.ipz[o] * KI + k, p3 = P.ipv[c] * KI + k, p4 = P.ipu[c] * KI + k;
                     double mx = 0.;
                     if (init) {
-                        for (int q = ln; q < d; q += g) { const int pq = P.ipz[o + q]; const double v = E[pq] + X[pq]; E[pq] = v; mx = fmax(mx, fabs(v)); }
+                        for (int q = ln; q < d; q += g) { const int pq = P.ipz[o + q] * KI + k; const double v = E[pq] + X[pq]; E[pq] = v; mx = fmax(mx, fabs(v)); }
                         if (ln == 0) { const double x3 = X[p3], x4 = X[p4]; E[p3] = x3; E[p4] = x4; mx = fmax(mx, fmax(fabs(x3), fabs(x4))); }
                     } else {
-                        gcdbl_p cs = csc + c * CSC_STRIDE;
+                        gcdbl_p cs = csc[k] + c * CSC_STRIDE;
                         const double eta2 = cs[CS_ETA2], x1 = X[p1], x3 = X[p3], x4 = X[p4];
                         const double tt = cs[CS_V1] * x3 + cs[CS_U1] * x4;
                         double qtx = 0.;
                         for (int q = 1 + ln; q < d; q += g) {
-                            const int pq = P.ipz[o + q];
-                            const double qq = qv[o + q], xq = X[pq];
+                            const int pq = P.ipz[o + q] * KI + k;
+                            const double qq = qv[k][o + q], xq = X[pq];
                             const double v = E[pq] + eta2 * (xq + tt * qq);
                             E[pq] = v; mx = fmax(mx, fabs(v));
                             qtx += qq * xq;
@@ -1215,36 +1407,73 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
                             mx = fmax(mx, fmax(fabs(v1), fmax(fabs(v3), fabs(v4))));
                         }
                     }
-                    nez = fmax(nez, mx);
+                    nez[k] = fmax(nez[k], mx);
                 });
             }
-            double nv[3] = {nex, ney, nez};
-            blk_reduce<OpMax, T, 3>(phase, nv);
-            double nerr = fmax(nv[0], nv[2]);
-            if (p > 0) nerr = fmax(nerr, nv[1]);
-            if (k > 0 && nerr > nerr_prev) { // got worse: undo and quit (ref :1579-1585)
-                if constexpr (NLDS == 1) { FOR_T(i, N) X[i] = Xg[i]; } // Xg still holds the previous iterate
-                else { FOR_T(i, N) X[i] -= dxr[i]; }
-                k--;
-                break;
-            }
-            if (k == NITREF || nerr < thr || (k > 0 && nerr_prev < IRERRFACT * nerr)) break;
-            nerr_prev = nerr;
-            if constexpr (NLDS == 1) { // another step: park the iterate in the slab, residual -> sweep vector (unit stride)
-                __syncthreads();
-                for_t_pre<T, 6>(N, [&](int i) { return V1{E[i]}; }, [&](int i, const V1 &r) { Xg[i] = X[i]; SV[i] = r.a; });
-            }
         }
-        __syncthreads();
-        for_t_pre<T, 4>(n, [&](int j) { return V1{X[P.ipx[j]]}; }, [&](int j, const V1 &r) { dx[j] = r.a; });
-        for_t_pre<T, 4>(p, [&](int j) { return V1{X[P.ipy[j]]}; }, [&](int j, const V1 &r) { dy[j] = r.a; });
-        for_t_pre<T, 8>(m, [&](int i) { return V1{X[P.ipz[i]]}; }, [&](int i, const V1 &r) { dz[i] = r.a; });
-        __syncthreads();
-        kref = k;
-        TICK_END(TK_KRES);
+        double nv[3 * KI];
+#pragma unroll
+        for (int k = 0; k < KI; k++) { nv[3 * k] = nex[k]; nv[3 * k + 1] = ney[k]; nv[3 * k + 2] = nez[k]; }
+        blk_reduce<OpMax, T, 3 * KI>(phase, nv);
+        bool undo[KI], all_done = true;
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            undo[k] = false;
+            if (rdone[k]) continue;
+            double nerr = fmax(nv[3 * k], nv[3 * k + 2]);
+            if (p > 0) nerr = fmax(nerr, nv[3 * k + 1]);
+            if (kcnt[k] > 0 && nerr > nerr_prev[k]) { undo[k] = true; kcnt[k]--; rdone[k] = true; } // got worse: undo and quit (ref :1579-1585)
+            else if (kcnt[k] == NITREF || nerr < thr[k] || (kcnt[k] > 0 && nerr_prev[k] < IRERRFACT * nerr)) rdone[k] = true;
+            else { nerr_prev[k] = nerr; all_done = false; }
+        }
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            if (!undo[k]) continue;
+            if constexpr (NLDS == 1) { FOR_T(i, N) X[i * KI + k] = Xg[i * KI + k]; } // Xg still holds the previous iterate
+            else { FOR_T(i, N) X[i] -= dxr[i]; }
+        }
+        if (all_done) break;
+        if constexpr (NLDS == 1) { // another step: park the iterate in the slab, residual -> sweep vector (unit stride)
+            __syncthreads();
+            for_t_pre<T, 6>(N, [&](int i) { VKI<KI> r; ldK<KI>(E, i, r.v); return r; }, [&](int i, const VKI<KI> &r) {
+                double c[KI];
+                ldK<KI>(X, i, c); stK<KI>(Xg, i, c); stK<KI>(SV, i, r.v);
+            });
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+        if (!((amask >> k) & 1)) continue;
+        for_t_pre<T, 4>(n, [&](int j) { return V1{X[P.ipx[j] * KI + k]}; }, [&](int j, const V1 &r) { dx[k][j] = r.a; });
+        for_t_pre<T, 4>(p, [&](int j) { return V1{X[P.ipy[j] * KI + k]}; }, [&](int j, const V1 &r) { dy[k][j] = r.a; });
+        for_t_pre<T, 8>(m, [&](int i) { return V1{X[P.ipz[i] * KI + k]}; }, [&](int i, const V1 &r) { dz[k][i] = r.a; });
+        if (tid == 0) inst_state<KI>(k).kref = kcnt[k];
+    }
+    __syncthreads();
+    tick(TK_KRES);
+}
 
-    // ---------------- post-processing of each KKT stage ----------------
+// ---------------- the KKT stages, part 2: post-processing of one instance (its state is in g_S) ----------------
+template <int T>
+__device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
+    ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W); stage = uni(stage);
+    const DevPat &P = c_pat[ps];
+    const int n = P.n, p = P.p, m = P.m, l = P.l, np = P.n + P.p;
+    const int tid = threadIdx.x;
+    DevInfo &wi = g_S.wi;
+    int phase = 0;
+    gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b;
+    gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
+    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
+    gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;     // elimination order (what the triangular sweeps consume)
+    gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k; // same values as [x | y | z] (what the residual reads)
+    gdbl_p dx1 = W + P.w_dx1, dy1 = W + P.w_dy1, dz1 = W + P.w_dz1, dx2 = W + P.w_dx2, dy2 = W + P.w_dy2, dz2 = W + P.w_dz2;
+    gdbl_p dsw = W + P.w_dsw, wdz = W + P.w_wdz, dsa = W + P.w_dsa, t1 = W + P.w_t1, t2 = W + P.w_t2;
+    gdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
+    const int kref = g_S.kref;
+    __syncthreads();
+    TICK_BEGIN;
     if (stage == ST_KKT_INIT1) { // ref :933-939
         if (tid == 0) wi.nitref1 = kref;
         for_t_pre<T, 4>(n, [&](int j) { return V1{dx1[j]}; }, [&](int j, const V1 &r) { wx[j] = r.a; });
@@ -1375,9 +1604,12 @@ __device__ __noinline__ int stage_kkt(int ps, gdbl_p I, gdbl_p W, int stage) {
     return stage;
 }
 
-template <int T, int NLDS, bool I16>
-__device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, double warm) {
+// ---------------- per-instance prologue of a solve (its state ends up in g_S); returns 1 if it was warm-started ----------------
+template <int T, int KI>
+__device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p Wg, int ki, double warm) {
+    ps = uni(ps); I = uni_ptr(I); Wg = uni_ptr(Wg); ki = uni(ki);
     const DevPat &P = c_pat[ps];
+    gdbl_p W = Wg + (size_t)ki * P.w_split;
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
     const int tid = threadIdx.x;
     DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
@@ -1386,15 +1618,15 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
         gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2, rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k;
         int phase = 0;
-    __syncthreads();
+        __syncthreads();
         if (tid == 0) { // sticky across solve() calls like the reference's w.i
             wi = *ginfo; g_S.bi = wi;
             // warm start (N3, not in the reference): needs a previous OPTIMAL solve of this instance
             g_S.fl[FL_WARM] = (warm > 0. && wi.n_factor > 0 && (wi.exitcode == 0 || wi.exitcode == 10)) ? 1 : 0;
             wi.n_factor = 0; wi.n_ldlsolve = 0;
-            g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7;
-        for (int q = 0; q < 12; q++) g_S.tick[q] = 0;
-        g_S.tick[7] = wall_clock64();
+            g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7; g_S.done = 0; g_S.kref = 0;
+            for (int q = 0; q < 12; q++) g_S.tick[q] = 0;
+            g_S.tick[7] = wall_clock64();
         }
         // resetKKTScalings (ref :807-846)
         FOR_T(i, l) Vv[i] = -1.;
@@ -1410,14 +1642,14 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         FOR_T(i, np + m) { rhs1k[i] = 0.; rhs2k[i] = 0.; }
         __syncthreads();
         { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
-            gdbl_p Kt = W + P.w_Kt;
+            gdbl_p Kt = Wg + (size_t)KI * P.w_Kt + ki; // KI-interleaved: element t of this instance at Kt[t * KI]
             if (P.tile) { // dense tile image of K: zero, then scatter the structural entries (+ 1 on the padding diagonals)
                 const int nimg = (P.nb + P.nt) * 256;
                 FOR_T(t, nimg) Kt[t] = 0.;
                 __syncthreads();
                 for_t_pre<T, 8>(P.tl_nimg, [&](int e) { return IV1{P.tl_img_dst[e], I[P.tl_img_src[e]]}; }, [&](int e, const IV1 &r) { Kt[r.i] = r.a; });
             } else
-            for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[t] = r.a; });
+            for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[(size_t)t * KI] = r.a; });
         }
         {
             double nr3[3] = {0., 0., 0.};
@@ -1429,12 +1661,10 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
                 g_S.sv[SV_RESX0] = fmax(1., sqrt(nr3[0])); g_S.sv[SV_RESY0] = fmax(1., sqrt(nr3[1])); g_S.sv[SV_RESZ0] = fmax(1., sqrt(nr3[2]));
             }
         }
-
     }
-    int stage = ST_FACTOR;
-    int iter = -1; // -1 while initialising
     __syncthreads();
-    if (g_S.fl[FL_WARM]) {
+    if (!g_S.fl[FL_WARM]) return 0;
+    {
         // ---- warm start: previous (x, y, z, s) of this instance (still in its slab, backscaled) re-equilibrated and
         // pushed into the cone -- LP rows floored at warm * mean|.|, cone heads at ||tail|| + the same margin --
         // instead of the two initialisation solves (ref :929-972); tau = kap = 1, first pass = iteration 0.
@@ -1465,37 +1695,84 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
             g_S.sv[SV_PRESPREV] = DBL_MAX;
         }
         __syncthreads();
-        stage = ST_RESID; iter = 0;
     }
-    while (stage != ST_DONE) {
-        if (stage == ST_FACTOR) stage = c_pat[ps].tile ? stage_factor_tiles<T, NLDS>(ps, I, W, iter) : stage_factor<T, NLDS, I16>(ps, I, W, iter);
-        else if (stage == ST_RESID) stage = stage_resid<T, NLDS, I16>(ps, I, W, iter);
-        else {
-            const int prev = stage;
-            stage = stage_kkt<T, NLDS, I16>(ps, I, W, stage);
-            if (stage == ST_RESID) iter = (prev == ST_KKT_INIT2) ? 0 : iter + 1; // a pass of the main loop completed
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
+    return 1;
+}
+
+// an instance has finished (its state is in g_S): exit code, Information and the phase timers go back to its slab / workspace
+__device__ __forceinline__ void instance_end(const DevPat &P, gdbl_p I, gdbl_p W) {
+    if (threadIdx.x == 0) {
+        DevInfo &wi = g_S.wi;
         wi.exitcode = g_S.fl[FL_FATAL] ? -7 : g_S.fl[FL_CODE];
-        *ginfo = wi;
+        *reinterpret_cast<DevInfo *>(I + P.i_info) = wi;
         // phase timers (microseconds) into the last row of the trace buffer: factor, LDL solves, refinement
-        // residuals, KKT post-processing, residual/statistics/scalings stage, [5] unused, [6] total
+        // residuals, KKT post-processing, residual/statistics/scalings stage, forward part of the solves, [6] total
         gdbl_p tr = W + P.w_trace + (size_t)(TRACE_ROWS - 1) * TRACE_COLS;
         for (int q = 0; q < TK_COUNT; q++) tr[q] = (double)g_S.tick[q] * 0.01;
         tr[6] = (double)(wall_clock64() - g_S.tick[7]) * 0.01;
-        for (int q = 8; q < 12; q++) tr[q - 1] = (double)g_S.tick[q] * 0.01; // factor: phase A, barrier, phase B, barrier
+        for (int q = 8; q < 12; q++) tr[q - 1] = (double)g_S.tick[q] * 0.01;
+        g_S.done = 1;
     }
 }
 
-template <int T, int NLDS, bool I16>
-__global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
+// ---------------- one group of KI instances, whole solve (reference Solver::solve, src/eicos.cpp:848-1262) ----------------
+// The KI instances run the same stage at the same time.  Factorisation and KKT solves are lock-step code over
+// KI-interleaved arrays; everything else runs per instance with that instance's scalar state swapped into g_S.
+// An instance that finishes early (exit test, fatal pivot) is written back at once and then only rides along.
+template <int T, int NLDS, bool I16, int KI>
+__device__ __forceinline__ void solve_group(int ps, gdbl_p (&Ik)[KI_MAX], int nvalid, gdbl_p Wg, double warm) {
+    const DevPat &P = c_pat[ps];
+    int stage = ST_FACTOR, iter = -1; // iter = -1 while initialising
+    int amask = 0; // bit k: instance k is still being solved
+    for (int k = 0; k < KI; k++) {
+        if (k >= nvalid) { if constexpr (KI > 1) { if (threadIdx.x == 0) g_Sk[k].done = 1; } continue; }
+        const int w = instance_begin<T, KI>(ps, Ik[k], Wg, k, warm);
+        if (w) { stage = ST_RESID; iter = 0; } // (warm start: single-instance groups only)
+        state_out<KI>(k);
+        amask |= 1 << k;
+    }
+    __syncthreads();
+    while (amask) {
+        if (stage == ST_FACTOR) {
+            if (P.tile) { if constexpr (KI == 1) stage_factor_tiles<T, NLDS>(ps, Ik[0], Wg, iter); }
+            else stage_factor<T, NLDS, I16, KI>(ps, Wg);
+            for (int k = 0; k < KI; k++) { // zero pivot -> fatal, no backscale (ref :901-905,1166-1170)
+                if (!((amask >> k) & 1) || !inst_state<KI>(k).fl[FL_FATAL]) continue;
+                state_in<KI>(k); instance_end(P, Ik[k], Wg + (size_t)k * P.w_split); state_out<KI>(k);
+                amask &= ~(1 << k);
+            }
+            stage = (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
+        } else if (stage == ST_RESID) {
+            for (int k = 0; k < KI; k++) {
+                if (!((amask >> k) & 1)) continue;
+                state_in<KI>(k);
+                if (stage_resid<T, NLDS, I16, KI>(ps, Ik[k], Wg, k, iter) == ST_DONE) { __syncthreads(); instance_end(P, Ik[k], Wg + (size_t)k * P.w_split); amask &= ~(1 << k); }
+                state_out<KI>(k);
+            }
+            stage = ST_FACTOR;
+        } else {
+            kkt_solve<T, NLDS, I16, KI>(ps, Ik[0], Ik[KI - 1], Wg, stage, amask);
+            int next = stage;
+            for (int k = 0; k < KI; k++) {
+                if (!((amask >> k) & 1)) continue;
+                state_in<KI>(k);
+                next = kkt_post<T>(ps, Ik[k], Wg + (size_t)k * P.w_split, stage);
+                state_out<KI>(k);
+            }
+            if (next == ST_RESID) iter = (stage == ST_KKT_INIT2) ? 0 : iter + 1; // a pass of the main loop completed
+            stage = next;
+        }
+    }
+    __syncthreads();
+}
+
+template <int T, int NLDS, bool I16, int KI>
+__global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
     int ps, double *inst, double *work, int B, int *queue, const int *order, double warm, double dyn_delta, double dyn_eps) {
     const DevPat &P = c_pat[ps];
-    gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
+    gdbl_p Wg = (gdbl_p)work + (size_t)blockIdx.x * P.group_stride;
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
-        int *dst = reinterpret_cast<int *>(g_dyn + (size_t)NLDS * P.Npad);
+        int *dst = reinterpret_cast<int *>(g_dyn + (size_t)KI * NLDS * P.Npad);
         auto stage = [&](const PackedSlice EICOS_GLOBAL *src, int cnt, int at) {
             gint_p si = reinterpret_cast<gint_p>(src);
             for (int q = threadIdx.x; q < cnt * 4; q += T) dst[at * 4 + q] = si[q];
@@ -1506,17 +1783,25 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_solve(
         __syncthreads();
     }
     if (threadIdx.x == 0) { g_S.dyn_delta = dyn_delta; g_S.dyn_eps = dyn_eps; }
-    // Instances differ in iteration count (12..18 on the headline batch): after its first instance (= its own
-    // index, so that workspace slot i holds the history of instance i when the batch fits the grid) a workgroup
-    // pulls the next unsolved instance from a queue instead of striding through the batch.
-    // `order` (batches larger than the grid): instances sorted by the work their previous solve took, longest first.
-    for (int i = blockIdx.x; i < B;) {
-        const int id = order ? order[i] : i;
-        solve_instance<T, NLDS, I16>(ps, (gdbl_p)inst + (size_t)id * P.inst_stride, W, warm);
+    // Instances differ in iteration count (12..18 on the headline batch): after its first group (= its own index, so
+    // that workspace slot g holds the history of instances g KI .. g KI + KI - 1 when the batch fits the grid) a
+    // workgroup pulls the next unsolved group from a queue instead of striding through the batch.
+    // `order` (batches larger than the grid): instances sorted by the work their previous solve took, longest first --
+    // consecutive entries, i.e. the members of a group, then have about the same number of passes ahead of them.
+    for (int g = blockIdx.x; g * KI < B;) {
+        gdbl_p Ik[KI_MAX];
+        int nvalid = 0;
+        for (int k = 0; k < KI_MAX; k++) {
+            const int i = min(g * KI + (k < KI ? k : 0), B - 1);
+            const int id = order ? order[i] : i;
+            Ik[k] = (gdbl_p)inst + (size_t)id * P.inst_stride;
+            if (k < KI && g * KI + k < B) nvalid++;
+        }
+        solve_group<T, NLDS, I16, KI>(ps, Ik, nvalid, Wg, warm);
         __syncthreads();
         if (threadIdx.x == 0) g_S.next = (int)gridDim.x + atomicAdd(queue, 1);
         __syncthreads();
-        i = g_S.next;
+        g = g_S.next;
     }
 }
 // Longest-processing-time-first order for k_solve's queue: instances keyed by the number of LDL solves of their
@@ -1650,7 +1935,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
     }
     for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
     __syncthreads();
-    stage_factor<T, 0, false>(ps, I, (gdbl_p)work, -1);
+    stage_factor<T, 0, false, 1>(ps, (gdbl_p)work);
 }
 
 // Debug: the solver's own residual/scaling stage (updateScalings + updateKKTScalings, ref :1160-1162) on instance `i`
@@ -1671,38 +1956,41 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
     for (int j = threadIdx.x; j < P.n; j += T) I[P.i_x + j] = 0.;
     for (int j = threadIdx.x; j < P.p; j += T) I[P.i_y + j] = 0.;
     __syncthreads();
-    const int st = stage_resid<T, 0, false>(ps, I, (gdbl_p)work, 0);
+    const int st = stage_resid<T, 0, false, 1>(ps, I, (gdbl_p)work, 0, 0);
     if (threadIdx.x == 0) ok[0] = (st == ST_FACTOR) ? 1 : 0;
 }
 
 // ---- launchers (called from api.cpp) ----
-template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, F &&f) {
+template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        if (idx16) {
-            if (nlds >= 2) return f((const void *)k_solve<T, 2, true>);
-            if (nlds == 1) return f((const void *)k_solve<T, 1, true>);
-            return f((const void *)k_solve<T, 0, true>);
+        if constexpr (T >= 256) { // lock-step pairs: one LDS vector per instance (NLDS = 1), 256 or 512 threads
+            if (ki == 2) return idx16 ? f((const void *)k_solve<T, 1, true, 2>) : f((const void *)k_solve<T, 1, false, 2>);
         }
-        if (nlds >= 2) return f((const void *)k_solve<T, 2, false>);
-        if (nlds == 1) return f((const void *)k_solve<T, 1, false>);
-        return f((const void *)k_solve<T, 0, false>);
+        if (idx16) {
+            if (nlds >= 2) return f((const void *)k_solve<T, 2, true, 1>);
+            if (nlds == 1) return f((const void *)k_solve<T, 1, true, 1>);
+            return f((const void *)k_solve<T, 0, true, 1>);
+        }
+        if (nlds >= 2) return f((const void *)k_solve<T, 2, false, 1>);
+        if (nlds == 1) return f((const void *)k_solve<T, 1, false, 1>);
+        return f((const void *)k_solve<T, 0, false, 1>);
     };
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
 }
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        int idx16, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
+                        int idx16, int ki, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // instance queue of this launch
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // group queue of this launch
     if (e != hipSuccess) return e;
-    if (B <= grid) order = nullptr; // everything starts at once: identity (slot i = instance i, eicos_debug_trace)
+    if (B <= grid * ki) order = nullptr; // everything starts at once: identity (group g = instances g ki .., eicos_debug_trace)
     else {
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
+    return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
         void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order, (void *)&warm, (void *)&dyn_delta,
                         (void *)&dyn_eps};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
@@ -1733,14 +2021,14 @@ hipError_t launch_debug_scalings(int ps, double *inst, double *work, int i, int 
     }
     return hipGetLastError();
 }
-hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu) {
-    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
+hipError_t solve_occupancy(int threads, int nlds, int idx16, int ki, size_t dyn_lds, int *blocks_per_cu) {
+    return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, threads, dyn_lds);
     });
 }
-hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds) {
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, int ki, size_t dyn_lds) {
     if (dyn_lds == 0) return hipSuccess;
-    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
+    return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
     });
 }

@@ -59,9 +59,10 @@ typedef struct eicos_dims {
     int n, m, p, l, ncones, dim_K, nnzA, nnzG, nnzK, nnzL, nlevels, order_mode, batch, device;
     long long factor_pairs;      /* multiply-subtract pairs of one numeric factorisation */
     size_t inst_bytes, work_bytes, pattern_bytes;
-    int threads_per_block, resident_blocks;
+    int threads_per_block;
+    int resident_blocks; /* instances resident on the GPU at a time = resident workgroups x instances_per_block */
     int lds_bytes; /* dynamic LDS per workgroup (solve vector staged in LDS), 0 if in HBM */
-    int pad_;
+    int instances_per_block; /* instances a workgroup solves in lock-step (1 or 2) */
 } eicos_dims;
 
 /* ---- construction: replaces Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)

@@ -1,4 +1,3 @@
-# round 2 GPU pass: full -m gpu suite (no -x: list every failure)
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/r2_pytest1.log
 cat gpurun_out/r2_pytest1.log
