@@ -147,7 +147,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     h->batch = batch; h->device = device; h->npairs = S.npairs;
     if (S.npairs >= (int64_t)1 << 31) { delete h; return fail(EICOS_E_UNSUPPORTED, "factor program exceeds 2^31 pairs"); }
     DevPat &D = h->dp;
-    const bool tile = S.tile != 0;
+    const bool tile = S.tile != 0;  // some part of L lives in 16 x 16 tiles: all of it (S.tile == 1) or the top block (hybrid, == 2)
+    const bool tile1 = S.tile == 1; // pure tile mode: no scalar programs at all
     const TilePlan &TP = h->tiles;
     // NV = length of the KKT-space vectors on the device: dim_K in elimination order, or (tile mode) the blocks padded to 16
     const int NV = tile ? TP.N16 : S.N;
@@ -257,19 +258,20 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     // (tile mode: the sweeps and the factorisation run over the tile plan instead; the scalar plans stay empty)
     TriPlan planF, planB;
-    if (!tile) { planF = build_tri_plan(S, h->threads, true); planB = build_tri_plan(S, h->threads, false); }
+    if (!tile1) { planF = build_tri_plan(S, h->threads, true); planB = build_tri_plan(S, h->threads, false); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
-    D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nUF = planF.slots; D.nUB = planB.slots;
+    D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     h->posB = planB.pos;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
     FactorPlan planX;
-    if (!tile) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
+    if (!tile1) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
     else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); }
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
     // KKT entries in target order: the factor's only per-target value stream; tile mode: the dense tile image
-    D.w_Kt = Wl.add((tile ? (size_t)(TP.nb + TP.nt) * 256 : planX.target.size()) + 8);
-    D.tile = tile ? 1 : 0; D.nb = TP.nb; D.nt = TP.nt; D.nblev = TP.nblev;
+    D.w_Kt = Wl.add((tile1 ? (size_t)(TP.nb + TP.nt) * 256 : planX.target.size()) + 8);
+    D.w_Kimg = tile1 ? D.w_Kt : (tile ? Wl.add((size_t)(TP.nb + TP.nt) * 256 + 8) : 0); // hybrid: the top block's image beside the scalar stream
+    D.tile = S.tile; D.nb = TP.nb; D.nt = TP.nt; D.nblev = TP.nblev; D.tl_base = TP.n0;
     if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), inverse diagonal tiles both ways (DC, DR)
         D.w_LC = Wl.add((size_t)TP.nt * 256 + 8); D.w_LR = Wl.add((size_t)TP.nt * 256 + 8);
         D.w_DC = Wl.add((size_t)TP.nb * 256); D.w_DR = Wl.add((size_t)TP.nb * 256);
@@ -362,6 +364,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const int tgt = planX.target[t];
         if (tgt < S.N) { fac_src[t] = srcoff(S.Dkind[tgt], S.Dsrc[tgt]); fac_dst[t] = -tgt - 1 - (pivot_positive(tgt) ? DIAG_POS : 0); fac_dstF[t] = 0; }
         else { const int e = tgt - S.N; fac_src[t] = srcoff(S.Lkind[e], S.Lsrc[e]); fac_dst[t] = planB.pos[e]; fac_dstF[t] = planF.pos[e]; fac_col[t] = col_of[e]; }
+        // hybrid: the targets of the top block (their pairs stop at column n0) are the tile factorisation's input image
+        if (S.tile == 2 && tgt < S.N && tgt >= S.n0) { fac_dst[t] = IMG_BASE + TP.D_img[tgt]; fac_dstF[t] = -1; }
+        if (S.tile == 2 && tgt >= S.N && col_of[tgt - S.N] >= S.n0) { fac_dst[t] = IMG_BASE + TP.Le_img[tgt - S.N]; fac_dstF[t] = -1; }
     }
     std::vector<int> v2t(std::max(S.nV, 1), D.fac_nt); // entries that are no target (none by construction) -> spare slot
     for (size_t t = 0; t < planX.target.size(); t++)
@@ -369,15 +374,17 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // ---- tile mode: where every KKT entry lands in the dense tile image, pivot signs, the tile program ----
     std::vector<int> img_dst, img_src, psign(tile ? NV : 0, 1);
     if (tile) {
-        for (int j = 0; j < S.N; j++) {
-            img_dst.push_back(TP.D_img[j]); img_src.push_back(srcoff(S.Dkind[j], S.Dsrc[j]));
-            if (S.Dkind[j] == SRC_V) v2t[S.Dsrc[j]] = TP.D_img[j];
-            psign[TP.slot[j]] = pivot_positive(j) ? 1 : -1;
-        }
-        for (int e = 0; e < S.nnzL; e++) {
-            if (S.Lkind[e] == SRC_ZERO) continue; // fill: stays 0 in the image
-            img_dst.push_back(TP.Le_img[e]); img_src.push_back(srcoff(S.Lkind[e], S.Lsrc[e]));
-            if (S.Lkind[e] == SRC_V) v2t[S.Lsrc[e]] = TP.Le_img[e];
+        for (int j = 0; j < S.N; j++) psign[TP.slot[j]] = pivot_positive(j) ? 1 : -1;
+        if (tile1) { // the image is filled straight from the instance slab (hybrid: by the scalar factor program)
+            for (int j = 0; j < S.N; j++) {
+                img_dst.push_back(TP.D_img[j]); img_src.push_back(srcoff(S.Dkind[j], S.Dsrc[j]));
+                if (S.Dkind[j] == SRC_V) v2t[S.Dsrc[j]] = TP.D_img[j];
+            }
+            for (int e = 0; e < S.nnzL; e++) {
+                if (S.Lkind[e] == SRC_ZERO) continue; // fill: stays 0 in the image
+                img_dst.push_back(TP.Le_img[e]); img_src.push_back(srcoff(S.Lkind[e], S.Lsrc[e]));
+                if (S.Lkind[e] == SRC_V) v2t[S.Lsrc[e]] = TP.Le_img[e];
+            }
         }
         for (int d : TP.pad_img) { img_dst.push_back(d); img_src.push_back(D.i_cst + 3); } // padding nodes: identity rows
     }
@@ -411,7 +418,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // 160 KiB per CU minus the static block (reductions + scalar state)
     D.Npad = tile ? NV + 16 : (NV + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding (tile mode: a whole zero block)
     {
-        D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
+        D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo + D.nfs_ext; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
         const size_t lds_static = 4096; // struct Sh + the per-instance states of kernels.hip (reductions + scalar state), rounded up
@@ -440,7 +447,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // instances at once -- slice decoding, index loads, barriers and the dependent chain of the sparse sweeps are shared,
         // values / gathers are 16-byte accesses over interleaved arrays.  Needs both sweep vectors in LDS.
         int ki = h->ki; // wanted (decided with the workgroup size, above); needs both vectors + the tables in LDS
-        if (ki != 2 || tile || fit < 2 || h->threads < 256 || batch < 2) ki = 1;
+        if (ki != 2 || tile || fit < 2 || h->threads < 256 || batch < 2) ki = 1; // (tile / hybrid factor paths are single-instance)
         h->ki = ki;
         // the single-instance kernel on the same workspace (warm start; debug hooks): one vector in LDS
         h->nlds1 = h->nlds; h->dyn_lds1 = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : scratch;
@@ -761,7 +768,13 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
             }
             std::vector<int> colj(S.nnzL);
             for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colj[e] = j;
+            std::vector<double> ub;
+            if (S.tile == 2) { // hybrid: the columns below the top block are in the scalar backward slots
+                ub.resize((size_t)P.nUB + 1);
+                HIP_TRY(hipMemcpy(ub.data(), h->d_work + P.w_UB, (size_t)P.nUB * sizeof(double), hipMemcpyDeviceToHost));
+            }
             for (int e = 0; e < S.nnzL; e++) {
+                if (S.tile == 2 && colj[e] < S.n0) { Uout[e] = ub[h->posB[e]]; continue; }
                 const int rr = TP.Le_rc[e] >> 4, cc = TP.Le_rc[e] & 15;
                 const double lv = TP.Le_tile[e] >= 0 ? LR[(size_t)TP.Le_tile[e] * 256 + tile_res(rr, cc)] : Ld[(size_t)(-1 - TP.Le_tile[e]) * 256 + rr * 16 + cc];
                 Uout[e] = lv * Dv[TP.slot[colj[e]]];
@@ -856,7 +869,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
         P.n = n; P.m = m; P.p = p; P.nc = ncones; P.q.assign(q, q + ncones);
         if (Gjc && Gir) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else { P.Gjc.assign(n + 1, 0); P.m = 0; P.nc = 0; P.q.clear(); }
         if (Ajc && Air) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else { P.Ajc.assign(n + 1, 0); P.p = 0; }
-        Symbolic S = analyze(P, order_mode);
+        Symbolic S = analyze(P, order_mode, 0); // the scalar programs (the tile and hybrid paths have their own checks)
         const int N = S.N;
         if (stats) { stats[0] = N; stats[1] = S.nnzK; stats[2] = S.nnzL; stats[3] = S.nlev; stats[4] = (int)std::min<int64_t>(S.npairs, 2147483647); stats[5] = S.order_mode; stats[6] = S.max_row_len; stats[7] = S.max_col_len; }
         // permutation sanity

@@ -39,7 +39,8 @@ constexpr int DEVINFO_DOUBLES = 32;
 // over the same rows: `more` = another sub-slice of these rows follows, `cont` = this one continues the previous.
 struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; }; // host form (plan building, host emulation)
 constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
-constexpr int DIAG_POS = 1 << 30; // factor program, diagonal targets: dst = -(j + 1) - (pivot sign is + ? DIAG_POS : 0)
+constexpr int DIAG_POS = 1 << 30;
+constexpr int IMG_BASE = 1 << 28; // factor program, hybrid: dst >= IMG_BASE = entry (dst - IMG_BASE) of the top block's tile image // factor program, diagonal targets: dst = -(j + 1) - (pivot sign is + ? DIAG_POS : 0)
 
 // Device form of a slice: 16 bytes = one ds_read_b128 / s_load_dwordx4.  off16 = index of the slice's first lane
 // in the plan's packed 16-bit gather-index array (one 8-byte entry = ELL_KMAX indices per lane), see api.cpp.
@@ -110,7 +111,10 @@ struct DevPat {
     gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;
     gint_p fac_p16; int fac_d16; // idx16: per lane and slice the four (pa, pb) pairs as eight 16-bit slot numbers (16 bytes)
     // ---- tile mode (dense fronts, tiles.hpp): L = block-sparse matrix of dense 16 x 16 tiles; D.N is then 16 * nb ----
-    int tile, nb, nt, nblev;       // 1 = tile path; blocks, off-diagonal tiles, block levels
+    int tile, nb, nt, nblev;       // 1 = tile path, 2 = hybrid (top block of the tree on tiles); blocks, off-diagonal tiles, block levels
+    int tl_base;                   // slot of block 0 in the KKT-space vectors (hybrid: the scalar part comes first)
+    int w_Kimg;                    // workspace: dense tile image of K the tile factorisation starts from (= w_Kt in pure tile mode)
+    int nfs_ext;                   // hybrid: slices of the forward plan's extra level (rows of the top block, columns below it)
     int tl_nimg, tl_scratch;       // entries of the K image scatter; offset (doubles) of the per-wave LDS scratch
     gint_p tl_blev, tl_tgt_lev, tl_tgt, tl_tp, tl_pa, tl_pb, tl_pk, tl_fin_lev, tl_fin; // levels, factor targets / pairs, finalise lists
     gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view

@@ -681,6 +681,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     const int tid = threadIdx.x;
     gdbl_p UF = Wg + (size_t)KI * P.w_UF, U = Wg + (size_t)KI * P.w_UB, D = Wg + (size_t)KI * P.w_D, invD = Wg + (size_t)KI * P.w_invD; // pa/pb index UB slots
     gcdbl_p Kt = Wg + (size_t)KI * P.w_Kt; // KKT entries in target order (solve prologue + updateKKTScalings)
+    gdbl_p Kimg = Wg + P.w_Kimg;           // hybrid (single-instance): targets of the top block go to its tile image
     __syncthreads();
     unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
     const int ns = P.fac_ns;
@@ -771,7 +772,9 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                 double val[KI];
 #pragma unroll
                 for (int k = 0; k < KI; k++) val[k] = c.kv[k] - acc[k];
-                if (c.dst < 0) { // diagonal target: -(j+1), plus DIAG_POS when the quasi-definite sign of pivot j is +
+                if (c.dst >= IMG_BASE) { // hybrid: K - (updates from the columns below the top block) -> input of the tile factorisation
+                    if constexpr (KI == 1) Kimg[c.dst - IMG_BASE] = val[0];
+                } else if (c.dst < 0) { // diagonal target: -(j+1), plus DIAG_POS when the quasi-definite sign of pivot j is +
                     const int e = -c.dst - 1, j = e & (DIAG_POS - 1);
                     double iv[KI];
 #pragma unroll
@@ -793,10 +796,10 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                 for_t_pre<T, 4>(lvl_t1 - lvl_t0, [&](int k) {
                     const int t = lvl_t0 + k, dst = P.fac_dst[t];
                     PB r; r.dst = dst; r.dstF = P.fac_dstF[t];
-                    ldK<KI>(U, max(dst, 0), r.u); ldK<KI>(invD, P.fac_col[t], r.d);
+                    ldK<KI>(U, (dst >= 0 && dst < IMG_BASE) ? dst : 0, r.u); ldK<KI>(invD, P.fac_col[t], r.d);
                     return r;
                 }, [&](int k, const PB &r) {
-                    if (r.dst >= 0) {
+                    if (r.dst >= 0 && r.dstF >= 0) {
                         double o[KI];
 #pragma unroll
                         for (int kk = 0; kk < KI; kk++) o[kk] = r.u[kk] * r.d[kk];
@@ -844,8 +847,9 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
     STAGE_PROLOGUE
     iter = uni(iter);
     constexpr int NW = T / 64;
-    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, D = W + P.w_D, invD = W + P.w_invD;
-    gcdbl_p Kt = W + P.w_Kt;
+    // (D, invD of the blocks start at slot tl_base: hybrid keeps the scalar part of the vectors in front)
+    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, D = W + P.w_D + P.tl_base, invD = W + P.w_invD + P.tl_base;
+    gcdbl_p Kt = W + P.w_Kimg;
     double *scr = g_dyn + P.tl_scratch + uni(wave) * TILE_SCR; // wave-private 16 x 17 tile in LDS
     const int nbk = P.nb, kq = lane >> 4, lc = lane & 15;
     cint_p c_tgt = as_const(P.tl_tgt), c_tp = as_const(P.tl_tp), c_pa = as_const(P.tl_pa), c_pb = as_const(P.tl_pb), c_pk = as_const(P.tl_pk);
@@ -929,7 +933,7 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
         }
         __syncthreads();
     }
-    if (tid == 0) wi.n_factor++;
+    if (tid == 0 && P.tile == 1) wi.n_factor++; // (hybrid: counted by the scalar part)
     __syncthreads();
     TICK_END(TK_FACTOR);
     if (g_S.fl[FL_FATAL]) return ST_DONE; // ref :901-905,1166-1170 (no backscale)
@@ -942,9 +946,10 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
 // lane groups are folded by two cross-lane adds: 2 KB contiguous per wavefront and tile, no index arrays at all.
 // The loads of TILE_PF tiles are in flight per wavefront; blocks whose diagonal tile is the identity skip its product.
 template <int T, bool LDSBAR, class WS>
-__device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws) {
+__device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
+    auto ws = ws0 + P.tl_base; // the blocks start at slot tl_base (hybrid: behind the scalar part of the vector)
     constexpr int NW = T / 64;
-    gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, invD = W + P.w_invD;
+    gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, invD = W + P.w_invD + P.tl_base;
     const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, lc = lane & 15;
     auto bar = [&] { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); };
     auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
@@ -1305,11 +1310,19 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         __syncthreads();
         // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
         const bool wave0 = uni(tid >> 6) == 0;
-        if (P.tile) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
+        if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
             if constexpr (KI == 1) { if constexpr (NLDS >= 1) tile_solve<T, true>(P, Wg, SV); else tile_solve<T, false>(P, Wg, SV); }
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
             tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
-            if (wave0) {
+            if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down
+                if constexpr (KI == 1) {
+                    if (wave0) tri_sweep<T, true, true, true, I16, KI>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    __syncthreads();
+                    tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tile_solve<T, true>(P, Wg, SV);
+                    if (wave0) tri_sweep<T, false, true, true, I16, KI>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                }
+            } else if (wave0) {
                 tri_sweep<T, true, true, true, I16, KI>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                 tri_sweep<T, false, true, true, I16, KI>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
@@ -1317,7 +1330,15 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
             tri_sweep<T, false, true, false, I16, KI>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
         } else {
             tri_sweep<T, true, false, false, I16, KI>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-            if (wave0) {
+            if (P.tile == 2) {
+                if constexpr (KI == 1) {
+                    if (wave0) tri_sweep<T, true, false, true, I16, KI>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    __syncthreads();
+                    tri_sweep<T, true, false, false, I16, KI>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tile_solve<T, false>(P, Wg, SV);
+                    if (wave0) tri_sweep<T, false, false, true, I16, KI>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                }
+            } else if (wave0) {
                 tri_sweep<T, true, false, true, I16, KI>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                 tri_sweep<T, false, false, true, I16, KI>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
@@ -1643,12 +1664,15 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p Wg, int ki, 
         __syncthreads();
         { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
             gdbl_p Kt = Wg + (size_t)KI * P.w_Kt + ki; // KI-interleaved: element t of this instance at Kt[t * KI]
-            if (P.tile) { // dense tile image of K: zero, then scatter the structural entries (+ 1 on the padding diagonals)
+            if (P.tile) { // dense tile image of K: zero, then scatter the structural entries (+ 1 on the padding diagonals);
+                          // hybrid: only the padding -- the scalar factor program writes the structural entries every pass
+                gdbl_p Kimg = Wg + P.w_Kimg;
                 const int nimg = (P.nb + P.nt) * 256;
-                FOR_T(t, nimg) Kt[t] = 0.;
+                FOR_T(t, nimg) Kimg[t] = 0.;
                 __syncthreads();
-                for_t_pre<T, 8>(P.tl_nimg, [&](int e) { return IV1{P.tl_img_dst[e], I[P.tl_img_src[e]]}; }, [&](int e, const IV1 &r) { Kt[r.i] = r.a; });
-            } else
+                for_t_pre<T, 8>(P.tl_nimg, [&](int e) { return IV1{P.tl_img_dst[e], I[P.tl_img_src[e]]}; }, [&](int e, const IV1 &r) { Kimg[r.i] = r.a; });
+            }
+            if (P.tile != 1)
             for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[(size_t)t * KI] = r.a; });
         }
         {
@@ -1734,8 +1758,8 @@ __device__ __forceinline__ void solve_group(int ps, gdbl_p (&Ik)[KI_MAX], int nv
     __syncthreads();
     while (amask) {
         if (stage == ST_FACTOR) {
+            if (P.tile != 1) stage_factor<T, NLDS, I16, KI>(ps, Wg); // scalar program (hybrid: everything below the top block + its image)
             if (P.tile) { if constexpr (KI == 1) stage_factor_tiles<T, NLDS>(ps, Ik[0], Wg, iter); }
-            else stage_factor<T, NLDS, I16, KI>(ps, Wg);
             for (int k = 0; k < KI; k++) { // zero pivot -> fatal, no backscale (ref :901-905,1166-1170)
                 if (!((amask >> k) & 1) || !inst_state<KI>(k).fl[FL_FATAL]) continue;
                 state_in<KI>(k); instance_end(P, Ik[k], Wg + (size_t)k * P.w_split); state_out<KI>(k);
@@ -1777,7 +1801,7 @@ __global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
             gint_p si = reinterpret_cast<gint_p>(src);
             for (int q = threadIdx.x; q < cnt * 4; q += T) dst[at * 4 + q] = si[q];
         };
-        stage(P.fsl, P.nfs + P.nfs_solo, P.lm_f); stage(P.bsl, P.nbs + P.nbs_solo, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
+        stage(P.fsl, P.nfs + P.nfs_solo + P.nfs_ext, P.lm_f); stage(P.bsl, P.nbs + P.nbs_solo, P.lm_b); stage(P.cag_sl, P.cag_ns, P.lm_cag);
         stage(P.rA_sl, P.rA_ns, P.lm_rA); stage(P.rG_sl, P.rG_ns, P.lm_rG);
         if (P.lm_fac >= 0) stage(P.fac_sl, P.fac_ns, P.lm_fac);
         __syncthreads();
@@ -1926,16 +1950,18 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
     if (threadIdx.x == 0) { g_S.fl[FL_FATAL] = 0; g_S.wi.n_factor = 0; g_S.dyn_delta = 0.; g_S.dyn_eps = 0.; for (int k = 0; k < 12; k++) g_S.tick[k] = 0; }
     gdbl_p I = (gdbl_p)inst + (size_t)i * P.inst_stride, Kt = (gdbl_p)work + P.w_Kt;
     if (P.tile) { // launched with the solve kernel's dynamic LDS size: the per-wave scratch sits at the same offset
-        for (int t = threadIdx.x; t < (P.nb + P.nt) * 256; t += T) Kt[t] = 0.;
+        gdbl_p Kimg = (gdbl_p)work + P.w_Kimg;
+        for (int t = threadIdx.x; t < (P.nb + P.nt) * 256; t += T) Kimg[t] = 0.;
         __syncthreads();
-        for (int e = threadIdx.x; e < P.tl_nimg; e += T) Kt[P.tl_img_dst[e]] = I[P.tl_img_src[e]];
+        for (int e = threadIdx.x; e < P.tl_nimg; e += T) Kimg[P.tl_img_dst[e]] = I[P.tl_img_src[e]];
         __syncthreads();
-        stage_factor_tiles<T, 0>(ps, I, (gdbl_p)work, -1);
-        return;
     }
-    for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
-    __syncthreads();
-    stage_factor<T, 0, false, 1>(ps, (gdbl_p)work);
+    if (P.tile != 1) {
+        for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
+        __syncthreads();
+        stage_factor<T, 0, false, 1>(ps, (gdbl_p)work);
+    }
+    if (P.tile) stage_factor_tiles<T, 0>(ps, I, (gdbl_p)work, -1);
 }
 
 // Debug: the solver's own residual/scaling stage (updateScalings + updateKKTScalings, ref :1160-1162) on instance `i`

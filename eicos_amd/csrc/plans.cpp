@@ -26,7 +26,14 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     pl.pos.assign(S.nnzL, 0);
     const std::vector<int> &ptr = forward ? S.Rp : S.Lp;
     const std::vector<int> &ind = forward ? S.Rj : S.Li;
-    auto len = [&](int r) { return ptr[r + 1] - ptr[r]; };
+    // hybrid: the sweeps cover the levels below the cut; a row of the top block keeps only its entries in columns < n0
+    // (a prefix: the columns of a row ascend), a column below the cut keeps all its rows
+    const bool hyb = S.tile == 2;
+    const int nlev = hyb ? S.lev_cut : S.nlev;
+    auto len = [&](int r) {
+        if (hyb && forward && r >= S.n0) return (int)(std::lower_bound(ind.begin() + ptr[r], ind.begin() + ptr[r + 1], S.n0) - (ind.begin() + ptr[r]));
+        return ptr[r + 1] - ptr[r];
+    };
     auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
     // shape of the next slice of a level at workgroup width Tw: rows [r, r+cnt), g lanes per row, K entries per lane
     auto shape = [&](int r, int end, int Tw, int &g, int &cnt, int &K) {
@@ -45,9 +52,9 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
         while (r < S.lev_ptr[v + 1]) { int g, cnt, K; shape(r, S.lev_ptr[v + 1], Tw, g, cnt, K); r += cnt; n++; }
         return n;
     };
-    auto emit_level = [&](int v, int Tw) {
+    auto emit_level = [&](int v, int Tw) { // v = nlev (hybrid, forward): the rows of the top block
         int r = S.lev_ptr[v];
-        const int end = S.lev_ptr[v + 1];
+        const int end = (hyb && v == nlev) ? S.N : S.lev_ptr[v + 1];
         bool first = true;
         while (r < end) {
             int g, cnt, K;
@@ -58,7 +65,7 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
             push_subslices(pl.sl, SliceMeta{r, cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
             pl.idx.resize((size_t)pl.slots + (size_t)K * lanes, S.N); // padding gathers the zero slot N
             for (int i = r; i < r + cnt; i++)
-                for (int e = ptr[i]; e < ptr[i + 1]; e++) {
+                for (int e = ptr[i]; e < ptr[i] + len(i); e++) {
                     const int j = e - ptr[i], q = j % g, kk = j / g;
                     const int slot = pl.slots + kk * lanes + (i - r) * g + q;
                     pl.idx[slot] = ind[e];
@@ -74,15 +81,16 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     };
     // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
     const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
-    int vs = S.nlev;
+    int vs = nlev;
     if (allow_solo) while (vs > v_first && slices_of(vs - 1, 64) <= 2) vs--;
     if (forward) {
         for (int v = v_first; v < vs; v++) emit_level(v, T);
         pad(); pl.n_wide = (int)pl.sl.size();
-        for (int v = std::max(vs, v_first); v < S.nlev; v++) emit_level(v, 64);
+        for (int v = std::max(vs, v_first); v < nlev; v++) emit_level(v, 64);
         pad(); pl.n_solo = (int)pl.sl.size() - pl.n_wide;
+        if (hyb) { emit_level(nlev, T); pad(); pl.n_ext = (int)pl.sl.size() - pl.n_wide - pl.n_solo; }
     } else {
-        for (int v = S.nlev - 1; v >= std::max(vs, v_first); v--) emit_level(v, 64);
+        for (int v = nlev - 1; v >= std::max(vs, v_first); v--) emit_level(v, 64);
         pad(); pl.n_solo = (int)pl.sl.size();
         for (int v = vs - 1; v >= v_first; v--) emit_level(v, T);
         pad(); pl.n_wide = (int)pl.sl.size() - pl.n_solo;
@@ -97,7 +105,7 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
     FactorPlan pl;
     auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
     auto gof = [&](int64_t m) { return std::max(1, std::min(64, pow2ceil((int)((m + ELL_KMAX - 1) / ELL_KMAX)))); };
-    for (int v = 0; v < S.nlev; v++) {
+    for (int v = 0; v + 1 < (int)S.ftask_ptr.size(); v++) { // (hybrid: the levels below the cut + one level for the top block)
         int r = S.ftask_ptr[v];
         const int end = S.ftask_ptr[v + 1];
         bool first = true;

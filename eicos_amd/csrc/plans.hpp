@@ -13,6 +13,9 @@ struct TriPlan {
     // lanes and run by a single wavefront without workgroup barriers: forward sl = [wide | solo], backward
     // sl = [solo | wide]; each part padded to a multiple of TRI_DEPTH slices.
     int n_wide = 0, n_solo = 0;
+    // hybrid (Symbolic::tile == 2), forward plan only: one more level after the solo part, laid out for the whole workgroup --
+    // the rows of the top block with their entries in columns < n0 (the block's own columns belong to the tile sweep)
+    int n_ext = 0;
     std::vector<int> idx;      // per slot: index of the gathered solve-vector entry (padding -> N)
     std::vector<int> pos;      // per CSC entry of L: its slot
     int slots = 0;

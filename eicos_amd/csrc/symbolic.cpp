@@ -2,6 +2,7 @@
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -99,7 +100,7 @@ void etree_rows(int N, const std::vector<ivec> &up, ivec &parent, std::vector<iv
 
 } // namespace
 
-static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program);
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program, bool hybrid = false);
 
 // order_mode < 0: try several slacks and keep the cheapest under a simple cost model:
 // every level costs the GPU one workgroup barrier + a dependent memory round trip, which is
@@ -117,8 +118,8 @@ Symbolic analyze(const ProblemPattern &P, int order_mode, int tile) {
             const double cost = S.nnzL + LEVEL_COST * S.nlev;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_mode = mode; best_nnzL = S.nnzL; }
         }
-        if (tile < 0) tile = (N > 0 && best_nnzL >= 16LL * N) ? 1 : 0; // ~16+ entries per column of L: dense fronts
-        if (tile == 0) return analyze_mode(P, best_mode, false, true);
+        if (tile < 0) tile = (N > 0 && best_nnzL >= 16LL * N) ? 1 : 2; // ~16+ entries per column of L: dense fronts; else hybrid if it pays
+        if (tile == 0 || tile == 2) return analyze_mode(P, best_mode, false, true, tile == 2);
     }
     // tile path: the cost is the number of 16 x 16 tiles (bytes streamed per solve) plus the block levels (barriers)
     Symbolic best;
@@ -142,7 +143,7 @@ Symbolic analyze(const ProblemPattern &P, int order_mode, int tile) {
     return best;
 }
 
-static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program) {
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program, bool hybrid) {
     Symbolic S;
     S.order_mode = order_mode;
     S.tile = tile ? 1 : 0;
@@ -327,6 +328,20 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
         else { int pos = find_csc(std::max(a, b), std::min(a, b)); S.Lkind[pos] = S.K_kind[e]; S.Lsrc[pos] = S.K_src[e]; }
     }
 
+    // ---- hybrid: does the scalar schedule end in a chain worth handing to the tile path? ----
+    if (!tile && program && hybrid && N > 0) {
+        int cut = S.nlev;
+        const int wmax = getenv("EICOS_HYB_W") ? atoi(getenv("EICOS_HYB_W")) : 4; // (tuning knob)
+        while (cut > 0 && S.lev_ptr[cut] - S.lev_ptr[cut - 1] <= wmax) cut--; // maximal tail of levels with <= 4 nodes
+        const int nD = N - S.lev_ptr[cut], nbD = (nD + 15) / 16;
+        // worth it: the tail is long (each of its levels costs the sweeps a dependent step, one block costs about two)
+        if (nD >= 24 && nD <= 1024 && S.nlev - cut >= 12 && 3 * nbD <= S.nlev - cut) {
+            S.tile = 2; S.lev_cut = cut; S.n0 = S.lev_ptr[cut];
+            S.nblk = nbD; S.nblev = nbD;
+            S.blk_ptr.clear(); S.blev_ptr.clear();
+            for (int b = 0; b <= nbD; b++) { S.blk_ptr.push_back(std::min(N, S.n0 + 16 * b)); S.blev_ptr.push_back(b); }
+        }
+    }
     if (tile || !program) { // tile mode has its own (tile-level) program, tiles.cpp; structure-only calls need none
         int64_t np = 0;
         for (int k = 0; k < N; k++) { int64_t c = S.Lp[k + 1] - S.Lp[k]; np += c * (c + 1) / 2; }
@@ -337,7 +352,8 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     const int64_t NT = (int64_t)N + S.nnzL;
     S.tp.assign(NT + 1, 0);
     auto for_each_pair = [&](auto &&fn) {
-        for (int k = 0; k < N; k++) {
+        const int kend = S.tile == 2 ? S.n0 : N; // hybrid: the columns of the top block update it through the tile program
+        for (int k = 0; k < kend; k++) {
             const int b0 = S.Lp[k], b1 = S.Lp[k + 1];
             for (int eb = b0; eb < b1; eb++) {
                 const int rb = S.Li[eb];
@@ -347,7 +363,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
         }
     };
     int64_t np = 0;
-    for (int k = 0; k < N; k++) { int64_t c = S.Lp[k + 1] - S.Lp[k]; np += c * (c + 1) / 2; }
+    for (int k = 0; k < (S.tile == 2 ? S.n0 : N); k++) { int64_t c = S.Lp[k + 1] - S.Lp[k]; np += c * (c + 1) / 2; }
     S.npairs = np;
     if (np > (int64_t)400 * 1000 * 1000)
         throw std::runtime_error("symbolic: scalar factor program too large for a sparse pattern (> 4e8 multiply-subtract pairs)");
@@ -361,10 +377,12 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     S.flops_factor = 3.0 * (double)np + N;
 
     // ---- per-level task lists, longest first ----
-    S.ftask_ptr.assign(S.nlev + 1, 0);
+    // (hybrid: the levels below the cut, then ONE level with every target of the top block)
+    const int nlev_f = S.tile == 2 ? S.lev_cut + 1 : S.nlev;
+    S.ftask_ptr.assign(nlev_f + 1, 0);
     S.ftask.reserve(NT);
-    for (int v = 0; v < S.nlev; v++) {
-        const int j0 = S.lev_ptr[v], j1 = S.lev_ptr[v + 1];
+    for (int v = 0; v < nlev_f; v++) {
+        const int j0 = S.lev_ptr[v], j1 = (S.tile == 2 && v == S.lev_cut) ? N : S.lev_ptr[v + 1];
         const size_t start = S.ftask.size();
         for (int j = j0; j < j1; j++) S.ftask.push_back(j);
         for (int e = S.Lp[j0]; e < S.Lp[j1]; e++) S.ftask.push_back(N + e);

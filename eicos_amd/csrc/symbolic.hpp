@@ -55,7 +55,14 @@ struct Symbolic {
     // ---- tile mode (patterns with dense fronts; tiles.hpp): the elimination order is an etree postorder cut into
     // blocks of <= 16 consecutive nodes aligned with the supernodes, blocks renumbered by block level.  L is then a
     // block-sparse matrix of dense 16 x 16 tiles; the scalar factor program (tp/pa/pb/pk, ftask) is not built.
+    // tile = 2: HYBRID.  The scalar (level-ordered) elimination order is kept; its narrow top -- the levels lev_cut.. of the
+    // schedule, nodes n0..N-1, typically one dense supernode whose scalar schedule is a chain of single-node levels -- is cut
+    // into plain 16-node blocks and handled by the tile path (one block level per block), everything below stays on the
+    // scalar sliced-ELL programs.  The scalar factor program then covers: every target in a column < n0, and, as one extra
+    // level ftask_ptr[lev_cut..lev_cut+1], every target of the top block with its pairs from columns < n0 only (the Schur
+    // complement the tile factorisation starts from).
     int tile = 0;
+    int lev_cut = 0, n0 = 0;
     int nblk = 0, nblev = 0;
     std::vector<int> blk_ptr;           // nblk+1: node range of each block
     std::vector<int> blev_ptr;          // nblev+1: block range of each block level
@@ -64,7 +71,8 @@ struct Symbolic {
 // order_mode: 0 = minimum degree, ties by index (sequential; deep trees)
 //             k>=1 = multiple independent elimination of nodes within k-1 of the minimum degree
 //             <0 = try several k, keep the best under a fill + tree-height cost model (default)
-// tile: 0 = scalar (sliced-ELL) path, 1 = tile path, < 0 = choose: tiles when L is dense (nnz(L) >= 16 dim_K)
+// tile: 0 = scalar (sliced-ELL) path, 1 = tile path, 2 = scalar with the top of the tree on tiles (hybrid) when it pays,
+// < 0 = choose: tiles when L is dense (nnz(L) >= 16 dim_K), otherwise hybrid when the scalar schedule ends in a long chain
 Symbolic analyze(const ProblemPattern &P, int order_mode = -1, int tile = -1);
 
 } // namespace eicos

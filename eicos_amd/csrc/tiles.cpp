@@ -12,17 +12,20 @@ namespace eicos {
 TilePlan build_tile_plan(const Symbolic &S) {
     if (!S.tile) throw std::logic_error("tile plan requested for a scalar-mode analysis");
     TilePlan T;
-    const int N = S.N, nb = S.nblk;
-    T.nb = nb; T.N16 = 16 * nb; T.nblev = S.nblev; T.blev_ptr = S.blev_ptr;
-    std::vector<int> blk(N), off(N);
+    // n0 = first node on tiles: 0 in pure tile mode; hybrid (Symbolic::tile == 2): the top block starts there, the nodes
+    // below keep their scalar slots (slot = elimination position) and only entries with BOTH indices >= n0 live in tiles
+    const int N = S.N, nb = S.nblk, n0 = S.tile == 2 ? S.n0 : 0;
+    T.nb = nb; T.n0 = n0; T.N16 = n0 + 16 * nb; T.nblev = S.nblev; T.blev_ptr = S.blev_ptr;
+    std::vector<int> blk(N, -1), off(N, 0);
     T.slot.resize(N);
+    for (int k = 0; k < n0; k++) T.slot[k] = k;
     for (int b = 0; b < nb; b++) {
         if (S.blk_ptr[b + 1] - S.blk_ptr[b] > 16 || S.blk_ptr[b + 1] <= S.blk_ptr[b]) throw std::logic_error("tile plan: bad block size");
-        for (int k = S.blk_ptr[b]; k < S.blk_ptr[b + 1]; k++) { blk[k] = b; off[k] = k - S.blk_ptr[b]; T.slot[k] = 16 * b + off[k]; }
+        for (int k = S.blk_ptr[b]; k < S.blk_ptr[b + 1]; k++) { blk[k] = b; off[k] = k - S.blk_ptr[b]; T.slot[k] = n0 + 16 * b + off[k]; }
     }
     // ---- tiles from the scalar pattern of L (CSC: column j, rows ascending) ----
     std::vector<std::vector<int>> colrows(nb);
-    for (int j = 0; j < N; j++)
+    for (int j = n0; j < N; j++)
         for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) if (blk[S.Li[e]] != blk[j]) colrows[blk[j]].push_back(blk[S.Li[e]]);
     T.tc_ptr.assign(nb + 1, 0);
     for (int J = 0; J < nb; J++) {
@@ -87,8 +90,8 @@ TilePlan build_tile_plan(const Symbolic &S) {
 
     // ---- where every scalar entry lives ----
     T.ident.assign(nb, 1);
-    T.Le_img.resize(S.nnzL); T.Le_tile.resize(S.nnzL); T.Le_rc.resize(S.nnzL); T.D_img.resize(N);
-    for (int j = 0; j < N; j++) {
+    T.Le_img.assign(S.nnzL, -1); T.Le_tile.assign(S.nnzL, 0); T.Le_rc.assign(S.nnzL, 0); T.D_img.assign(N, -1);
+    for (int j = n0; j < N; j++) {
         T.D_img[j] = blk[j] * 256 + tile_res(off[j], off[j]);
         for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
             const int i = S.Li[e], I = blk[i], J = blk[j];

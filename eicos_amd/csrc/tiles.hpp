@@ -20,7 +20,8 @@ namespace eicos {
 
 struct TilePlan {
     int nb = 0, nt = 0, nblev = 0; // blocks, off-diagonal tiles, block levels
-    int N16 = 0;                   // 16 * nb: length of the KKT-space vectors in padded elimination order
+    int n0 = 0;                    // first node on tiles (hybrid: the nodes below keep their scalar slots); 0 in pure tile mode
+    int N16 = 0;                   // n0 + 16 * nb: length of the KKT-space vectors on the device (blocks padded to 16)
     std::vector<int> slot;         // elimination position -> slot in the padded order
     std::vector<int> blev_ptr;     // nblev+1: block range per level (copy of Symbolic::blev_ptr)
     // off-diagonal tiles, CSC by block column (rows ascending); tile t = (t_row[t], t_col[t])

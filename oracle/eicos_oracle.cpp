@@ -1022,6 +1022,12 @@ double oracle_batch_solve(int n, int m, int p, int ncones, const int *q,
             const int i = next.fetch_add(1);
             if (i >= batch) break;
             ptrs(i, g, a, ci, hi, bi);
+            // Every instance of a batch is its own problem = its own Solver object as far as the reference's sticky state
+            // goes (pinfres / dinfres are never cleared and survive solve() calls on one object; on the GPU
+            // they persist per INSTANCE).  The thread's solver object is reused for speed only, so the flags an earlier,
+            // different instance left behind are dropped -- otherwise one infeasible instance turns every later instance
+            // of that thread into an immediate DINF / PINF exit.
+            S->w.i.has_pinfres = 0; S->w.i.has_dinfres = 0;
             auto ta = std::chrono::steady_clock::now();
             S->update(nnzG ? g : nullptr, nnzA ? a : nullptr, ci, hi, bi);
             auto tb = std::chrono::steady_clock::now();

@@ -157,7 +157,8 @@ def test_dense_front_socp():
                                  {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_IDX16": "0"}, {"EICOS_IDX16": "0", "EICOS_NLDS": "0"},
                                  {"EICOS_TILES": "1"}, {"EICOS_TILES": "1", "EICOS_NLDS": "0"}, {"EICOS_TILES": "1", "EICOS_THREADS": "128", "EICOS_NLDS": "2"},
                                  {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"},
-                                 {"EICOS_KI": "2"}, {"EICOS_KI": "2", "EICOS_THREADS": "256"}, {"EICOS_KI": "2", "EICOS_IDX16": "0"}])
+                                 {"EICOS_KI": "2", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_THREADS": "256", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
+                                 {"EICOS_TILES": "0"}, {"EICOS_TILES": "2", "EICOS_NLDS": "0"}, {"EICOS_TILES": "2", "EICOS_THREADS": "128"}, {"EICOS_TILES": "2", "EICOS_THREADS": "512", "EICOS_IDX16": "0"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
     # or in the workspace slab, 128/256/512 threads, 16-/32-bit gather indices, and the tile (dense-front) factor/solve
@@ -484,7 +485,8 @@ def test_config3_lpnetlib_batch256(name):
         if oc == 0:
             # |pcost| ~ 4e7 on lp_agg: agreement at the solver's own relative-gap tolerance when both sides stop at the same
             # pass; when rounding moves the exit by one pass the objectives differ by that last step's progress
-            tol = 5e-8 if ia["iter"][i] == oi["iter"] else 5e-7
+            # (feasibility tolerances of 1e-8 relative to norms of 1e7 leave the objective itself determined to ~1e-7)
+            tol = 2e-7 if ia["iter"][i] == oi["iter"] else 5e-7
             assert abs(ia["pcost"][i] - oi["pcost"]) <= tol * max(1.0, abs(oi["pcost"])), (name, i, ia["pcost"][i], oi["pcost"])
         o.close()
     g.close()
