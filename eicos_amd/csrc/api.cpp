@@ -39,6 +39,7 @@ struct eicos_batch {
     DevPat dp{};
     int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
     int ki = 1;               // instances per workgroup solved in lock-step (DevPat::w_split)
+    size_t upd_lds = 0;       // > 0: updateData runs the entry-parallel kernel with this much dynamic LDS (values + maxima)
     size_t dyn_lds1 = 0; int nlds1 = 0; // launch shape of the single-instance kernel on the same workspace (warm start)
     int *d_pattern = nullptr;
     int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
@@ -339,6 +340,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     auto put = [&](const int *&field, const std::vector<int> &v) { slots.push_back({&field, pool.add(v)}); };
     put(D.Ajc, P.Ajc); put(D.Air, P.Air); put(D.At_ptr, S.At_ptr); put(D.At_pos, S.At_pos);
     put(D.Gjc, P.Gjc); put(D.Gir, P.Gir); put(D.Gt_ptr, S.Gt_ptr); put(D.Gt_pos, S.Gt_pos);
+    {
+        std::vector<int> Acol(S.nnzA), Gcol(S.nnzG);
+        for (int j = 0; j < S.n; j++) { for (int k = P.Ajc[j]; k < P.Ajc[j + 1]; k++) Acol[k] = j; for (int k = P.Gjc[j]; k < P.Gjc[j + 1]; k++) Gcol[k] = j; }
+        put(D.Acol, Acol); put(D.Gcol, Gcol);
+    }
     put(D.cq, S.q); put(D.cone_off, S.cone_off); put(D.cone_vbase, cone_vbase); put(D.cone_small, cone_small); put(D.cone_big, cone_big);
     D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
     put(D.zdsign, zdsign);
@@ -481,6 +487,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min((batch + h->ki - 1) / h->ki, resident);
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
+    {   // entry-parallel updateData: needs the A / G values and the row / column maxima in LDS and <= 8 vector entries per thread
+        const size_t need = ((size_t)S.nnzA + S.nnzG + S.n + S.p + S.m + 8) * sizeof(double);
+        const bool small_vecs = S.n <= 8 * 512 && S.p <= 8 * 512 && S.m <= 16 * 512;
+        if (need <= 156 * 1024 && small_vecs && env_int("EICOS_UPDATE_LDS", 1)) { h->upd_lds = need; h->upd_grid = std::min(batch, prop.multiProcessorCount); }
+    }
     h->pattern_ints = pool.data.size();
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
     HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -580,7 +591,7 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
     if (!h->in_chunked_update) HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
-    HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->stream));
+    HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->upd_lds, h->stream));
     if (!h->in_chunked_update) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
     return EICOS_OK;
 }

@@ -75,6 +75,7 @@ struct DevPat {
     // A, G in CSC (column) form and row pointers + CSC positions of the transposed form (updateData)
     gint_p Ajc, Air, At_ptr, At_pos;
     gint_p Gjc, Gir, Gt_ptr, Gt_pos;
+    gint_p Acol, Gcol; // column of every CSC entry (entry-parallel updateData)
     // sliced-ELL plans of the matrix-vector products (plans.hpp: EllPlan): stacked columns of [A;G]
     // (cag: x-space results), rows of A (rA), rows of G (rG).  *_src: slot -> offset of the CSC value
     // relative to Av (-1 = padding); cag has two gather-index sets: KKT indices (refinement) and

@@ -1943,6 +1943,110 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
     }
 }
 
+// The same updateData for patterns whose A and G values fit LDS (most: MPC02 needs 76 KB for the values + 48 KB for the
+// row / column maxima): ENTRY-parallel instead of thread-per-column.  The equilibrated working copy of the values and the
+// running maxima stay in LDS across the three sweeps, every pass is unit-stride over the entries, the maxima are integer
+// atomic maxima on the bit patterns of |a| (non-negative doubles order like their bit patterns: exact), and HBM sees
+// each input once plus the outputs.  Same arithmetic in the same order per entry as k_update (rows, then columns;
+// cone rows share the SUM of their row maxima; |a| < 1e-6 -> 1): bit-identical results.
+// LDS: [ Av | Gv | xt (n) | at (p) | gt (m) ] doubles.
+template <int T>
+__global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int first, int count,
+                                                  const double *Gpr, const double *Apr, const double *cin,
+                                                  const double *hin, const double *bin) {
+    const DevPat &P = c_pat[ps];
+    const int n = P.n, p = P.p, m = P.m, l = P.l, nnzA = P.nnzA, nnzG = P.nnzG;
+    double *sA = g_dyn, *sG = sA + nnzA, *xt = sG + nnzG, *at = xt + n, *gt = at + p;
+    unsigned long long *xtb = reinterpret_cast<unsigned long long *>(xt), *atb = reinterpret_cast<unsigned long long *>(at), *gtb = reinterpret_cast<unsigned long long *>(gt);
+    auto sq = [](double a) { return fabs(a) < 1e-6 ? 1. : sqrt(a); };
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        gdbl_p I = (gdbl_p)inst + (size_t)(first + q) * P.inst_stride;
+        gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
+        gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
+        DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
+        const bool was_eq = ginfo->equilibrated != 0;
+        __syncthreads();
+        // un-equilibrate what is kept, overwrite what is given (ref :2053-2074, :389-404) -> LDS copy of the values
+        for_t_pre<T, 4>(nnzA, [&](int k) {
+            if (Apr) return V3{Apr[(size_t)q * nnzA + k], 1., 1.};
+            return was_eq ? V3{Av[k], ae[P.Air[k]], xe[P.Acol[k]]} : V3{Av[k], 1., 1.};
+        }, [&](int k, const V3 &r) { sA[k] = (Apr || !was_eq) ? r.a : r.a * (r.b * r.c); });
+        for_t_pre<T, 4>(nnzG, [&](int k) {
+            if (Gpr) return V3{Gpr[(size_t)q * nnzG + k], 1., 1.};
+            return was_eq ? V3{Gv[k], ge[P.Gir[k]], xe[P.Gcol[k]]} : V3{Gv[k], 1., 1.};
+        }, [&](int k, const V3 &r) { sG[k] = (Gpr || !was_eq) ? r.a : r.a * (r.b * r.c); });
+        FOR_T(j, n) cv[j] = cin ? cin[(size_t)q * n + j] : (was_eq ? cv[j] * xe[j] : cv[j]);
+        FOR_T(r, p) bv[r] = Apr ? bin[(size_t)q * p + r] : (was_eq ? bv[r] * ae[r] : bv[r]);
+        FOR_T(i, m) hv[i] = Gpr ? hin[(size_t)q * m + i] : (was_eq ? hv[i] * ge[i] : hv[i]);
+        __syncthreads();
+        // the accumulated scalings live in registers of the thread that owns the index (fixed FOR_T mapping); they are
+        // written once at the end.  Up to 8 indices per thread and vector: patterns beyond that take the generic kernel.
+        constexpr int OWN = 8;
+        double xacc[OWN], aacc[OWN], gacc[2 * OWN];
+#pragma unroll
+        for (int u = 0; u < OWN; u++) { xacc[u] = 1.; aacc[u] = 1.; gacc[2 * u] = 1.; gacc[2 * u + 1] = 1.; }
+        for (int it = 0; it < EQUIL_ITERS; it++) {
+            FOR_T(j, n) xtb[j] = 0ull;
+            FOR_T(r, p) atb[r] = 0ull;
+            FOR_T(i, m) gtb[i] = 0ull;
+            __syncthreads();
+            // column maxima over A and G, row maxima of A and of G: one pass over the entries
+            FOR_T(k, nnzA) { const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(sA[k])); atomicMax(&xtb[P.Acol[k]], b); atomicMax(&atb[P.Air[k]], b); }
+            FOR_T(k, nnzG) { const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(sG[k])); atomicMax(&xtb[P.Gcol[k]], b); atomicMax(&gtb[P.Gir[k]], b); }
+            __syncthreads();
+            FOR_T(j, n) xt[j] = sq(xt[j]);
+            FOR_T(r, p) at[r] = sq(at[r]);
+            FOR_T(i, l) gt[i] = sq(gt[i]); // cone rows: sqrt after the per-cone sum (ref :338-350)
+            __syncthreads();
+            FOR_T(c, P.nc) { // cone rows share the SUM of their row maxima
+                const int o = P.cone_off[c], d = P.cq[c];
+                double tot = 0.;
+                for (int k = 0; k < d; k++) tot += gt[o + k];
+                tot = sq(tot);
+                for (int k = 0; k < d; k++) gt[o + k] = tot;
+            }
+            __syncthreads();
+            // rows first, then columns -- same division order as the reference (:353-356)
+            FOR_T(k, nnzA) sA[k] = (sA[k] / at[P.Air[k]]) / xt[P.Acol[k]];
+            FOR_T(k, nnzG) sG[k] = (sG[k] / gt[P.Gir[k]]) / xt[P.Gcol[k]];
+#pragma unroll
+            for (int u = 0; u < OWN; u++) { // (compile-time register indices: the accumulators must not go to scratch)
+                const int j = threadIdx.x + u * T;
+                if (j < n) xacc[u] *= xt[j];
+                if (j < p) aacc[u] *= at[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) gacc[u] *= gt[i]; }
+            __syncthreads();
+        }
+        // write back: scalings, scaled c, b, h, the values
+#pragma unroll
+        for (int u = 0; u < OWN; u++) {
+            const int j = threadIdx.x + u * T;
+            if (j < n) { xe[j] = xacc[u]; cv[j] = cv[j] / xacc[u]; }
+            if (j < p) { ae[j] = aacc[u]; bv[j] = bv[j] / aacc[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) { ge[i] = gacc[u]; hv[i] = hv[i] / gacc[u]; } }
+        FOR_T(k, nnzA) Av[k] = sA[k];
+        FOR_T(k, nnzG) Gv[k] = sG[k];
+        // sliced-ELL value copies for the products, straight from LDS; *_src is relative to Av (G values follow at i_Gv - i_Av)
+        const int grel = P.i_Gv - P.i_Av;
+        auto ell_copy = [&](gdbl_p dst, gint_p src, int cnt) {
+            for_t_pre<T, 8>(cnt, [&](int k) { return src[k]; }, [&](int k, int e) { dst[k] = e < 0 ? 0. : (e < grel ? sA[e] : sG[e - grel]); });
+        };
+        ell_copy(cagv, P.cag_src, P.cag_slots + 1);
+        ell_copy(rAv, P.rA_src, P.rA_slots + 1);
+        ell_copy(rGv, P.rG_src, P.rG_slots + 1);
+        if (threadIdx.x == 0) { // static-regularisation constants read by the factor program
+            gdbl_p cst = I + P.i_cst;
+            cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 1.; // [3]: diagonal of the padding nodes (tile mode)
+            ginfo->equilibrated = 1;
+        }
+        __syncthreads();
+    }
+}
+
 // Debug: factorise instance `i` with the KKT scaling block as it stands in memory (runs the solver's own stage).
 template <int T>
 __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, double *inst, double *work, int i) {
@@ -2023,9 +2127,13 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
     });
 }
 hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,
-                         const double *c, const double *h, const double *b, double *scratch, int grid, hipStream_t st) {
+                         const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, hipStream_t st) {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
+    if (lds_bytes > 0) { // values + maxima fit LDS: the entry-parallel kernel, 512 threads, one workgroup per CU at a time
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_update_lds<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr_set = true; }
+        hipLaunchKernelGGL(k_update_lds<512>, dim3(grid), dim3(512), lds_bytes, st, ps, inst, first, count, Gpr, Apr, c, h, b);
+    } else hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
     return hipGetLastError();
 }
 hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int threads, size_t dyn_lds, hipStream_t st) {

@@ -10,6 +10,7 @@ F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-parameter ${FPC:--ffp-contract=off} $*
 /opt/rocm/bin/hipcc $F -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c api.cpp -o $out/api.o
 /opt/rocm/bin/hipcc $F -x c++ -c symbolic.cpp -o $out/symbolic.o
 /opt/rocm/bin/hipcc $F -x c++ -c plans.cpp -o $out/plans.o
+/opt/rocm/bin/hipcc $F -x c++ -c tiles.cpp -o $out/tiles.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build_exp/lib$tag.so $out/kernels.o $out/api.o $out/symbolic.o $out/plans.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build_exp/lib$tag.so $out/kernels.o $out/api.o $out/symbolic.o $out/plans.o $out/tiles.o
 echo built build_exp/lib$tag.so
