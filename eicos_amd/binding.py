@@ -92,8 +92,9 @@ def _lib():
         L.eicos_debug_scalings.argtypes = [vp, C.c_int, dp, dp, dp, ip]
         L.eicos_debug_host_check.restype = C.c_double
         L.eicos_debug_host_check.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
-        L.eicos_debug_host_check_tiles.restype = C.c_double
-        L.eicos_debug_host_check_tiles.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
+        for fn in (L.eicos_debug_host_check_tiles, L.eicos_debug_host_check_hybrid):
+            fn.restype = C.c_double
+            fn.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_uint, C.c_int, ip]
         for f in ("create", "update", "update_device", "solve", "solve_async", "sync", "solution", "duals", "info",
                   "solution_device", "dims", "set_stream", "last_solve_ms", "last_update_ms", "destroy"):
             getattr(L, "eicos_batch_" + f).restype = C.c_int
@@ -271,11 +272,13 @@ class BatchSolver:
             pass
 
 
-def host_check_tiles(pat, seed: int = 1, order_mode: int = -1):
-    """Host-only check of the tile (dense-front) plan (no GPU): returns (relative residual, stats dict)."""
+def host_check_tiles(pat, seed: int = 1, order_mode: int = -1, hybrid: bool = False):
+    """Host-only check of the tile (dense-front) plan, or of the hybrid plan (scalar programs + tiles on the top block
+    of the tree; residual -10 = the pattern does not qualify) -- no GPU: returns (relative residual, stats dict)."""
     q, Gjc, Gir, Ajc, Air = [np.ascontiguousarray(a, dtype=np.int32) for a in (pat.q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)]
     st = np.zeros(8, np.int32)
-    r = _lib().eicos_debug_host_check_tiles(pat.n, pat.m, pat.p, pat.ncones, _ip(q) if pat.ncones else None,
+    fn = _lib().eicos_debug_host_check_hybrid if hybrid else _lib().eicos_debug_host_check_tiles
+    r = fn(pat.n, pat.m, pat.p, pat.ncones, _ip(q) if pat.ncones else None,
                                             _ip(Gjc) if pat.m else None, _ip(Gir) if pat.m else None,
                                             _ip(Ajc) if pat.p else None, _ip(Air) if pat.p else None, seed, order_mode, _ip(st))
     keys = ("dim_K", "nnzK", "nnzL", "block_levels", "tile_pairs", "order_mode", "blocks", "tiles")

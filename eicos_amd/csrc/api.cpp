@@ -1014,15 +1014,17 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
 // factorisation and the two tile sweeps executed exactly as the kernels index them (tile image, pair lists, finalise
 // lists, CSR / CSC tile views, column- / row-major tile copies, inverse diagonal tiles), then ||K x - b|| / ||b||.
 // stats[8] = {dim_K, nnzK, nnzL, block levels, tile pairs, order_mode, blocks, off-diagonal tiles}.
-double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
-                                    const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats) {
+static double host_check_tiles_impl(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                    const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats, int mode) {
     try {
         ProblemPattern P;
         P.n = n; P.m = m; P.p = p; P.nc = ncones; P.q.assign(q, q + ncones);
         if (Gjc && Gir) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else { P.Gjc.assign(n + 1, 0); P.m = 0; P.nc = 0; P.q.clear(); }
         if (Ajc && Air) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else { P.Ajc.assign(n + 1, 0); P.p = 0; }
-        Symbolic S = analyze(P, order_mode, 1);
+        Symbolic S = analyze(P, order_mode, mode);
+        if (S.tile != mode) return -10.0; // (hybrid requested, but the schedule has no tail worth handing to the tile path)
         TilePlan TP = build_tile_plan(S);
+        const int n0 = TP.n0;
         if (getenv("EICOS_PLAN_STATS")) (void)build_tile_sweeps(TP, 8, TILE_PF);
         const int N = S.N, nb = TP.nb, nt = TP.nt, N16 = TP.N16;
         if (stats) { stats[0] = N; stats[1] = S.nnzK; stats[2] = S.nnzL; stats[3] = TP.nblev; stats[4] = (int)std::min<int64_t>(TP.npairs, 2147483647); stats[5] = S.order_mode; stats[6] = nb; stats[7] = nt; }
@@ -1034,27 +1036,78 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
             if (r == c) Kv[e] = (r < S.n ? 1.0 : -1.0) * (4.0 + rnd());
             else Kv[e] = 0.2 * (rnd() - 0.5);
         }
-        // the tile image of P K P' (what solve_instance scatters from the instance slab)
-        std::vector<double> img((size_t)(nb + nt) * 256, 0.0);
+        // values of P K P' per entry of L / per diagonal
+        std::vector<double> Lv(S.nnzL, 0.0), Dv(N, 0.0);
         for (int e = 0; e < S.nnzK; e++) {
             const int a = S.iperm[S.K_row[e]], b = S.iperm[S.K_col[e]];
-            if (a == b) img[TP.D_img[a]] = Kv[e];
+            if (a == b) Dv[a] = Kv[e];
             else {
                 const int i = std::max(a, b), j = std::min(a, b);
                 auto it = std::lower_bound(S.Li.begin() + S.Lp[j], S.Li.begin() + S.Lp[j + 1], i);
                 if (it == S.Li.begin() + S.Lp[j + 1] || *it != i) return -4.0;
-                img[TP.Le_img[it - S.Li.begin()]] = Kv[e];
+                Lv[it - S.Li.begin()] = Kv[e];
             }
         }
+        // the tile image: pure tile mode -- P K P' itself (what the solve prologue scatters from the instance slab);
+        // hybrid -- written by the scalar factor program below (K minus the updates from the columns under the top block)
+        std::vector<double> img((size_t)(nb + nt) * 256, 0.0);
         for (int d : TP.pad_img) img[d] = 1.0;
-        std::vector<double> LC((size_t)nt * 256 + 1, 0.0), LR((size_t)nt * 256 + 1, 0.0), DC((size_t)nb * 256, 0.0), DR((size_t)nb * 256, 0.0), D(N16, 0.0), invD(N16, 0.0);
+        std::vector<double> LC((size_t)nt * 256 + 1, 0.0), LR((size_t)nt * 256 + 1, 0.0), DC((size_t)nb * 256, 0.0), DR((size_t)nb * 256, 0.0), Dall(N16 + 1, 0.0), invDall(N16 + 1, 0.0);
+        double *D = Dall.data() + n0, *invD = invDall.data() + n0; // block-relative views (DevPat::tl_base)
+        constexpr int TW = 256; // workgroup size the scalar plans of the hybrid are laid out for in this check
+        TriPlan pf, pb;
+        std::vector<double> UF, UB;
+        if (mode == 1) {
+            for (int j = 0; j < N; j++) img[TP.D_img[j]] = Dv[j];
+            for (int e = 0; e < S.nnzL; e++) img[TP.Le_img[e]] = Lv[e];
+        } else {
+            // ---- hybrid: the scalar factor program, lane by lane as stage_factor walks it (api.cpp's destination codes) ----
+            pf = build_tri_plan(S, TW, true); pb = build_tri_plan(S, TW, false);
+            FactorPlan px = build_factor_plan(S, TW, pb.pos, pb.slots, pf.pos, pf.slots);
+            UF.assign(pf.slots + 1, 0.0); UB.assign(pb.slots + 1, 0.0);
+            std::vector<int> colof(S.nnzL);
+            for (int j = 0; j < N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colof[e] = j;
+            size_t s0 = 0;
+            std::vector<double> carry;
+            while (s0 < px.sl.size()) {
+                size_t s1 = s0 + 1;
+                while (s1 < px.sl.size() && !(px.sl[s1].newlev & 1)) s1++;
+                for (size_t si = s0; si < s1; si++) {
+                    const SliceMeta &sm = px.sl[si];
+                    const int g = 1 << sm.lg, lanes = sm.cnt * g;
+                    if (lanes > TW || sm.K > ELL_KMAX) return -6.0;
+                    if (!sm.cont) carry.assign(sm.cnt, 0.0);
+                    for (int r = 0; r < sm.cnt; r++) {
+                        double acc = carry[r];
+                        for (int qq = 0; qq < g; qq++)
+                            for (int kk = 0; kk < sm.K; kk++) { const int slot = sm.off + kk * lanes + r * g + qq; acc += UB[px.pa[slot]] * UF[px.pb[slot]]; }
+                        if (sm.more) { carry[r] = acc; continue; }
+                        const int tgt = px.target[sm.row0 + r];
+                        if (tgt < N) {
+                            if (tgt >= n0) img[TP.D_img[tgt]] = Dv[tgt] - acc;                         // top block: image
+                            else { Dall[tgt] = Dv[tgt] - acc; invDall[tgt] = 1.0 / Dall[tgt]; }
+                        } else {
+                            const int e = tgt - N;
+                            if (colof[e] >= n0) img[TP.Le_img[e]] = Lv[e] - acc;                       // top block: image
+                            else UB[pb.pos[e]] = Lv[e] - acc;
+                        }
+                    }
+                }
+                for (size_t si = s0; si < s1; si++)
+                    for (int r = 0; r < px.sl[si].cnt && !px.sl[si].more; r++) {
+                        const int tgt = px.target[px.sl[si].row0 + r];
+                        if (tgt >= N && colof[tgt - N] < n0) { const int e = tgt - N; UF[pf.pos[e]] = UB[pb.pos[e]] * invDall[colof[e]]; }
+                    }
+                s0 = s1;
+            }
+        }
         for (int v = 0; v < TP.nblev; v++) {
             for (int qi = TP.tgt_lev_ptr[v]; qi < TP.tgt_lev_ptr[v + 1]; qi++) { // phase 1
                 const int tg = TP.tgt[qi];
                 double Tt[16][16];
                 for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) Tt[r][c] = img[(size_t)tg * 256 + tile_res(r, c)];
                 for (int e = TP.tp_ptr[qi]; e < TP.tp_ptr[qi + 1]; e++) {
-                    const double *A = LC.data() + (size_t)TP.pa[e] * 256, *B = LC.data() + (size_t)TP.pb[e] * 256, *d = D.data() + TP.pk[e] * 16;
+                    const double *A = LC.data() + (size_t)TP.pa[e] * 256, *B = LC.data() + (size_t)TP.pb[e] * 256, *d = D + TP.pk[e] * 16;
                     for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { double sacc = 0; for (int k = 0; k < 16; k++) sacc += A[tile_op(r, k)] * (B[tile_op(c, k)] * d[k]); Tt[r][c] -= sacc; }
                 }
                 if (tg >= nb) { double *o = LC.data() + (size_t)(tg - nb) * 256; for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) o[tile_op(r, c)] = Tt[r][c]; continue; }
@@ -1082,9 +1135,23 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
                 for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { LR[(size_t)t * 256 + tile_res(r, c)] = Tt[r][c]; LC[(size_t)t * 256 + tile_op(r, c)] = Tt[r][c]; }
             }
         }
-        std::vector<double> rhs(N), ws(N16 + 1, 0.0);
+        std::vector<double> rhs(N), wsall(N16 + 17, 0.0);
         for (int i = 0; i < N; i++) rhs[i] = rnd() - 0.5;
-        for (int i = 0; i < N; i++) ws[TP.slot[i]] = rhs[S.perm[i]];
+        for (int i = 0; i < N; i++) wsall[TP.slot[i]] = rhs[S.perm[i]];
+        double *ws = wsall.data() + n0; // block-relative view
+        auto ell_sweep = [&](const TriPlan &pl, const std::vector<double> &val, bool fwd) { // the scalar sweeps, slice by slice
+            for (const SliceMeta &sm : pl.sl) {
+                const int g = 1 << sm.lg, lanes = sm.cnt * g;
+                std::vector<double> acc(sm.cnt, 0.0);
+                for (int t = 0; t < lanes; t++)
+                    for (int kk = 0; kk < sm.K; kk++) { const int slot = sm.off + kk * lanes + t; acc[t / g] += val[slot] * wsall[pl.idx[slot]]; }
+                for (int r = 0; r < sm.cnt; r++) {
+                    const int i = sm.row0 + r;
+                    wsall[i] = (fwd || sm.more) ? wsall[i] - acc[r] : (wsall[i] - acc[r]) * invDall[i];
+                }
+            }
+        };
+        if (mode == 2) ell_sweep(pf, UF, true); // levels under the top block, then its rows against them (the plan's extra level)
         auto block = [&](int B, const std::vector<int> &tiles_of, int e0, int e1, const std::vector<double> &val, const std::vector<double> &dia, bool fwd) {
             double acc[16] = {0};
             for (int e = e0; e < e1; e++) {
@@ -1100,9 +1167,10 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
         };
         for (int v = 0; v < TP.nblev; v++) for (int B = TP.blev_ptr[v]; B < TP.blev_ptr[v + 1]; B++) block(B, TP.tr_tile, TP.tr_ptr[B], TP.tr_ptr[B + 1], LC, DC, true);
         for (int v = TP.nblev - 1; v >= 0; v--) for (int B = TP.blev_ptr[v]; B < TP.blev_ptr[v + 1]; B++) block(B, TP.tr_tile, TP.tc_ptr[B], TP.tc_ptr[B + 1], LR, DR, false);
+        if (mode == 2) ell_sweep(pb, UB, false);
         std::vector<double> x(N);
-        for (int j = 0; j < N; j++) x[S.perm[j]] = ws[TP.slot[j]];
-        for (int s_ = 0; s_ < N16; s_++) { bool real = false; for (int j = 0; j < N && !real; j++) real = TP.slot[j] == s_; if (!real && ws[s_] != 0.0) return -5.0; if (N > 4000) break; } // padding slots stay 0
+        for (int j = 0; j < N; j++) x[S.perm[j]] = wsall[TP.slot[j]];
+        for (int s_ = 0; s_ < N16; s_++) { bool real = false; for (int j = 0; j < N && !real; j++) real = TP.slot[j] == s_; if (!real && wsall[s_] != 0.0) return -5.0; if (N > 4000) break; } // padding slots stay 0
         std::vector<double> r(rhs);
         for (int e = 0; e < S.nnzK; e++) {
             const int a = S.K_row[e], b = S.K_col[e];
@@ -1113,6 +1181,17 @@ double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *
         for (int i = 0; i < N; i++) { nr = std::max(nr, std::fabs(r[i])); nbn = std::max(nbn, std::fabs(rhs[i])); }
         return N ? nr / nbn : 0.0;
     } catch (const std::exception &e) { g_err = e.what(); return -2.0; }
+}
+
+
+double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                    const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats) {
+    return host_check_tiles_impl(n, m, p, ncones, q, Gjc, Gir, Ajc, Air, seed, order_mode, stats, 1);
+}
+// hybrid: scalar programs under the cut + tile path on the top block; returns -10 when the pattern does not qualify
+double eicos_debug_host_check_hybrid(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                     const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats) {
+    return host_check_tiles_impl(n, m, p, ncones, q, Gjc, Gir, Ajc, Air, seed, order_mode, stats, 2);
 }
 
 } // extern "C"

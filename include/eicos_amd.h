@@ -179,6 +179,11 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
 double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
                                     const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats);
 
+/* the same for the hybrid path (scalar programs below the cut, tiles on the top block of the tree); returns -10 when the
+ * pattern's schedule has no tail worth handing to the tile path */
+double eicos_debug_host_check_hybrid(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                     const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,3 +170,37 @@ def test_cpp_surfaces_compile_including_the_eigen_typed_overloads(tmp_path):
                      '#endif\nint main() { return 0; }\n')
     subprocess.check_call(base + ["-fsyntax-only", str(probe)])
     subprocess.check_call(base + ["-fsyntax-only", "-I", os.path.join(ROOT, "tests", "eigen_standin"), str(probe)])
+
+
+def test_tile_and_hybrid_plans_on_the_host():
+    # The dense-front path without a GPU: the block-sparse 16 x 16 tile plan (ordering, blocks, tile pair program, finalise
+    # lists, CSR / CSC tile views, tile-internal element order, inverse diagonal tiles, identity-tile skipping) and the
+    # hybrid plan (scalar programs below the cut, extra forward level, image destinations, tiles on the top block) are
+    # executed on the host exactly as the kernels index them: || K x - b || / || b || on random quasi-definite values.
+    import eicos_amd
+    from eicos_amd import binding as b
+    from eicos_amd.generate import dense_front_pattern, random_socp_pattern
+    from conftest import ALL_FIXTURES, load_fixture
+    hybrid = {}
+    for name in ALL_FIXTURES:
+        pat, _ = load_fixture(name)
+        if pat.n == 0:
+            continue
+        r, st = b.host_check_tiles(pat)                      # pure tile mode forced on every pattern
+        assert 0 <= r < 1e-12, (name, r, eicos_amd.binding._lib().eicos_last_error())
+        assert st["blocks"] * 16 >= st["dim_K"] and st["block_levels"] >= 1
+        r, st = b.host_check_tiles(pat, hybrid=True)
+        assert r == -10.0 or 0 <= r < 1e-12, (name, r)
+        hybrid[name] = (r, st)
+    # the deep Netlib patterns end in a chain of single-node levels and do qualify; the MPC pattern (log-depth tree) does not
+    for name in ("lp_25fv47", "lp_agg", "lp_agg2", "lp_agg3", "lp_bandm", "lp_beaconfd", "lp_bnl1"):
+        assert hybrid[name][0] >= 0 and hybrid[name][1]["blocks"] >= 3, (name, hybrid[name])
+    assert hybrid["MPC02"][0] == -10.0
+    # BASELINE.json config 4 in full (n = 2000, 32 cones x 64): the tile program replaces 5.8 M scalar pairs
+    pat, _ = dense_front_pattern(2000, 32, 64)
+    r, st = b.host_check_tiles(pat)
+    assert 0 <= r < 1e-12 and st["tile_pairs"] < 4000 and st["block_levels"] <= 16 and st["nnzL"] > 16 * st["dim_K"], (r, st)
+    for seed in range(3):
+        pat, _ = random_socp_pattern(40 + 10 * seed, 8, 12, [20, 3, 17], density=0.4, seed=seed)
+        r, st = b.host_check_tiles(pat, seed=seed + 1)
+        assert 0 <= r < 1e-12, (seed, r)

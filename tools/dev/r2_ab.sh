@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-bash tools/dev/ab_env_r1.sh 1024 EICOS_BLOCKS_PER_CU=2 EICOS_BLOCKS_PER_CU=3 > gpurun_out/r2_ab.log 2>&1
-bash tools/dev/ab_env_r1.sh 1536 EICOS_BLOCKS_PER_CU=2 EICOS_BLOCKS_PER_CU=3 >> gpurun_out/r2_ab.log 2>&1
-bash tools/dev/ab_env_r1.sh 4096 EICOS_BLOCKS_PER_CU=2 EICOS_BLOCKS_PER_CU=3 >> gpurun_out/r2_ab.log 2>&1
+for round in 1 2; do for lib in "" build_exp/libe3.so build_exp/libe4.so; do
+EICOS_AMD_LIB=$lib python tools/dev/gpu_sweep.py dense-front 512 2 2>&1 | head -2 | cut -c1-330
+done; done > gpurun_out/r2_ab.log 2>&1
 cat gpurun_out/r2_ab.log
