@@ -3,7 +3,8 @@ export TMPDIR=/tmp
 rm -rf gpurun_out/prof_r2
 python3 bench.py --steps 10 --warmup 2 > gpurun_out/prof_r2_bench_plain.json 2> gpurun_out/prof_r2_bench_plain.err
 tail -1 gpurun_out/prof_r2_bench_plain.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_r2_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-soc > gpurun_out/prof_r2_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2/soc_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --soc > gpurun_out/prof_r2_bench_soc.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/prof_r2/pmc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-soc > gpurun_out/prof_r2_pmc_$tag.log 2>&1
