@@ -39,6 +39,8 @@ struct eicos_batch {
     DevPat dp{};
     int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
     int ki = 1;               // instances per workgroup solved in lock-step (DevPat::w_split)
+    int order_min = 0;        // batches up to this size (one instance per CU) are solved in identity order, larger ones longest-first
+    bool last_ordered = false; int last_kis = 1; // how the most recent solve was launched (eicos_debug_trace)
     size_t upd_lds = 0;       // > 0: updateData runs the entry-parallel kernel with this much dynamic LDS (values + maxima)
     size_t dyn_lds1 = 0; int nlds1 = 0; // launch shape of the single-instance kernel on the same workspace (warm start)
     int *d_pattern = nullptr;
@@ -276,6 +278,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), inverse diagonal tiles both ways (DC, DR)
         D.w_LC = Wl.add((size_t)TP.nt * 256 + 8); D.w_LR = Wl.add((size_t)TP.nt * 256 + 8);
         D.w_DC = Wl.add((size_t)TP.nb * 256); D.w_DR = Wl.add((size_t)TP.nb * 256);
+        D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
     }
     D.work_stride = Wl.size;
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
@@ -455,12 +458,21 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         int ki = h->ki; // wanted (decided with the workgroup size, above); needs both vectors + the tables in LDS
         if (ki != 2 || tile || fit < 2 || h->threads < 256 || batch < 2) ki = 1; // (tile / hybrid factor paths are single-instance)
         h->ki = ki;
-        // the single-instance kernel on the same workspace (warm start; debug hooks): one vector in LDS
-        h->nlds1 = h->nlds; h->dyn_lds1 = h->nlds >= 1 ? (size_t)h->nlds * vec + meta : scratch;
-        if (ki == 2) { h->nlds = 1; h->nlds1 = 1; h->dyn_lds1 = vec + meta; }
+        // Dual right-hand-side solves (pure tile mode: bandwidth-bound on streaming L and G): needs two vectors in LDS
+        int dual = (tile1 && fit == 2) ? 1 : 0;
+        dual = env_int("EICOS_DUAL", dual);
+        if (!tile1 || fit < 2) dual = 0;
+        if (dual) h->nlds = 1;
+        D.dual = dual;
+        if (ki == 2) h->nlds = 1;
+        const int nvec = (ki == 2 || dual) ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS
+        // (the single-instance kernel on a pair handle -- warm start -- runs with the same LDS layout)
+        h->nlds1 = h->nlds;
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
-        h->dyn_lds = h->nlds >= 1 ? (size_t)ki * h->nlds * vec + meta : scratch;
-        D.tl_scratch = h->nlds >= 1 ? h->nlds * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
+        h->dyn_lds = h->nlds >= 1 ? (size_t)nvec * vec + meta : scratch;
+        h->dyn_lds1 = h->dyn_lds;
+        D.lds_tab = h->nlds >= 1 ? nvec * D.Npad : 0;
+        D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
     }
     D.group_stride = (size_t)h->ki * D.work_stride;
     HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds));
@@ -486,6 +498,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min((batch + h->ki - 1) / h->ki, resident);
+    h->order_min = prop.multiProcessorCount;
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
     {   // entry-parallel updateData: needs the A / G values and the row / column maxima in LDS and <= 8 vector entries per thread
         const size_t need = ((size_t)S.nnzA + S.nnzG + S.n + S.p + S.m + 8) * sizeof(double);
@@ -650,9 +663,10 @@ int eicos_batch_solve_async(eicos_batch *h) {
     // then be in different stages, so warm-started handles run the single-instance kernel (same workspace slabs)
     const bool single = h->ki == 1 || h->warm_shift > 0.;
     HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, single ? h->nlds1 : h->nlds,
-                         h->dp.idx16, single ? 1 : h->ki, h->warm_shift, h->dyn_delta, h->dyn_eps, single ? h->dyn_lds1 : h->dyn_lds, h->stream));
+                         h->dp.idx16, single ? 1 : h->ki, h->order_min * (single ? 1 : h->ki), h->warm_shift, h->dyn_delta, h->dyn_eps, single ? h->dyn_lds1 : h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
+    h->last_kis = single ? 1 : h->ki; h->last_ordered = h->batch > h->order_min * h->last_kis;
     return EICOS_OK;
 }
 
@@ -851,11 +865,18 @@ int eicos_debug_scalings(eicos_batch *h, int inst, const double *s, const double
 
 int eicos_debug_trace(eicos_batch *h, int inst, double *out) {
     if (!h || !out || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
-    const int kis = (h->ki == 1 || h->warm_shift > 0.) ? 1 : h->ki; // instances per workgroup of the kernel that ran
+    const int kis = h->last_kis; // instances per workgroup of the kernel that ran
     if (h->batch > h->grid * kis) return fail(EICOS_E_INVALID, "trace is per workspace slot: needs batch <= resident instances");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)(inst / kis) * h->dp.group_stride + (size_t)(inst % kis) * h->dp.w_split + h->dp.w_trace,
+    int slot = inst;
+    if (h->last_ordered) { // the launch took the instances in longest-first order: slot q holds instance order[q]
+        std::vector<int> ord(h->batch);
+        HIP_TRY(hipMemcpy(ord.data(), h->d_queue + 16, (size_t)h->batch * sizeof(int), hipMemcpyDeviceToHost));
+        slot = (int)(std::find(ord.begin(), ord.end(), inst) - ord.begin());
+        if (slot >= h->batch) return fail(EICOS_E_INVALID, "instance not found in the launch order");
+    }
+    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)(slot / kis) * h->dp.group_stride + (size_t)(slot % kis) * h->dp.w_split + h->dp.w_trace,
                       (size_t)TRACE_ROWS * TRACE_COLS * sizeof(double), hipMemcpyDeviceToHost));
     return EICOS_OK;
 }

@@ -133,6 +133,8 @@ struct DevPat {
     // w_split are per instance (instance k at k * w_split + offset), the arrays at or above it -- the factor, its value
     // stream Kt and the KKT-space vectors -- are shared KI-interleaved (element i of instance k at KI * offset + i * KI + k).
     int w_split;
+    int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)
+    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves (tile mode): flag + the two interleaved vectors in the workspace
     size_t inst_stride, work_stride; // in doubles
     size_t group_stride;             // workspace of one resident workgroup = (instances per workgroup of the handle) * work_stride
 };

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 #include <type_traits>
 
 #include "device_types.hpp"
@@ -72,7 +73,7 @@ struct ShI {
     DevInfo wi, bi;
     double sv[SV_COUNT];
     int fl[FL_COUNT];
-    int kref, done; // refinement steps of the last KKT solve; 1 = this instance has finished (lock-step groups)
+    int kref, kref2, done; // refinement steps of the last KKT solve (kref2: of the second right-hand side of a dual solve); 1 = this instance has finished (lock-step groups)
     unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
 };
 struct Sh : ShI {
@@ -328,7 +329,7 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
 // Lock-step form of ell_dots for KI instances of one workgroup: the slice descriptors and gather indices are shared, the
 // matrix values come from the KI instance slabs (eval[k]), the gathered vector x is KI-interleaved; `pre(k, row)` /
 // `epi(k, row, sum, pre)` get the instance number.
-template <int T, bool I16, int KI, class SM, class X, class Pre, class Epi>
+template <int T, bool I16, int KI, bool SHARED, class SM, class X, class Pre, class Epi>
 __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, const gcdbl_p (&eval)[KI], X x, int dummy_slot,
                                            Pre &&pre, Epi &&epi) {
     if (ns == 0) return; // no rows
@@ -347,8 +348,11 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
+            // streamed once per pass: keep the shared index arrays in L2.  SHARED (dual right-hand sides of ONE instance):
+            // the KI vectors are multiplied by the same matrix values -> one load
+            nv[kk][0] = ld_u32_nt(eval[0], slot);
 #pragma unroll
-            for (int k = 0; k < KI; k++) nv[kk][k] = ld_u32_nt(eval[k], slot); // streamed once per pass: keep the shared index arrays in L2
+            for (int k = 1; k < KI; k++) nv[kk][k] = SHARED ? nv[kk][0] : ld_u32_nt(eval[k], slot);
         }
 #pragma unroll
         for (int k = 0; k < KI; k++) nr[k] = pre(k, act ? nm.row0 + (t >> nm.lg) : 0);
@@ -651,7 +655,7 @@ __device__ __forceinline__ void restore_scalars() { // w = w_best (scalars), cou
 }
 
 // Slice table `which` of the current pattern: the LDS copy (NLDS >= 1) or the one in global memory.
-#define LDS_TABLE(at) (reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)KI * NLDS * P.Npad) + (at))
+#define LDS_TABLE(at) (reinterpret_cast<const PackedSlice *>(g_dyn + P.lds_tab) + (at))
 
 // states of the solve program
 enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KKT_AFF, ST_KKT_COMB, ST_DONE };
@@ -699,7 +703,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
     // the loads that need them, so that their round trip is not on the path either
-    auto fmeta = [&](int sidx) { return tab_lds ? slice_at(reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)KI * NLDS * P.Npad) + P.lm_fac, sidx) : slice_at(P.fac_sl, sidx); };
+    auto fmeta = [&](int sidx) { return tab_lds ? slice_at(reinterpret_cast<const PackedSlice *>(g_dyn + P.lds_tab) + P.lm_fac, sidx) : slice_at(P.fac_sl, sidx); };
     auto fload = [&](const Sl &nm, FSlot &o) {
         o.row0 = nm.row0; o.cnt = nm.cnt; o.lg = nm.lg; o.K = nm.K; o.off = nm.off;
         o.newlev = nm.newlev; o.last = nm.last;
@@ -945,15 +949,16 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
 // A tile mat-vec: lane l multiplies its four tile elements by the vector entries 4 s + (l >> 4), s = 0..3, and the four
 // lane groups are folded by two cross-lane adds: 2 KB contiguous per wavefront and tile, no index arrays at all.
 // The loads of TILE_PF tiles are in flight per wavefront; blocks whose diagonal tile is the identity skip its product.
-template <int T, bool LDSBAR, class WS>
+// NR = 2: two right-hand sides at once (the KKT1 and affine systems of one pass): ws is NR-interleaved, a
+// tile is loaded ONCE and multiplies both vectors -- the sweeps stream L once instead of twice.
+template <int T, bool LDSBAR, int NR, class WS>
 __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
-    auto ws = ws0 + P.tl_base; // the blocks start at slot tl_base (hybrid: behind the scalar part of the vector)
+    auto ws = ws0 + (size_t)P.tl_base * NR; // the blocks start at slot tl_base (hybrid: behind the scalar part of the vector)
     constexpr int NW = T / 64;
     gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, invD = W + P.w_invD + P.tl_base;
     const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, lc = lane & 15;
     auto bar = [&] { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); };
     auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
-
     // One sweep: per level every wavefront walks ITS flat list of tile operations (host: build_tile_sweeps) -- the tiles
     // of its blocks, each block closed by its diagonal operation -- with the tile loads of the next TILE_PF operations in
     // flight across block boundaries (they do not depend on ws).
@@ -968,7 +973,9 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                 const i4_t op = ops[min(o, o1 - 1)];
                 x = tile_ld((op.w & TOP_DIAG) ? dia : val, op.x, lane);
             };
-            double acc = 0.;
+            double acc[NR];
+#pragma unroll
+            for (int k = 0; k < NR; k++) acc[k] = 0.;
             if (o0 < o1) {
 #pragma unroll
                 for (int u = 0; u < TILE_PF; u++) load(o0 + u, qv[u]);
@@ -982,19 +989,29 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                     const int fl = op.w, vb = op.y;
                     if (!(fl & TOP_DIAG)) {
 #pragma unroll
-                        for (int st = 0; st < 4; st++) acc += cv[st] * ws[vb * 16 + 4 * st + kq];
-                    } else { // close block vb: r = b_B - acc, then the diagonal tile
-                        const double own = ws[vb * 16 + lc];
-                        const double r = (scale ? own * invD[vb * 16 + lc] : own) - fold(acc);
-                        acc = 0.;
-                        double res = r;
-                        if (!(fl & TOP_IDENT)) {
-                            double oo = 0.;
+                        for (int st = 0; st < 4; st++) {
+                            double y[NR];
+                            ldK<NR>(ws, vb * 16 + 4 * st + kq, y);
 #pragma unroll
-                            for (int st = 0; st < 4; st++) oo += cv[st] * __shfl(r, 4 * st + kq, 64);
-                            res = fold(oo);
+                            for (int k = 0; k < NR; k++) acc[k] += cv[st] * y[k];
                         }
-                        if (lane < 16) ws[vb * 16 + lane] = res;
+                    } else { // close block vb: r = b_B - acc, then the diagonal tile
+                        double own[NR], res[NR];
+                        ldK<NR>(ws, vb * 16 + lc, own);
+                        const double idv = scale ? invD[vb * 16 + lc] : 1.;
+#pragma unroll
+                        for (int k = 0; k < NR; k++) {
+                            const double r = (scale ? own[k] * idv : own[k]) - fold(acc[k]);
+                            acc[k] = 0.;
+                            res[k] = r;
+                            if (!(fl & TOP_IDENT)) {
+                                double oo = 0.;
+#pragma unroll
+                                for (int st = 0; st < 4; st++) oo += cv[st] * __shfl(r, 4 * st + kq, 64);
+                                res[k] = fold(oo);
+                            }
+                        }
+                        if (lane < 16) stK<NR>(ws, vb * 16 + lane, res);
                     }
                 }
             }
@@ -1233,7 +1250,11 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int
 // (step count, previous error, done flag): the loop runs until all of them have stopped; an instance that has stopped
 // keeps its iterate while the others take further steps (its lanes still compute, the result is discarded).
 // amask: bit k set = instance k takes part (not finished, slot in use).
-template <int T, int NLDS, bool I16, int KI>
+// DUAL (KI = 2, tile mode): not two instances but the TWO INDEPENDENT right-hand sides of one instance -- rhs1 and rhs2 of
+// the initialisation (ref :933, :966) or of a pass (KKT1 and the affine system, ref :1173-1179: RHSaffine does not depend on
+// the first solution) -- solved together: the sweeps and the refinement residuals stream L, A and G once for both.  The
+// vectors are interleaved like a lock-step pair's, the matrix arrays are the instance's own.
+template <int T, int NLDS, bool I16, int KI, bool DUAL = false>
 __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, int stage, int amask) {
     ps = uni(ps); I0 = uni_ptr(I0); I1 = uni_ptr(I1); Wg = uni_ptr(Wg); stage = uni(stage); amask = uni(amask);
     const DevPat &P = c_pat[ps];
@@ -1248,14 +1269,16 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     gdbl_p dx[KI], dy[KI], dz[KI];
 #pragma unroll
     for (int k = 0; k < KI; k++) {
-        gdbl_p I = Ik[k], W = Wg + (size_t)k * P.w_split;
+        gdbl_p I = Ik[k], W = Wg + (DUAL ? 0 : (size_t)k * P.w_split);
+        const bool fk = DUAL ? (k == 0) : first; // dual: right-hand side 0 is rhs1 -> (dx1, dy1, dz1), 1 is rhs2 -> (dx2, dy2, dz2)
         cagv[k] = I + P.i_cag; rAv[k] = I + P.i_rA; rGv[k] = I + P.i_rG;
-        rhsp[k] = W + (first ? P.w_rhs1 : P.w_rhs2);                   // elimination order (what the triangular sweeps consume)
-        gcdbl_p rhsk = W + (first ? P.w_rhs1k : P.w_rhs2k);            // same values as [x | y | z] (what the residual reads)
+        rhsp[k] = W + (fk ? P.w_rhs1 : P.w_rhs2);                      // elimination order (what the triangular sweeps consume)
+        gcdbl_p rhsk = W + (fk ? P.w_rhs1k : P.w_rhs2k);               // same values as [x | y | z] (what the residual reads)
         bx[k] = rhsk; by[k] = rhsk + n; bz[k] = rhsk + np;
         lpv[k] = W + P.w_lpv; csc[k] = W + P.w_csc; qv[k] = W + P.w_qv;
-        dx[k] = W + (first ? P.w_dx1 : P.w_dx2); dy[k] = W + (first ? P.w_dy1 : P.w_dy2); dz[k] = W + (first ? P.w_dz1 : P.w_dz2);
+        dx[k] = W + (fk ? P.w_dx1 : P.w_dx2); dy[k] = W + (fk ? P.w_dy1 : P.w_dy2); dz[k] = W + (fk ? P.w_dz1 : P.w_dz2);
     }
+    auto state = [&](int k) -> ShI & { if constexpr (DUAL) return g_S; else return inst_state<KI>(k); };
     // KKT-space vectors, in elimination order: X = current solution, E = rhs / residual / solve vector.
     // Both in LDS (NLDS = 2) or both in the workspace slab (NLDS = 0, patterns too large for LDS).
     // Roles: SV = vector the triangular sweeps run on; X = solution the residual gathers from; E = where the
@@ -1265,9 +1288,9 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     // further refinement step borrows the LDS vector.  NLDS = 0: everything in the workspace slab.
     auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return Wg + (size_t)KI * P.w_ek; }();
     auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return Wg + (size_t)KI * P.w_xk; }();
-    auto E = [&] { if constexpr (NLDS == 1) return Wg + (size_t)KI * P.w_ek; else return SV; }();
-    gdbl_p Xg = Wg + (size_t)KI * P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
-    const PackedSlice *tabs = reinterpret_cast<const PackedSlice *>(g_dyn + (size_t)KI * NLDS * P.Npad);
+    auto E = [&] { if constexpr (DUAL) return Wg + P.w_dual_ek; else if constexpr (NLDS == 1) return Wg + (size_t)KI * P.w_ek; else return SV; }();
+    gdbl_p Xg = DUAL ? Wg + P.w_dual_xk : Wg + (size_t)KI * P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
+    const PackedSlice *tabs = reinterpret_cast<const PackedSlice *>(g_dyn + P.lds_tab);
     auto tab_cag = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_cag; else return P.cag_sl; }();
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rA; else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rG; else return P.rG_sl; }();
@@ -1279,7 +1302,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         if (tid == 0) {
             const unsigned long long t1_ = wall_clock64();
 #pragma unroll
-            for (int k = 0; k < KI; k++) if ((amask >> k) & 1) inst_state<KI>(k).tick[slot] += t1_ - tk0_;
+            for (int k = 0; k < (DUAL ? 1 : KI); k++) if ((amask >> k) & 1) state(k).tick[slot] += t1_ - tk0_;
             tk0_ = t1_;
         }
     };
@@ -1311,7 +1334,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
         const bool wave0 = uni(tid >> 6) == 0;
         if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
-            if constexpr (KI == 1) { if constexpr (NLDS >= 1) tile_solve<T, true>(P, Wg, SV); else tile_solve<T, false>(P, Wg, SV); }
+            if constexpr (KI == 1 || DUAL) { if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV); }
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
             tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
             if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down
@@ -1319,7 +1342,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
                     if (wave0) tri_sweep<T, true, true, true, I16, KI>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
                     tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                    tile_solve<T, true>(P, Wg, SV);
+                    tile_solve<T, true, 1>(P, Wg, SV);
                     if (wave0) tri_sweep<T, false, true, true, I16, KI>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
@@ -1335,7 +1358,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
                     if (wave0) tri_sweep<T, true, false, true, I16, KI>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
                     tri_sweep<T, true, false, false, I16, KI>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                    tile_solve<T, false>(P, Wg, SV);
+                    tile_solve<T, false, 1>(P, Wg, SV);
                     if (wave0) tri_sweep<T, false, false, true, I16, KI>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
@@ -1360,7 +1383,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         }
         if (tid == 0) {
 #pragma unroll
-            for (int k = 0; k < KI; k++) if (!rdone[k]) inst_state<KI>(k).wi.n_ldlsolve++;
+            for (int k = 0; k < KI; k++) if (!rdone[k]) state(k).wi.n_ldlsolve++;
         }
 #pragma unroll
         for (int k = 0; k < KI; k++) if (!rdone[k]) kcnt[k]++;
@@ -1371,21 +1394,21 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
 #pragma unroll
         for (int k = 0; k < KI; k++) nex[k] = ney[k] = nez[k] = 0.;
         struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
-        ell_dots_k<T, I16, KI>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
+        ell_dots_k<T, I16, KI, DUAL>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
                     [&](int k, int j) { return PreK{ld_u32(bx[k], j), 0., ld_u32(P.ipx, j), 0}; },
                     [&](int k, int j, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - s - DELTASTAT * X[o * KI + k]; // ex = bx - G'dz - A'dy - delta dx
             E[o * KI + k] = e; nex[k] = fmax(nex[k], fabs(e));
         });
-        ell_dots_k<T, I16, KI>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
+        ell_dots_k<T, I16, KI, DUAL>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
                     [&](int k, int r) { return PreK{ld_u32(by[k], r), 0., ld_u32(P.ipy, r), 0}; },
                     [&](int k, int r, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - s + DELTASTAT * X[o * KI + k]; // ey = by - A dx + delta dy
             E[o * KI + k] = e; ney[k] = fmax(ney[k], fabs(e));
         });
-        ell_dots_k<T, I16, KI>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
+        ell_dots_k<T, I16, KI, DUAL>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
                     [&](int k, int i) { return PreK{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i)}; },
                     [&](int k, int i, double s, const PreK &pr) {
             const int o = pr.o;
@@ -1469,7 +1492,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         for_t_pre<T, 4>(n, [&](int j) { return V1{X[P.ipx[j] * KI + k]}; }, [&](int j, const V1 &r) { dx[k][j] = r.a; });
         for_t_pre<T, 4>(p, [&](int j) { return V1{X[P.ipy[j] * KI + k]}; }, [&](int j, const V1 &r) { dy[k][j] = r.a; });
         for_t_pre<T, 8>(m, [&](int i) { return V1{X[P.ipz[i] * KI + k]}; }, [&](int i, const V1 &r) { dz[k][i] = r.a; });
-        if (tid == 0) inst_state<KI>(k).kref = kcnt[k];
+        if (tid == 0) { if (DUAL && k == 1) g_S.kref2 = kcnt[k]; else state(k).kref = kcnt[k]; }
     }
     __syncthreads();
     tick(TK_KRES);
@@ -1774,6 +1797,20 @@ __device__ __forceinline__ void solve_group(int ps, gdbl_p (&Ik)[KI_MAX], int nv
                 state_out<KI>(k);
             }
             stage = ST_FACTOR;
+        } else if (KI == 1 && NLDS == 1 && P.dual && (stage == ST_KKT_INIT1 || stage == ST_KKT1)) {
+            // the two right-hand sides of this point of the algorithm do not depend on each other: one dual solve
+            if constexpr (KI == 1 && NLDS == 1) {
+                if (stage == ST_KKT1) kkt_post<T>(ps, Ik[0], Wg, ST_KKT1); // RHSaffine (ref :1176) needs the residuals only
+                kkt_solve<T, 1, I16, 2, true>(ps, Ik[0], Ik[0], Wg, stage, 3);
+                const int second = (stage == ST_KKT1) ? ST_KKT_AFF : ST_KKT_INIT2;
+                if (stage == ST_KKT_INIT1) kkt_post<T>(ps, Ik[0], Wg, ST_KKT_INIT1);
+                __syncthreads();
+                if (threadIdx.x == 0) g_S.kref = g_S.kref2;
+                __syncthreads();
+                const int next = kkt_post<T>(ps, Ik[0], Wg, second);
+                if (next == ST_RESID) iter = 0; // (after the initialisation pair)
+                stage = next;
+            }
         } else {
             kkt_solve<T, NLDS, I16, KI>(ps, Ik[0], Ik[KI - 1], Wg, stage, amask);
             int next = stage;
@@ -1796,7 +1833,7 @@ __global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
     const DevPat &P = c_pat[ps];
     gdbl_p Wg = (gdbl_p)work + (size_t)blockIdx.x * P.group_stride;
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
-        int *dst = reinterpret_cast<int *>(g_dyn + (size_t)KI * NLDS * P.Npad);
+        int *dst = reinterpret_cast<int *>(g_dyn + P.lds_tab); // (doubles from the start of the dynamic LDS: behind the vectors)
         auto stage = [&](const PackedSlice EICOS_GLOBAL *src, int cnt, int at) {
             gint_p si = reinterpret_cast<gint_p>(src);
             for (int q = threadIdx.x; q < cnt * 4; q += T) dst[at * 4 + q] = si[q];
@@ -2111,11 +2148,14 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
     return byT(std::integral_constant<int, 256>{});
 }
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        int idx16, int ki, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
+                        int idx16, int ki, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // group queue of this launch
     if (e != hipSuccess) return e;
-    if (B <= grid * ki) order = nullptr; // everything starts at once: identity (group g = instances g ki .., eicos_debug_trace)
+    // Longest-first order (by the work of the previous solve) whenever a CU gets more than one workgroup: for a batch larger
+    // than the grid it is the queue's processing order; for a one-round batch it makes the dispatcher pair a long instance
+    // with a short one on each CU, which then finishes the long one alone (+7 % at batch 512 on 256 CUs).
+    if (B <= order_min) order = nullptr; // at most one instance per CU: identity
     else {
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order);
         if ((e = hipGetLastError()) != hipSuccess) return e;
