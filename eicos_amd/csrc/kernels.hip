@@ -893,7 +893,7 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
             for (int j = 0; j < 16; j++) {
                 double dj = scr[j * 17 + j];
                 if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
-                    const double sg = (double)P.tl_psign[J * 16 + j];
+                    const double sg = (double)P.tl_psign[P.tl_base + J * 16 + j]; // (per slot of the KKT-space vectors)
                     if (sg * dj <= g_S.dyn_eps) { dj = sg * g_S.dyn_delta; if (lane == 0) scr[j * 17 + j] = dj; }
                 }
                 if (dj == 0. && lane == 0) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)

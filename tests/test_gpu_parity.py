@@ -733,3 +733,21 @@ def test_invalid_arguments_are_refused_with_error_codes():
     assert L.eicos_batch_set_warm_start(g._h, -1.0) == -1
     assert L.eicos_solve(g._h, None) == -1                          # single-instance call on a batch of two
     g.close()
+
+
+@pytest.mark.parametrize("name,env", [("lp_bandm", {}), ("lp_bandm", {"EICOS_TILES": "1"}), ("issue98", {"EICOS_TILES": "1"})])
+def test_dynamic_regularisation_sign_pattern_on_the_tile_and_hybrid_paths(name, env, monkeypatch):
+    # N4 on the dense-front code: the 16 x 16 diagonal LDL' repairs a pivot whose sign disagrees with the quasi-definite sign
+    # pattern (tl_psign, one entry per slot of the KKT-space vectors).  On a well-conditioned instance no pivot may trigger:
+    # with a wrong sign table (or a wrong slot offset in hybrid mode, where the top block sits behind the scalar part)
+    # every pivot of the block would be replaced and the solve would fall apart.
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pat, sets = load_fixture(name)
+    o = OracleSolver(pat, sets[0]); oc = o.solve(); oi = o.info()
+    g = eicos_amd.BatchSolver(pat, 2); g.update(*rep(sets[0], 2))
+    g.set_dynamic_regularization(2e-7, 1e-13)
+    codes = g.solve(); gi = g.info()
+    assert list(codes) == [oc, oc] and abs(gi[0]["iter"] - oi["iter"]) <= 1
+    assert abs(gi[0]["pcost"] - oi["pcost"]) <= 1e-7 * max(1.0, abs(oi["pcost"]))
+    g.close(); o.close()
