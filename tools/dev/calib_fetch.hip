@@ -15,6 +15,14 @@ template <class V, bool NT> __global__ void k_read(const V *p, size_t n, double 
     }
     if (acc == 1.2345) out[0] = acc;
 }
+// Random 8-byte gather (the access shape of the global-vector fallback's ELL gathers): n loads spread by a
+// multiplicative hash over the whole buffer, so nearly every load touches its own HBM granule.
+__global__ void k_gather8(const double *p, size_t n, size_t mask, double *out) {
+    double acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc += p[(i * 0x9E3779B97F4A7C15ull >> 20) & mask];
+    if (acc == 1.2345) out[0] = acc;
+}
 __global__ void k_write8(double *p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (double)i;
 }
@@ -26,6 +34,8 @@ int main() {
     hipLaunchKernelGGL((k_read<double, false>), dim3(4096), dim3(256), 0, 0, (const double *)buf, bytes / 8, out);
     hipLaunchKernelGGL((k_read<double, true>), dim3(4096), dim3(256), 0, 0, (const double *)buf, bytes / 8, out);
     hipLaunchKernelGGL((k_read<double2, false>), dim3(4096), dim3(256), 0, 0, (const double2 *)buf, bytes / 16, out);
+    // 2^24 gathered loads = 2^27 useful bytes; FETCH_SIZE x 1024 / 2^24 = bytes the counter charges per gathered load
+    hipLaunchKernelGGL(k_gather8, dim3(4096), dim3(256), 0, 0, (const double *)buf, (size_t)1 << 24, (bytes / 8) - 1, out);
     hipLaunchKernelGGL(k_write8, dim3(4096), dim3(256), 0, 0, (double *)buf, bytes / 8);
     if (hipDeviceSynchronize() != hipSuccess) return 2;
     printf("done: each kernel touches %zu bytes\n", bytes);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output of tools/dev/profile_r1.sh into profiles/<tag>_*.{csv,md}.
 
-usage: python tools/summarize_profile.py gpurun_out/prof_r1 profiles/r01 ["MPC02 batch=1024"]
+usage: python tools/summarize_profile.py gpurun_out/prof_r2 profiles/r02_v2 ["MPC02 batch=1024" [prefix]]
 The optional third argument names the workload the passes were taken on; together with a hash of the kernel sources
 it is recorded in the JSON so that bench.py only quotes `roofline.traffic` from a summary of the SAME code and workload.
 Per-launch averages of the PMC counters for the solve kernel; FETCH_SIZE/WRITE_SIZE are reported in
@@ -20,14 +20,15 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "MPC02 batch=1024"
+prefix = sys.argv[4] if len(sys.argv) > 4 else ""  # sub-run inside src: "" (headline), "soc_", "tile_"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bench import kernel_source_hash
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, prefix + "stats", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], dst + "_kernel_stats.csv")
 agg = collections.defaultdict(list)
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for f in glob.glob(os.path.join(src, prefix + "pmc_*", "*", "*counter_collection.csv")):
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
         if "k_solve" in r["Kernel_Name"]:
