@@ -37,7 +37,8 @@ class Dims(C.Structure):
                                        "nlevels", "order_mode", "batch", "device")] + \
                [("factor_pairs", C.c_longlong), ("inst_bytes", C.c_size_t), ("work_bytes", C.c_size_t),
                 ("pattern_bytes", C.c_size_t), ("threads_per_block", C.c_int), ("resident_blocks", C.c_int),
-                ("lds_bytes", C.c_int), ("instances_per_block", C.c_int)]
+                ("lds_bytes", C.c_int), ("instances_per_block", C.c_int),
+                ("lds_resident", C.c_int), ("factor_path", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

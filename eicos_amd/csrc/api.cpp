@@ -47,6 +47,7 @@ struct eicos_batch {
     int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
     size_t dyn_lds = 0;
     int nlds = 0;
+    int ldsres = 0;           // 1: solves run the LDS-resident kernel (ldsres::launch_solve), slabs copied in and out per instance
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     int *d_queue = nullptr; // instance queue of the solve kernel (reset per launch)
@@ -473,12 +474,32 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         h->dyn_lds1 = h->dyn_lds;
         D.lds_tab = h->nlds >= 1 ? nvec * D.Npad : 0;
         D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
+        // LDS-resident variant (small patterns, kernels_ldsres.hip): when the instance slab and the workspace slab fit LDS
+        // beside the vectors and tables, k_solve works on LDS copies of both, so the elementwise stages and the products wait
+        // for LDS instead of L2 (+12 % on lp_afiro at batch 256; the level-by-level sweeps are issue-bound and do not change:
+        // DESIGN.md 5.1).  Only for batches that fit the grid in one round -- beyond that the eight small workgroups per CU
+        // of the HBM-slab kernel hide more latency than the <= 3 that LDS holds here (measured, lp_afiro batch 2048).
+        h->ldsres = 0; D.lr_inst = D.lr_work = 0;
+        if (!tile && ki == 1 && !dual && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1)) {
+            const size_t base = (h->dyn_lds + 15) & ~(size_t)15, islab = (D.inst_stride + 1) & ~(size_t)1, wslab = (D.work_stride + 1) & ~(size_t)1;
+            const size_t total = base + (islab + wslab) * sizeof(double);
+            const size_t per_cu = (160 * 1024) / (total + lds_static); // workgroups per CU that LDS allows
+            if (per_cu >= 1 && (size_t)batch <= per_cu * (size_t)prop.multiProcessorCount) {
+                h->ldsres = 1; D.lr_inst = (int)(base / sizeof(double)); D.lr_work = D.lr_inst + (int)islab;
+                h->dyn_lds = h->dyn_lds1 = total;
+            }
+        }
     }
     D.group_stride = (size_t)h->ki * D.work_stride;
-    HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds));
-    if (h->ki > 1) HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds1, h->dp.idx16, 1, h->dyn_lds1));
     int bpc = 1;
-    HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds, &bpc));
+    if (h->ldsres) {
+        HIP_TRY_H(ldsres::solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, 1, h->dyn_lds));
+        HIP_TRY_H(ldsres::solve_occupancy(h->threads, h->nlds, h->dp.idx16, 1, h->dyn_lds, &bpc));
+    } else {
+        HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds));
+        if (h->ki > 1) HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds1, h->dp.idx16, 1, h->dyn_lds1));
+        HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds, &bpc));
+    }
     bpc = std::max(1, std::min(bpc, 8));
     {
         // Workgroups per CU for this batch.  A workgroup slows down by about half of its stand-alone time per
@@ -519,6 +540,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     }
     if (h->pslot < 0) return bail(EICOS_E_INVALID, "too many live handles on this device (64)");
     HIP_TRY_H(upload_pattern(h->pslot, h->dp));
+    if (h->ldsres) HIP_TRY_H(ldsres::upload_pattern(h->pslot, h->dp));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.group_stride * sizeof(double)));
@@ -662,6 +684,10 @@ int eicos_batch_solve_async(eicos_batch *h) {
     // warm start decides per instance whether the initialisation solves are skipped: members of a lock-step group could
     // then be in different stages, so warm-started handles run the single-instance kernel (same workspace slabs)
     const bool single = h->ki == 1 || h->warm_shift > 0.;
+    if (h->ldsres)
+        HIP_TRY(ldsres::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, 1,
+                                     h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
+    else
     HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, single ? h->nlds1 : h->nlds,
                          h->dp.idx16, single ? 1 : h->ki, h->order_min * (single ? 1 : h->ki), h->warm_shift, h->dyn_delta, h->dyn_eps, single ? h->dyn_lds1 : h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
@@ -750,6 +776,7 @@ int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     o->inst_bytes = h->dp.inst_stride * sizeof(double); o->work_bytes = h->dp.work_stride * sizeof(double);
     o->pattern_bytes = h->pattern_ints * sizeof(int);
     o->threads_per_block = h->threads; o->resident_blocks = h->grid * h->ki; o->lds_bytes = (int)h->dyn_lds; o->instances_per_block = h->ki;
+    o->lds_resident = h->ldsres; o->factor_path = h->sym.tile;
     return EICOS_OK;
 }
 

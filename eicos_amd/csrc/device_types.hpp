@@ -135,6 +135,7 @@ struct DevPat {
     int w_split;
     int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)
     int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves (tile mode): flag + the two interleaved vectors in the workspace
+    int lr_inst, lr_work;            // LDS-resident variant: offsets (doubles) of the instance slab and the workspace slab in the dynamic LDS
     size_t inst_stride, work_stride; // in doubles
     size_t group_stride;             // workspace of one resident workgroup = (instances per workgroup of the handle) * work_stride
 };

@@ -35,7 +35,28 @@
 #include "device_types.hpp"
 #include "launch.hpp"
 
+// This file is compiled twice.  EICOS_LDSRES = 0 (kernels.o): the slabs of an instance live in HBM.  EICOS_LDSRES = 1
+// (kernels_ldsres.o, namespace eicos::ldsres): the LDS-RESIDENT variant for small patterns -- k_solve copies the
+// instance slab and the workspace slab into LDS, solves there and copies both back, so every "slab" pointer below is an
+// LDS pointer (address space 3, ds_read / ds_write) and a dependent step of the sparse programs costs an LDS round trip
+// instead of an L2 one.  The shared pattern tables stay global in both builds.
+#ifndef EICOS_LDSRES
+#define EICOS_LDSRES 0
+#endif
+
 namespace eicos {
+#if EICOS_LDSRES
+namespace ldsres {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EICOS_DATA __attribute__((address_space(3)))
+#else
+#define EICOS_DATA
+#endif
+typedef double EICOS_DATA *gdbl_p;        // (shadow the global-memory typedefs of device_types.hpp)
+typedef const double EICOS_DATA *gcdbl_p;
+#else
+#define EICOS_DATA EICOS_GLOBAL
+#endif
 
 // ---- constants of struct Settings (reference include/eicos.hpp:23-47) ----
 __device__ constexpr double GAMMA = 0.99, DELTASTAT = 7e-8;
@@ -51,7 +72,11 @@ constexpr int EX_NOT_CONVERGED = -87;
 // the 160 KB of LDS hold), 128 threads -> 4 (small patterns, up to eight workgroups per CU).  The AMDGPU
 // attributor propagates the kernel's budget to the non-inlined stage functions.
 // Lock-step pairs (KI = 2) run as ONE workgroup per CU (both sweep vectors in LDS): 512 threads = 2 waves per SIMD -> 256 VGPRs.
+#if EICOS_LDSRES
+template <int T, int KI = 1> constexpr int waves_per_eu() { return 2; } // LDS allows at most three small workgroups per CU
+#else
 template <int T, int KI = 1> constexpr int waves_per_eu() { return KI == 2 ? T / 256 : (T == 256 ? 3 : 4); }
+#endif
 
 constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values per reduction
 
@@ -112,20 +137,29 @@ template <class E> __device__ __forceinline__ E ld_u32_nt(const E EICOS_GLOBAL *
     return __builtin_nontemporal_load(reinterpret_cast<const E EICOS_GLOBAL *>(reinterpret_cast<const char EICOS_GLOBAL *>(base) + (unsigned)i * (unsigned)sizeof(E)));
 }
 template <class Ptr> __device__ __forceinline__ Ptr uni_ptr(Ptr p) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return (Ptr)(((unsigned long long)hi << 32) | lo);
+    if constexpr (sizeof(Ptr) == 4) return (Ptr)__builtin_amdgcn_readfirstlane((unsigned)p); // LDS pointer
+    else {
+        const unsigned long long a = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (Ptr)(((unsigned long long)hi << 32) | lo);
+    }
 }
+typedef double d2_t __attribute__((ext_vector_type(2)));
+#if EICOS_LDSRES // slab arrays are LDS arrays: plain ds_read
+__device__ __forceinline__ double ld_u32(const double EICOS_DATA *base, int i) { return base[i]; }
+__device__ __forceinline__ double ld_u32_nt(const double EICOS_DATA *base, int i) { return base[i]; }
+__device__ __forceinline__ d2_t ld_u32(const d2_t EICOS_DATA *base, int i) { return base[i]; }
+__device__ __forceinline__ d2_t ld_u32_nt(const d2_t EICOS_DATA *base, int i) { return base[i]; }
+#endif
 
 // ---- KI-interleaved arrays: element (i, k) of an array shared by the KI instances of a workgroup sits at i * KI + k, so the
 // KI values of one slot are ONE load / store of 8 KI bytes (KI = 2: 16 bytes per lane, the width the memory system likes best).
-typedef double d2_t __attribute__((ext_vector_type(2)));
 template <class P> struct vec2_of;
 template <> struct vec2_of<double *> { typedef d2_t *type; };
 template <> struct vec2_of<const double *> { typedef const d2_t *type; };
 #if defined(__HIP_DEVICE_COMPILE__)
-template <> struct vec2_of<gdbl_p> { typedef d2_t EICOS_GLOBAL *type; };
-template <> struct vec2_of<gcdbl_p> { typedef const d2_t EICOS_GLOBAL *type; };
+template <> struct vec2_of<gdbl_p> { typedef d2_t EICOS_DATA *type; };
+template <> struct vec2_of<gcdbl_p> { typedef const d2_t EICOS_DATA *type; };
 #endif
 template <int KI, class P> __device__ __forceinline__ void ldK(P base, int i, double (&o)[KI]) {
     if constexpr (KI == 1) o[0] = base[i];
@@ -140,7 +174,7 @@ template <int KI, bool NT> __device__ __forceinline__ void ldK_g(gcdbl_p base, i
     if constexpr (KI == 1) o[0] = NT ? ld_u32_nt(base, i) : ld_u32(base, i);
     else {
         static_assert(KI == 2, "KI");
-        const d2_t EICOS_GLOBAL *b2 = reinterpret_cast<const d2_t EICOS_GLOBAL *>(base);
+        const d2_t EICOS_DATA *b2 = reinterpret_cast<const d2_t EICOS_DATA *>(base);
         const d2_t v = NT ? ld_u32_nt(b2, i) : ld_u32(b2, i);
         o[0] = v.x; o[1] = v.y;
     }
@@ -840,8 +874,8 @@ typedef const int __attribute__((address_space(4))) *cint_p;
 typedef int i4_t __attribute__((ext_vector_type(4)));
 typedef const i4_t __attribute__((address_space(4))) *cint4_p;
 __device__ __forceinline__ cint_p as_const(gint_p p) { return (cint_p)(unsigned long long)p; }
-typedef const d4_t EICOS_GLOBAL *gcd4_p;
-typedef d4_t EICOS_GLOBAL *gd4_p;
+typedef const d4_t EICOS_DATA *gcd4_p;
+typedef d4_t EICOS_DATA *gd4_p;
 // the four doubles of lane `lane` of tile `t` (tile-internal order of device_types.hpp: two 16-byte loads)
 __device__ __forceinline__ d4_t tile_ld(gcdbl_p base, int t, int lane) { return *reinterpret_cast<gcd4_p>(base + (size_t)t * 256 + lane * 4); }
 
@@ -1656,7 +1690,7 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p Wg, int ki, 
     gdbl_p W = Wg + (size_t)ki * P.w_split;
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
     const int tid = threadIdx.x;
-    DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
+    DevInfo *ginfo = (DevInfo *)(I + P.i_info); // (C-style cast: in the LDS-resident build the slab pointer is an LDS pointer)
     DevInfo &wi = g_S.wi;
     {
         gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
@@ -1751,7 +1785,7 @@ __device__ __forceinline__ void instance_end(const DevPat &P, gdbl_p I, gdbl_p W
     if (threadIdx.x == 0) {
         DevInfo &wi = g_S.wi;
         wi.exitcode = g_S.fl[FL_FATAL] ? -7 : g_S.fl[FL_CODE];
-        *reinterpret_cast<DevInfo *>(I + P.i_info) = wi;
+        *(DevInfo *)(I + P.i_info) = wi;
         // phase timers (microseconds) into the last row of the trace buffer: factor, LDL solves, refinement
         // residuals, KKT post-processing, residual/statistics/scalings stage, forward part of the solves, [6] total
         gdbl_p tr = W + P.w_trace + (size_t)(TRACE_ROWS - 1) * TRACE_COLS;
@@ -1831,7 +1865,14 @@ template <int T, int NLDS, bool I16, int KI>
 __global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
     int ps, double *inst, double *work, int B, int *queue, const int *order, double warm, double dyn_delta, double dyn_eps) {
     const DevPat &P = c_pat[ps];
+#if EICOS_LDSRES
+    static_assert(KI == 1 && NLDS >= 1, "LDS-resident variant: single instances, sweep vector + tables in LDS");
+    gdbl_p Wg = (gdbl_p)(g_dyn + P.lr_work), Il = (gdbl_p)(g_dyn + P.lr_inst); // the slabs of the instance being solved
+    double *Wglob = work + (size_t)blockIdx.x * P.group_stride;
+    for (int q = threadIdx.x; q < (int)P.work_stride; q += T) Wg[q] = Wglob[q]; // (zero padding slots, cone state kept between solves)
+#else
     gdbl_p Wg = (gdbl_p)work + (size_t)blockIdx.x * P.group_stride;
+#endif
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
         int *dst = reinterpret_cast<int *>(g_dyn + P.lds_tab); // (doubles from the start of the dynamic LDS: behind the vectors)
         auto stage = [&](const PackedSlice EICOS_GLOBAL *src, int cnt, int at) {
@@ -1855,11 +1896,28 @@ __global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
         for (int k = 0; k < KI_MAX; k++) {
             const int i = min(g * KI + (k < KI ? k : 0), B - 1);
             const int id = order ? order[i] : i;
+#if EICOS_LDSRES
+            Ik[k] = Il;
+            if (k == 0) {
+                const double *Ig = inst + (size_t)id * P.inst_stride;
+                __syncthreads();
+                for (int q = threadIdx.x; q < (int)P.inst_stride; q += T) Il[q] = Ig[q];
+                __syncthreads();
+            }
+#else
             Ik[k] = (gdbl_p)inst + (size_t)id * P.inst_stride;
+#endif
             if (k < KI && g * KI + k < B) nvalid++;
         }
         solve_group<T, NLDS, I16, KI>(ps, Ik, nvalid, Wg, warm);
         __syncthreads();
+#if EICOS_LDSRES
+        { // results, persistent per-instance state and (for the debug readbacks) the workspace go back to HBM
+            double *Ig = inst + (size_t)(order ? order[g] : g) * P.inst_stride;
+            for (int q = threadIdx.x; q < (int)P.inst_stride; q += T) Ig[q] = Il[q];
+            for (int q = threadIdx.x; q < (int)P.work_stride; q += T) Wglob[q] = Wg[q];
+        }
+#endif
         if (threadIdx.x == 0) g_S.next = (int)gridDim.x + atomicAdd(queue, 1);
         __syncthreads();
         g = g_S.next;
@@ -1890,6 +1948,7 @@ __global__ __launch_bounds__(1024) void k_order(int ps, const double *inst, int 
 // (The KKT "AG" scatter of updateKKTAG :1990-2030 is implicit: the factor kernel reads the
 //  equilibrated A/G values in place through DevPat::Lsrc.)
 // ============================================================================================
+#if !EICOS_LDSRES // (updateData and the debug kernels work on the slabs in HBM: main build only)
 template <int T>
 __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, int count,
                                               const double *Gpr, const double *Apr, const double *cin,
@@ -2127,7 +2186,19 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
     if (threadIdx.x == 0) ok[0] = (st == ST_FACTOR) ? 1 : 0;
 }
 
+#endif // !EICOS_LDSRES
+
 // ---- launchers (called from api.cpp) ----
+#if EICOS_LDSRES
+template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
+    auto byT = [&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if (idx16) return nlds >= 2 ? f((const void *)k_solve<T, 2, true, 1>) : f((const void *)k_solve<T, 1, true, 1>);
+        return nlds >= 2 ? f((const void *)k_solve<T, 2, false, 1>) : f((const void *)k_solve<T, 1, false, 1>);
+    };
+    return byT(std::integral_constant<int, 128>{}); // (small patterns run 128 threads; 64 measured no faster)
+}
+#else
 template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
@@ -2147,6 +2218,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
 }
+#endif
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
                         int idx16, int ki, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
@@ -2166,6 +2238,7 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
 }
+#if !EICOS_LDSRES
 hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,
                          const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, hipStream_t st) {
     if (count <= 0) return hipSuccess;
@@ -2195,6 +2268,7 @@ hipError_t launch_debug_scalings(int ps, double *inst, double *work, int i, int 
     }
     return hipGetLastError();
 }
+#endif // !EICOS_LDSRES
 hipError_t solve_occupancy(int threads, int nlds, int idx16, int ki, size_t dyn_lds, int *blocks_per_cu) {
     return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, threads, dyn_lds);
@@ -2211,6 +2285,10 @@ hipError_t upload_pattern(int ps, const DevPat &P) {
     if (ps < 0 || ps >= MAX_PATTERNS) return hipErrorInvalidValue;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_pat), &P, sizeof(DevPat), (size_t)ps * sizeof(DevPat), hipMemcpyHostToDevice);
 }
+#if EICOS_LDSRES
+} // namespace ldsres
+#else
 int max_patterns() { return MAX_PATTERNS; }
+#endif
 
 } // namespace eicos

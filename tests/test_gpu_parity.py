@@ -158,6 +158,7 @@ def test_dense_front_socp():
                                  {"EICOS_TILES": "1"}, {"EICOS_TILES": "1", "EICOS_NLDS": "0"}, {"EICOS_TILES": "1", "EICOS_THREADS": "128", "EICOS_NLDS": "2"},
                                  {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"},
                                  {"EICOS_KI": "2", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_THREADS": "256", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
+                                 {"EICOS_LDSRES": "0"}, {"EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_TILES": "0"},
                                  {"EICOS_TILES": "0"}, {"EICOS_TILES": "2", "EICOS_NLDS": "0"}, {"EICOS_TILES": "2", "EICOS_THREADS": "128"}, {"EICOS_TILES": "2", "EICOS_THREADS": "512", "EICOS_IDX16": "0"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
@@ -180,6 +181,35 @@ def test_every_kernel_variant_matches_oracle(env, monkeypatch):
             if oc == 0:
                 assert abs(gi[i]["pcost"] - oi["pcost"]) <= PCOST_RTOL * max(1.0, abs(oi["pcost"]))
         g.close(); o.close()
+
+
+def test_lds_resident_variant_is_bit_identical_to_the_hbm_slab_kernel(monkeypatch):
+    # small patterns whose slabs fit LDS run the LDS-resident build of k_solve (same code, slab pointers in LDS): same
+    # arithmetic in the same order, so every output must be bit-identical to the kernel that works on the slabs in HBM;
+    # LP, SOC and an infeasible fixture + a perturbed batch with different iteration counts per instance
+    from eicos_amd.generate import perturbed_batch
+    cases = []
+    for name in ("lp_afiro", "issue98", "infeasible1", "update_data"):
+        pat, sets = load_fixture(name)
+        cases.append((name, pat, rep(sets[0], 3), 3))
+    pat, sets = load_fixture("lp_afiro")
+    d = perturbed_batch(pat, sets[0], 0, 40, seed=5)
+    cases.append(("lp_afiro/perturbed", pat, (d["Gpr"], d["Apr"], d["c"], d["h"], d["b"]), 40))
+    for name, pat, data, B in cases:
+        out = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("EICOS_LDSRES", flag)
+            g = eicos_amd.BatchSolver(pat, B)
+            res = g.dims()["lds_resident"]
+            assert res == 0 if flag == "0" else (res == 1 or not name.startswith("lp_afiro")), (name, g.dims())
+            g.update(*data); codes = g.solve().copy(); ia = g.info_arrays()
+            y, z, s_ = g.duals()
+            out.append((codes, g.solution().copy(), y.copy(), z.copy(), s_.copy(), ia["iter"].copy(), ia["pcost"].copy(), ia["n_ldlsolve"].copy()))
+            codes2 = g.solve().copy()  # second solve: persistent per-instance state went through the copy-out / copy-in
+            out[-1] += (codes2, g.solution().copy())
+            g.close()
+        for a_, b_ in zip(out[0], out[1]):
+            assert np.array_equal(a_, b_, equal_nan=True), name
 
 
 def test_lockstep_pairs_match_oracle_on_a_heterogeneous_batch(monkeypatch):

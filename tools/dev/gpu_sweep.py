@@ -20,7 +20,7 @@ ms = []
 for r in range(reps):
     codes = g.solve(); ms.append(g.last_solve_ms())
 ia = g.info_arrays(); dm = g.dims()
-tag = f"lib={os.path.basename(os.environ.get('EICOS_AMD_LIB','default'))} T={dm['threads_per_block']} lds={dm['lds_bytes']} resident={dm['resident_blocks']}"
+tag = f"lib={os.path.basename(os.environ.get('EICOS_AMD_LIB','default'))} T={dm['threads_per_block']} lds={dm['lds_bytes']} resident={dm['resident_blocks']} ldsres={dm.get('lds_resident')} path={dm.get('factor_path')}"
 print(f"{name} B={B} {tag}: ms={min(ms):.2f} (all {['%.1f'%m for m in ms]}) iters={ia['iter'].sum()} ok={(codes==0).sum()} -> {ia['iter'].sum()/min(ms)*1e3:.0f} iter/s  pcost0={ia['pcost'][0]:.10e}", flush=True)
 
 if B <= dm['resident_blocks']:

@@ -1,5 +1,16 @@
-export TMPDIR=/tmp
-for p in lp_afiro lp_adlittle lp_blend lp_bandm lp_beaconfd lp_agg; do
-python tools/dev/gpu_sweep.py $p 256 2 2>&1 | tail -3
-done > gpurun_out/r2_small.log 2>&1
-cat gpurun_out/r2_small.log
+#!/bin/bash
+# small Netlib patterns (config 3 shape: batch 256): factor paths x LDS residency
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out
+{
+for p in lp_afiro lp_adlittle lp_blend; do
+  for B in 256; do
+    python tools/dev/gpu_sweep.py $p $B 3
+    EICOS_TILES=0 python tools/dev/gpu_sweep.py $p $B 3
+    EICOS_TILES=0 EICOS_THREADS=64 python tools/dev/gpu_sweep.py $p $B 3
+    EICOS_TILES=1 python tools/dev/gpu_sweep.py $p $B 3
+    EICOS_TILES=1 EICOS_THREADS=256 python tools/dev/gpu_sweep.py $p $B 3
+  done
+done
+} > gpurun_out/small.log 2>&1
+grep -v "factor us per call" gpurun_out/small.log | tail -60
