@@ -278,7 +278,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.tile = S.tile; D.nb = TP.nb; D.nt = TP.nt; D.nblev = TP.nblev; D.tl_base = TP.n0;
     if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), inverse diagonal tiles both ways (DC, DR)
         D.w_LC = Wl.add((size_t)TP.nt * 256 + 8); D.w_LR = Wl.add((size_t)TP.nt * 256 + 8);
-        D.w_DC = Wl.add((size_t)TP.nb * 256); D.w_DR = Wl.add((size_t)TP.nb * 256);
+        D.w_DC = Wl.add((size_t)TP.nb * 256); D.w_DR = Wl.add((size_t)TP.nb * 256); D.w_DL = Wl.add((size_t)TP.nb * 256);
         D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
     }
     D.work_stride = Wl.size;
@@ -801,23 +801,14 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     if (h->sym.tile) { // tiles -> the scalar view (D per elimination position, U = L D per CSC entry of L)
         const Symbolic &S = h->sym;
         const TilePlan &TP = h->tiles;
-        std::vector<double> Dv((size_t)TP.N16), LR((size_t)TP.nt * 256 + 1), DR((size_t)TP.nb * 256);
+        std::vector<double> Dv((size_t)TP.N16), LR((size_t)TP.nt * 256 + 1);
         HIP_TRY(hipMemcpy(Dv.data(), h->d_work + P.w_D, Dv.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (TP.nt) HIP_TRY(hipMemcpy(LR.data(), h->d_work + P.w_LR, (size_t)TP.nt * 256 * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(DR.data(), h->d_work + P.w_DR, DR.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (Dout) for (int j = 0; j < S.N; j++) Dout[j] = Dv[TP.slot[j]];
         if (Uout) {
-            // the kernel keeps the INVERSE of every unit-lower diagonal tile; invert it back (16 x 16 forward substitution)
+            // the diagonal tiles themselves (strictly lower part, row-major) as the factorisation's triangular solves read them
             std::vector<double> Ld((size_t)TP.nb * 256, 0.0);
-            for (int J = 0; J < TP.nb; J++) {
-                const double *M = DR.data() + (size_t)J * 256; double *Lj = Ld.data() + (size_t)J * 256;
-                for (int r = 0; r < 16; r++)
-                    for (int c = r; c >= 0; c--) { // (L M)[r][c] = sum_{k=c..r} L[r][k] M[k][c] = delta_rc with M[c][c] = 1: columns right to left
-                        double sacc = (r == c) ? 1.0 : 0.0;
-                        for (int k = c + 1; k <= r; k++) sacc -= Lj[r * 16 + k] * M[tile_res(k, c)];
-                        Lj[r * 16 + c] = sacc;
-                    }
-            }
+            HIP_TRY(hipMemcpy(Ld.data(), h->d_work + P.w_DL, Ld.size() * sizeof(double), hipMemcpyDeviceToHost));
             std::vector<int> colj(S.nnzL);
             for (int j = 0; j < S.N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) colj[e] = j;
             std::vector<double> ub;

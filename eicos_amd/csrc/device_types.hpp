@@ -122,7 +122,7 @@ struct DevPat {
     gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op
     gint_p tl_ident;               // per block: 1 = the diagonal tile of L is the identity (skipped by the sweeps)
     gint_p tl_img_dst, tl_img_src, tl_psign; // K image scatter (slab offset -> image index); quasi-definite pivot sign per slot
-    int w_LC, w_LR, w_DC, w_DR;    // workspace: L tiles column- / row-major, inverse diagonal tiles column- / row-major
+    int w_LC, w_LR, w_DC, w_DR, w_DL;    // workspace: L tiles column- / row-major, inverse diagonal tiles column- / row-major
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets

@@ -189,6 +189,11 @@ template <int CTRL> __device__ __forceinline__ double dpp_shl_add(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
     return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
+// lane C of every 16-lane DPP row, broadcast to the whole row: ONE v_mov_b64_dpp row_newbcast:C (the only DPP control
+// the 64-bit data path of gfx90a+ has)
+template <int C> __device__ __forceinline__ double dpp_row_bcast(double v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xF, 0xF, false); // (every lane has a source: `old` is never used)
+}
 __device__ __forceinline__ double grp_reduce_to_lane0(double v, int lg) { // lg is wavefront-uniform
     if (lg == 0) return v; // one lane per row (most slices): one scalar branch instead of the six of the ladder
     if (lg >= 3) {
@@ -819,6 +824,9 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                     for (int k = 0; k < KI; k++) {
                         if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
                             const double sg = (e & DIAG_POS) ? 1. : -1.;
+#ifdef EICOS_TRACE_DYNREG
+                            if (sg * val[k] <= g_S.dyn_eps) printf("[dynreg scalar] blk %d j %d val %.6e sg %.0f\n", (int)blockIdx.x, j, val[k], sg);
+#endif
                             if (sg * val[k] <= g_S.dyn_eps) val[k] = sg * g_S.dyn_delta;
                         }
                         iv[k] = 1. / val[k];
@@ -861,7 +869,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
 // One WAVEFRONT per tile operation; levels of the block dependency graph are separated by workgroup barriers.
 //   LC[t] : unit-lower L tile t = (I, J), column-major ((r, c) at 16 c + r)  -- forward sweep + both MFMA operands
 //   LR[t] : the same tile row-major ((r, c) at 16 r + c)                      -- backward sweep
-//   DC[J] / DR[J] : inverse of the unit-lower diagonal tile L_JJ, column- / row-major; D, invD per slot
+//   DC[J] / DR[J] : inverse of the unit-lower diagonal tile L_JJ, column- / row-major (the sweeps); D, invD per slot
+//   DL[J] : the strictly lower part of L_JJ itself, plain row-major (the factorisation's triangular solves)
 // v_mfma_f64_16x16x4_f64 lane maps (checked on gfx950, tools/dev/mfma_f64_layout.hip): operand A: lane l holds
 // A[row l&15][k l>>4], operand B: B[k l>>4][col l&15], result: C[row (l>>4) + 4 reg][col l&15].  A column-major tile is
 // therefore read as four fully coalesced 512-byte loads (element s*64 + l for K-step s), for A and for B alike.
@@ -886,7 +895,7 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
     iter = uni(iter);
     constexpr int NW = T / 64;
     // (D, invD of the blocks start at slot tl_base: hybrid keeps the scalar part of the vectors in front)
-    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, D = W + P.w_D + P.tl_base, invD = W + P.w_invD + P.tl_base;
+    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, DL = W + P.w_DL, D = W + P.w_D + P.tl_base, invD = W + P.w_invD + P.tl_base;
     gcdbl_p Kt = W + P.w_Kimg;
     double *scr = g_dyn + P.tl_scratch + uni(wave) * TILE_SCR; // wave-private 16 x 17 tile in LDS
     const int nbk = P.nb, kq = lane >> 4, lc = lane & 15;
@@ -914,10 +923,8 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
 #pragma unroll
                 for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[st], b[st] * dd[st], acc, 0, 0, 0);
             }
-            if (tg >= nbk) { // off-diagonal target: park T in operand order in its own L slot (phase 2 reads it as an MFMA operand)
-                const int t = tg - nbk;
-#pragma unroll
-                for (int r = 0; r < 4; r++) LC[(size_t)t * 256 + tile_op(kq + 4 * r, lc)] = acc[r];
+            if (tg >= nbk) { // off-diagonal target: park T in its own L slot, result order = the accumulator as it stands
+                *reinterpret_cast<gd4_p>(LR + (size_t)(tg - nbk) * 256 + lane * 4) = acc;
                 continue;
             }
             // ---- diagonal target: dense LDL' of the 16 x 16 tile in LDS (lower triangle), then the inverse of L_JJ ----
@@ -928,6 +935,9 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
                 double dj = scr[j * 17 + j];
                 if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
                     const double sg = (double)P.tl_psign[P.tl_base + J * 16 + j]; // (per slot of the KKT-space vectors)
+#ifdef EICOS_TRACE_DYNREG
+                    if (sg * dj <= g_S.dyn_eps && lane == 0) printf("[dynreg tile] blk %d level %d J %d j %d slot %d dj %.6e sg %.0f iter %d\n", (int)blockIdx.x, v, J, j, P.tl_base + J * 16 + j, dj, sg, iter);
+#endif
                     if (sg * dj <= g_S.dyn_eps) { dj = sg * g_S.dyn_delta; if (lane == 0) scr[j * 17 + j] = dj; }
                 }
                 if (dj == 0. && lane == 0) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
@@ -953,19 +963,53 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
 #pragma unroll
                 for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + tile_op(r, lane)] = mcol[r]; DR[(size_t)J * 256 + tile_res(r, lane)] = mcol[r]; }
             }
+            { // L_JJ itself (strictly lower part, row-major: element e = 16 r + k) for the triangular solves of phase 2
+                d4_t lv;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const int e = lane * 4 + i, r = e >> 4, k = e & 15; lv[i] = (k < r) ? scr[r * 17 + k] : 0.; }
+                *reinterpret_cast<gd4_p>(DL + (size_t)J * 256 + lane * 4) = lv;
+            }
         }
         __syncthreads();
-        // ---- phase 2: L_IJ = T_IJ L_JJ^-T D_J^-1 for the off-diagonal tiles of the level's block columns ----
+        // ---- phase 2: L_IJ = T_IJ L_JJ^-T D_J^-1 for the off-diagonal tiles of the level's block columns, as a triangular
+        // solve X L_JJ' = T by substitution over the columns (backward stable like the scalar program's dot products; the
+        // product with the explicit inverse of L_JJ loses cond(L_JJ) digits, which flips delta-sized pivots of the last
+        // blocks).  Lane l holds X[(l >> 4) + 4 reg][l & 15]: column c of X reaches the other columns of its rows through a
+        // DPP row broadcast, the multiplier L_JJ[l & 15][c] is zero for c >= l & 15. ----
         const int f1 = c_fl[v + 1];
-        for (int q = c_fl[v] + uni(wave); q < f1; q += NW) {
+        struct Fin { d4_t x, l; double idc; } nx; // one tile's inputs: T, L_JJ (2 KB per wavefront, row-major), 1/D of column l & 15
+        auto load2 = [&](int q, Fin &o) {
             const int t = c_fin[q], J = c_tcol[t];
-            const d4_t a = tile_ld(LC, t, lane), b = tile_ld(DC, J, lane);
-            const double idc = invD[J * 16 + lc];
-            d4_t acc = {0., 0., 0., 0.};
+            o.x = tile_ld(LR, t, lane); o.l = tile_ld(DL, J, lane);
+            o.idc = invD[J * 16 + lc];
+        };
+        const int q0 = c_fl[v] + uni(wave);
+        if (q0 < f1) load2(q0, nx);
+        for (int q = q0; q < f1; q += NW) {
+            const int t = c_fin[q];
+            const Fin cu = nx;
+            load2(min(q + NW, f1 - 1), nx); // the next tile's inputs in flight behind this tile's substitution (unconditional, clamped)
+            d4_t acc = cu.x;
+            // every lane needs row l & 15 of L_JJ: through the wavefront's LDS tile (one global load of the tile per
+            // wavefront instead of four; a wavefront's LDS accesses execute in order)
 #pragma unroll
-            for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], b[st], acc, 0, 0, 0);
+            for (int i = 0; i < 4; i++) { const int e = lane * 4 + i; scr[(e >> 4) * 17 + (e & 15)] = cu.l[i]; }
+            double lrow[15];
+#pragma unroll
+            for (int c = 0; c < 15; c++) lrow[c] = scr[lc * 17 + c];
+            const double idc = cu.idc;
+            auto step = [&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = __builtin_fma(-dpp_row_bcast<c>(acc[r]), lrow[c], acc[r]);
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
             acc *= idc;
-            *reinterpret_cast<gd4_p>(LR + (size_t)t * 256 + lane * 4) = acc; // result order = the accumulator as it stands
+            *reinterpret_cast<gd4_p>(LR + (size_t)t * 256 + lane * 4) = acc; // result order = the accumulator layout
 #pragma unroll
             for (int r = 0; r < 4; r++) LC[(size_t)t * 256 + tile_op(kq + 4 * r, lc)] = acc[r];
         }

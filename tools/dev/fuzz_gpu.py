@@ -20,11 +20,11 @@ for case in range(ncase):
     p = int(rng.integers(0, max(1, n // 2)))
     l = int(rng.integers(0, 50 * scale))
     nc = int(rng.integers(0, 5 * scale))
-    q = [int(rng.choice([1, 2, 3, 4, 7, 12, 33, 40])) for _ in range(nc)]
+    q = [int(rng.choice([1, 2, 3, 4, 7, 12, 33, 40, 64])) for _ in range(nc)]
     if l + sum(q) == 0:
         l = 3
     dens = float(rng.choice([0.05, 0.15, 0.3, 0.6])) / scale
-    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16"):
+    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL"):
         os.environ.pop(k, None)
     var = {}
     if rng.random() < 0.7:
@@ -33,6 +33,15 @@ for case in range(ncase):
         var["EICOS_NLDS"] = str(rng.choice([0, 1, 2]))
     if rng.random() < 0.3:
         var["EICOS_IDX16"] = "0"
+    # round 2: factor path (unset = chosen by the symbolic analysis; 0 scalar, 1 dense tiles, 2 hybrid if the pattern has a
+    # narrow top), LDS-resident build off, dual right-hand sides off
+    r = rng.random()
+    if r < 0.6:
+        var["EICOS_TILES"] = str(rng.choice([0, 1, 2]))
+    if rng.random() < 0.3:
+        var["EICOS_LDSRES"] = "0"
+    if rng.random() < 0.3:
+        var["EICOS_DUAL"] = "0"
     os.environ.update(var)
     try:
         pat, base = random_socp_pattern(n, p, l, q, density=dens, seed=seed0 + case)
