@@ -172,6 +172,7 @@ class Job:
             "mean_iter": float(ia["iter"].mean()),
             "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
             "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
+            "factor_path": ("scalar", "tile", "hybrid")[dims.get("factor_path", 0)], "lds_resident": bool(dims.get("lds_resident", 0)),
             "update_kernel_ms": r["update_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
