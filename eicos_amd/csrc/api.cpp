@@ -42,6 +42,7 @@ struct eicos_batch {
     int order_min = 0;        // batches up to this size (one instance per CU) are solved in identity order, larger ones longest-first
     bool last_ordered = false; int last_kis = 1; // how the most recent solve was launched (eicos_debug_trace)
     size_t upd_lds = 0;       // > 0: updateData runs the entry-parallel kernel with this much dynamic LDS (values + maxima)
+    int upd_vals_lds = 1;     // 1: its working copy of the values is in LDS too; 0: streamed in place in the instance slab
     size_t dyn_lds1 = 0; int nlds1 = 0; // launch shape of the single-instance kernel on the same workspace (warm start)
     int *d_pattern = nullptr;
     int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
@@ -523,8 +524,15 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
     {   // entry-parallel updateData: needs the A / G values and the row / column maxima in LDS and <= 8 vector entries per thread
         const size_t need = ((size_t)S.nnzA + S.nnzG + S.n + S.p + S.m + 8) * sizeof(double);
+        const size_t need_max = ((size_t)S.n + S.p + S.m + 8) * sizeof(double); // the row / column maxima alone
         const bool small_vecs = S.n <= 8 * 512 && S.p <= 8 * 512 && S.m <= 16 * 512;
-        if (need <= 156 * 1024 && small_vecs && env_int("EICOS_UPDATE_LDS", 1)) { h->upd_lds = need; h->upd_grid = std::min(batch, prop.multiProcessorCount); }
+        const int mode = env_int("EICOS_UPDATE_LDS", 1); // 0: thread-per-column kernel, 2: force the streamed-values variant
+        if (need <= 156 * 1024 && small_vecs && mode == 1) { h->upd_lds = need; h->upd_vals_lds = 1; h->upd_grid = std::min(batch, prop.multiProcessorCount); }
+        else if (need_max <= 156 * 1024 && small_vecs && mode >= 1) { // values streamed in place, maxima in LDS: as many 512-thread workgroups per CU as fit (<= 4)
+            h->upd_lds = need_max; h->upd_vals_lds = 0;
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (need_max + 1024)));
+            h->upd_grid = std::min(batch, prop.multiProcessorCount * per_cu);
+        }
     }
     h->pattern_ints = pool.data.size();
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
@@ -626,7 +634,7 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
     if (!h->in_chunked_update) HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
-    HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->upd_lds, h->stream));
+    HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->upd_lds, h->upd_vals_lds, h->stream));
     if (!h->in_chunked_update) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
     return EICOS_OK;
 }

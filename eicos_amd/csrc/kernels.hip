@@ -276,6 +276,8 @@ struct V4 { double a, b, c, d; };
 template <int KI> struct VKI { double v[KI]; };
 struct IV1 { int i; double a; };
 struct IV2 { int i; double a, b; };
+struct IIV { int i, j; double a; };
+struct IIV3 { int i, j; double a, b, c; };
 template <int T, int U = 4, class L, class F>
 __device__ __forceinline__ void for_t_pre(int cnt, L &&ld, F &&fn) {
     for (int i0 = threadIdx.x; i0 < cnt; i0 += U * T) {
@@ -2089,14 +2091,17 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
 // atomic maxima on the bit patterns of |a| (non-negative doubles order like their bit patterns: exact), and HBM sees
 // each input once plus the outputs.  Same arithmetic in the same order per entry as k_update (rows, then columns;
 // cone rows share the SUM of their row maxima; |a| < 1e-6 -> 1): bit-identical results.
-// LDS: [ Av | Gv | xt (n) | at (p) | gt (m) ] doubles.
-template <int T>
+// LDS: [ xt (n) | at (p) | gt (m) | Av | Gv ] doubles.
+// LDSV = false (values too large for LDS, e.g. the dense-front config: 131 k entries): the same entry-parallel passes with
+// the working copy of the values IN PLACE in the instance slab (it is their destination anyway) and only the maxima in
+// LDS; every pass over the values then streams them from HBM with batched loads (for_t_pre), several workgroups per CU.
+template <int T, bool LDSV>
 __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int first, int count,
                                                   const double *Gpr, const double *Apr, const double *cin,
                                                   const double *hin, const double *bin) {
     const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, nnzA = P.nnzA, nnzG = P.nnzG;
-    double *sA = g_dyn, *sG = sA + nnzA, *xt = sG + nnzG, *at = xt + n, *gt = at + p;
+    double *xt = g_dyn, *at = xt + n, *gt = at + p;
     unsigned long long *xtb = reinterpret_cast<unsigned long long *>(xt), *atb = reinterpret_cast<unsigned long long *>(at), *gtb = reinterpret_cast<unsigned long long *>(gt);
     auto sq = [](double a) { return fabs(a) < 1e-6 ? 1. : sqrt(a); };
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
@@ -2105,8 +2110,10 @@ __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int firs
         gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
         DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
         const bool was_eq = ginfo->equilibrated != 0;
+        auto sA = [&] { if constexpr (LDSV) return gt + m; else return Av; }(); // working copy of the values: LDS, or in place
+        auto sG = [&] { if constexpr (LDSV) return gt + m + nnzA; else return Gv; }();
         __syncthreads();
-        // un-equilibrate what is kept, overwrite what is given (ref :2053-2074, :389-404) -> LDS copy of the values
+        // un-equilibrate what is kept, overwrite what is given (ref :2053-2074, :389-404) -> working copy of the values
         for_t_pre<T, 4>(nnzA, [&](int k) {
             if (Apr) return V3{Apr[(size_t)q * nnzA + k], 1., 1.};
             return was_eq ? V3{Av[k], ae[P.Air[k]], xe[P.Acol[k]]} : V3{Av[k], 1., 1.};
@@ -2131,8 +2138,10 @@ __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int firs
             FOR_T(i, m) gtb[i] = 0ull;
             __syncthreads();
             // column maxima over A and G, row maxima of A and of G: one pass over the entries
-            FOR_T(k, nnzA) { const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(sA[k])); atomicMax(&xtb[P.Acol[k]], b); atomicMax(&atb[P.Air[k]], b); }
-            FOR_T(k, nnzG) { const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(sG[k])); atomicMax(&xtb[P.Gcol[k]], b); atomicMax(&gtb[P.Gir[k]], b); }
+            for_t_pre<T, 8>(nnzA, [&](int k) { return IIV{P.Acol[k], P.Air[k], sA[k]}; }, [&](int k, const IIV &r) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(r.a)); atomicMax(&xtb[r.i], b); atomicMax(&atb[r.j], b); });
+            for_t_pre<T, 8>(nnzG, [&](int k) { return IIV{P.Gcol[k], P.Gir[k], sG[k]}; }, [&](int k, const IIV &r) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(r.a)); atomicMax(&xtb[r.i], b); atomicMax(&gtb[r.j], b); });
             __syncthreads();
             FOR_T(j, n) xt[j] = sq(xt[j]);
             FOR_T(r, p) at[r] = sq(at[r]);
@@ -2147,8 +2156,8 @@ __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int firs
             }
             __syncthreads();
             // rows first, then columns -- same division order as the reference (:353-356)
-            FOR_T(k, nnzA) sA[k] = (sA[k] / at[P.Air[k]]) / xt[P.Acol[k]];
-            FOR_T(k, nnzG) sG[k] = (sG[k] / gt[P.Gir[k]]) / xt[P.Gcol[k]];
+            for_t_pre<T, 8>(nnzA, [&](int k) { return IIV{P.Acol[k], P.Air[k], sA[k]}; }, [&](int k, const IIV &r) { sA[k] = (r.a / at[r.j]) / xt[r.i]; });
+            for_t_pre<T, 8>(nnzG, [&](int k) { return IIV{P.Gcol[k], P.Gir[k], sG[k]}; }, [&](int k, const IIV &r) { sG[k] = (r.a / gt[r.j]) / xt[r.i]; });
 #pragma unroll
             for (int u = 0; u < OWN; u++) { // (compile-time register indices: the accumulators must not go to scratch)
                 const int j = threadIdx.x + u * T;
@@ -2168,12 +2177,15 @@ __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int firs
         }
 #pragma unroll
         for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) { ge[i] = gacc[u]; hv[i] = hv[i] / gacc[u]; } }
-        FOR_T(k, nnzA) Av[k] = sA[k];
-        FOR_T(k, nnzG) Gv[k] = sG[k];
-        // sliced-ELL value copies for the products, straight from LDS; *_src is relative to Av (G values follow at i_Gv - i_Av)
+        if constexpr (LDSV) {
+            FOR_T(k, nnzA) Av[k] = sA[k];
+            FOR_T(k, nnzG) Gv[k] = sG[k];
+        } else __syncthreads(); // (in place: the gathers below read entries other threads scaled)
+        // sliced-ELL value copies for the products, straight from the working copy; *_src is relative to Av (G values follow at i_Gv - i_Av)
         const int grel = P.i_Gv - P.i_Av;
         auto ell_copy = [&](gdbl_p dst, gint_p src, int cnt) {
-            for_t_pre<T, 8>(cnt, [&](int k) { return src[k]; }, [&](int k, int e) { dst[k] = e < 0 ? 0. : (e < grel ? sA[e] : sG[e - grel]); });
+            if constexpr (LDSV) for_t_pre<T, 8>(cnt, [&](int k) { return src[k]; }, [&](int k, int e) { dst[k] = e < 0 ? 0. : (e < grel ? sA[e] : sG[e - grel]); });
+            else for_t_pre<T, 8>(cnt, [&](int k) { const int e = src[k]; return IV1{e, Av[max(e, 0)]}; }, [&](int k, const IV1 &r) { dst[k] = r.i < 0 ? 0. : r.a; });
         };
         ell_copy(cagv, P.cag_src, P.cag_slots + 1);
         ell_copy(rAv, P.rA_src, P.rA_slots + 1);
@@ -2284,12 +2296,16 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
 }
 #if !EICOS_LDSRES
 hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,
-                         const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, hipStream_t st) {
+                         const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, int vals_in_lds, hipStream_t st) {
     if (count <= 0) return hipSuccess;
-    if (lds_bytes > 0) { // values + maxima fit LDS: the entry-parallel kernel, 512 threads, one workgroup per CU at a time
+    if (lds_bytes > 0 && !vals_in_lds) { // entry-parallel, maxima in LDS, values streamed in place in the slab (several workgroups per CU)
+        static bool attr_set2 = false;
+        if (!attr_set2) { (void)hipFuncSetAttribute((const void *)k_update_lds<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr_set2 = true; }
+        hipLaunchKernelGGL((k_update_lds<512, false>), dim3(grid), dim3(512), lds_bytes, st, ps, inst, first, count, Gpr, Apr, c, h, b);
+    } else if (lds_bytes > 0) { // values + maxima fit LDS: the entry-parallel kernel, 512 threads, one workgroup per CU at a time
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_update_lds<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr_set = true; }
-        hipLaunchKernelGGL(k_update_lds<512>, dim3(grid), dim3(512), lds_bytes, st, ps, inst, first, count, Gpr, Apr, c, h, b);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_update_lds<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr_set = true; }
+        hipLaunchKernelGGL((k_update_lds<512, true>), dim3(grid), dim3(512), lds_bytes, st, ps, inst, first, count, Gpr, Apr, c, h, b);
     } else hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
     return hipGetLastError();
 }

@@ -308,6 +308,37 @@ def test_lpnetlib_perturbed_ill_posed_instances_match_oracle():
     g.close()
 
 
+@pytest.mark.parametrize("name", ["update_data", "issue98", "MPC02", "dense-front"])
+def test_the_three_update_kernels_agree_bit_for_bit(name, monkeypatch):
+    # updateData (equilibration, src/eicos.cpp:302-374,2053-2082) exists three times: thread-per-column (EICOS_UPDATE_LDS=0),
+    # entry-parallel with values and maxima in LDS (1, default when they fit), entry-parallel with the values streamed in
+    # place in the slab and only the maxima in LDS (2, default for patterns like the dense-front config).  Same arithmetic
+    # in the same order per entry -> the equilibrated matrices, the scaled vectors and therefore every solve output are
+    # bit-identical; second round: c, h only (A, G, b kept -> the un-equilibrate / re-equilibrate path)
+    if name == "dense-front":
+        pat, base = dense_front_pattern(n=150, k=4, d=40)
+        d = feasible_batch(pat, base, 0, 3)
+        data = (d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    else:
+        pat, sets = load_fixture(name)
+        data = rep(sets[0], 3)
+    outs = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("EICOS_UPDATE_LDS", mode)
+        g = eicos_amd.BatchSolver(pat, 3)
+        g.update(*data)
+        r, c, v1 = g.debug_kkt(2)
+        codes = g.solve().copy(); x1 = g.solution().copy(); it1 = g.info_arrays()["iter"].copy()
+        g.update(c=data[2] * 1.01, h=data[3] + 0.01 * np.abs(data[3]))
+        r, c, v2 = g.debug_kkt(1)
+        codes2 = g.solve().copy(); x2 = g.solution().copy()
+        outs.append((v1.copy(), codes, x1, it1, v2.copy(), codes2, x2))
+        g.close()
+    for o in outs[1:]:
+        for a_, b_ in zip(outs[0], o):
+            assert np.array_equal(a_, b_, equal_nan=True), name
+
+
 def test_update_keep_semantics_and_ranges():
     # NULL groups keep the previous data (reference updateData(double*...), src/eicos.cpp:2053-2082);
     # partial ranges only touch their instances.
