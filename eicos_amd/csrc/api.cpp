@@ -189,16 +189,57 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     std::vector<int> zexp0(S.m);
     { for (int i = 0; i < S.l; i++) zexp0[i] = i; for (int c = 0; c < S.nc; c++) for (int k = 0; k < S.q[c]; k++) zexp0[S.cone_off[c] + k] = S.cone_off[c] + k + 2 * c; }
     const int gv_rel = D.i_Gv - D.i_Av;
+    // ---- G in dense 16 x 16 tiles (dense-front patterns on the tile path: the products are bandwidth-bound) ----
+    // Row block = 16 consecutive rows of G; its tiles = the sorted union of the columns of those rows, cut into groups of 16
+    // (so a tile's columns need not be consecutive).  One pass over the tiles yields G x (per row block, in registers) and the
+    // partial column sums of G' z (per tile, reduced per column in a second, fixed-order pass): G is streamed ONCE per
+    // evaluation instead of once in column form and once in row form, with no index bytes.  Taken when the tiles are at
+    // least half full; the sliced-ELL plans of the products then hold A only.
+    struct GTiles { int on = 0, nrb = 0, nt = 0, W = 0; std::vector<int> rbptr, col, src, cidx; } GT;
+    if (S.tile == 1 && S.nnzG > 0 && env_int("EICOS_GTILES", 1)) {
+        const int nrb = (S.m + 15) / 16;
+        GT.nrb = nrb; GT.rbptr.assign(nrb + 1, 0);
+        std::vector<std::vector<int>> rbcols(nrb);
+        for (int rb = 0; rb < nrb; rb++) {
+            std::vector<int> &cs = rbcols[rb];
+            for (int i = rb * 16; i < std::min(S.m, rb * 16 + 16); i++) for (int e = S.Gt_ptr[i]; e < S.Gt_ptr[i + 1]; e++) cs.push_back(S.Gt_col[e]);
+            std::sort(cs.begin(), cs.end()); cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+            GT.rbptr[rb + 1] = GT.rbptr[rb] + ((int)cs.size() + 15) / 16;
+        }
+        GT.nt = GT.rbptr[nrb];
+        if (GT.nt > 0 && (double)S.nnzG >= 0.5 * 256.0 * GT.nt) {
+            GT.on = 1;
+            GT.col.assign((size_t)GT.nt * 16, -1); GT.src.assign((size_t)GT.nt * 256 + 1, -1);
+            std::vector<int> ccount(S.n, 0);
+            for (int rb = 0; rb < nrb; rb++) {
+                const std::vector<int> &cs = rbcols[rb];
+                for (size_t q = 0; q < cs.size(); q++) { GT.col[(size_t)GT.rbptr[rb] * 16 + q] = cs[q]; ccount[cs[q]]++; }
+                for (int i = rb * 16; i < std::min(S.m, rb * 16 + 16); i++)
+                    for (int e = S.Gt_ptr[i]; e < S.Gt_ptr[i + 1]; e++) {
+                        const int q = (int)(std::lower_bound(cs.begin(), cs.end(), S.Gt_col[e]) - cs.begin());
+                        GT.src[(size_t)(GT.rbptr[rb] + q / 16) * 256 + tile_op(i - rb * 16, q % 16)] = gv_rel + S.Gt_pos[e];
+                    }
+            }
+            GT.W = 8; // contributions per column the kernel adds (fixed width, padded)
+            if (*std::max_element(ccount.begin(), ccount.end()) > GT.W) GT.on = 0; // (a column met by more than 8 tiles: keep the ELL products)
+            GT.cidx.assign((size_t)S.n * GT.W, -1); // padding
+            std::fill(ccount.begin(), ccount.end(), 0);
+            if (GT.on) for (int t = 0; t < GT.nt; t++) for (int k = 0; k < 16; k++) { const int j = GT.col[(size_t)t * 16 + k]; if (j >= 0) GT.cidx[(size_t)j * GT.W + ccount[j]++] = t * 16 + k; }
+        }
+    }
+    const std::vector<int> Gt_ptr_used = GT.on ? std::vector<int>(S.m + 1, 0) : S.Gt_ptr; // (rows without entries: the epilogue still runs)
     for (int j = 0; j < S.n; j++) {
         for (int k = P.Ajc[j]; k < P.Ajc[j + 1]; k++) { cag_val.push_back(k); cag_k.push_back(S.n + P.Air[k]); cag_yz.push_back(P.Air[k]); }
-        for (int k = P.Gjc[j]; k < P.Gjc[j + 1]; k++) { cag_val.push_back(gv_rel + k); cag_k.push_back(S.n + S.p + zexp0[P.Gir[k]]); cag_yz.push_back(-1 - P.Gir[k]); }
+        if (!GT.on) for (int k = P.Gjc[j]; k < P.Gjc[j + 1]; k++) { cag_val.push_back(gv_rel + k); cag_k.push_back(S.n + S.p + zexp0[P.Gir[k]]); cag_yz.push_back(-1 - P.Gir[k]); }
         cag_ptr[j + 1] = (int)cag_val.size();
     }
     EllPlan pcag = build_ell_plan(cag_ptr, S.n, h->threads), prA = build_ell_plan(S.At_ptr, S.p, h->threads),
-            prG = build_ell_plan(S.Gt_ptr, S.m, h->threads);
+            prG = build_ell_plan(Gt_ptr_used, S.m, h->threads);
     D.cag_ns = (int)pcag.sl.size(); D.rA_ns = (int)prA.sl.size(); D.rG_ns = (int)prG.sl.size();
     D.cag_slots = pcag.slots; D.rA_slots = prA.slots; D.rG_slots = prG.slots;
     D.i_cag = L.add((size_t)pcag.slots + 8); D.i_rA = L.add((size_t)prA.slots + 8); D.i_rG = L.add((size_t)prG.slots + 8);
+    D.gt_on = GT.on; D.gt_nrb = GT.nrb; D.gt_nt = GT.nt; D.gt_W = GT.W;
+    D.i_Gt = GT.on ? (int)L.add((size_t)GT.nt * 256 + 8) : 0;
     D.i_c = L.add(S.n); D.i_h = L.add(S.m); D.i_b = L.add(S.p);
     D.i_xe = L.add(S.n); D.i_ae = L.add(S.p); D.i_ge = L.add(S.m);
     D.i_Vv = L.add(S.nV); D.i_cst = L.add(4);
@@ -229,6 +270,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
+    if (GT.on) { // G tile products: partial column sums per tile, G'z per column, G x per row; two right-hand sides
+        D.w_gpart = Wl.add((size_t)GT.nt * 16 * 2); D.w_gx = Wl.add((size_t)S.n * 2); D.w_gz = Wl.add((size_t)S.m * 2);
+    } else D.w_gpart = D.w_gx = D.w_gz = 0;
     // ---- from here on: arrays shared KI-interleaved by the instances of a lock-step workgroup (DevPat::w_split) ----
     D.w_split = (int)Wl.size;
     D.w_xk = Wl.add((size_t)NV + 16); D.w_ek = Wl.add((size_t)NV + 16); D.w_dxr = Wl.add(NV);
@@ -361,6 +405,12 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     put(D.cag_idx_k, cag_idx_k); put(D.cag_idx_yz, cag_idx_yz); put(D.cag_src, cag_src);
     put(D.rA_idx, rA_idx); put(D.rA_src, rA_src); put(D.rG_idx, rG_idx); put(D.rG_src, rG_src);
     put(D.rA_idx_k, rA_idx_k); put(D.rG_idx_k, rG_idx_k);
+    {   // G tiles: columns of a tile as variable index and as elimination-order slot, slot of every row's z entry
+        std::vector<int> gt_colk(GT.col.size()), gt_zslot((size_t)GT.nrb * 16, NV);
+        for (size_t q = 0; q < GT.col.size(); q++) gt_colk[q] = GT.col[q] < 0 ? NV : posK(GT.col[q]);
+        if (GT.on) for (int i = 0; i < S.m; i++) gt_zslot[i] = posK(S.n + S.p + zexp0[i]);
+        put(D.gt_rbptr, GT.rbptr); put(D.gt_col, GT.col); put(D.gt_colk, gt_colk); put(D.gt_zslot, gt_zslot); put(D.gt_cidx, GT.cidx); put(D.gt_src, GT.src);
+    }
     put(D.ipx, ipx); put(D.ipy, ipy); put(D.ipz, ipz); put(D.ipv, ipv); put(D.ipu, ipu);
     // quasi-definite sign of pivot `pos` (elimination position): + for the x block and the u expansion of every cone
     // (ref setupKKT :1734-1890), - elsewhere; only used by the dynamic-regularisation extension
@@ -515,7 +565,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
             if (cost < best - 1e-12) { best = cost; best_r = r; }
         }
-        bpc = best_r;
+        const int forced = env_int("EICOS_FORCE_BLOCKS_PER_CU", 0); // experiments: override the estimate (within what fits)
+        bpc = forced > 0 ? std::min(forced, bpc) : best_r;
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
     const int resident = prop.multiProcessorCount * bpc;

@@ -136,6 +136,11 @@ struct DevPat {
     int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)
     int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves (tile mode): flag + the two interleaved vectors in the workspace
     int lr_inst, lr_work;            // LDS-resident variant: offsets (doubles) of the instance slab and the workspace slab in the dynamic LDS
+    // G in dense 16 x 16 tiles (api.cpp): gt_nrb row blocks of 16 rows, tiles [gt_rbptr[rb], gt_rbptr[rb+1]) of row block rb,
+    // 16 columns per tile (gt_col: variable index or -1, gt_colk: elimination-order slot), gt_zslot: slot of z_i per row,
+    // gt_cidx: per column gt_W indices into the partial sums, gt_src: value source of every tile element (updateData)
+    int gt_on, gt_nrb, gt_nt, gt_W, i_Gt, w_gpart, w_gx, w_gz;
+    gint_p gt_rbptr, gt_col, gt_colk, gt_zslot, gt_cidx, gt_src;
     size_t inst_stride, work_stride; // in doubles
     size_t group_stride;             // workspace of one resident workgroup = (instances per workgroup of the handle) * work_stride
 };

@@ -1116,6 +1116,91 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
     sweep(P.tl_bops, P.tl_bptr, LR, DR, true);  // backward: block columns, levels down
 }
 
+// ---------------- G in dense tiles: G x and G' z in ONE pass over the values (DevPat::gt_on, host: api.cpp) ----------------
+// One wavefront per row block of 16 rows: lane l = 16 kq + r holds G[r][4 reg + kq] of the current tile (tile-internal
+// operand order, two 16-byte loads), gathers the vector entries of its four columns and the z entry of its row, and
+//   * accumulates row r of G x over the tiles of the row block (folded over kq at the end: two cross-lane adds),
+//   * forms G[r][c] z_r and sums it over the 16 rows of the tile inside the DPP row (column c's partial sum, one per tile).
+// A second pass adds the partial sums of every column in a fixed order (gt_cidx): deterministic, no atomics.
+// NR right-hand sides share one load of the tile.  getx(column entry of gt_col / gt_colk, k), getz(row, k): the vectors.
+// Outputs: gz[i * NR + k] = (G x)_i, gx[j * NR + k] = (G' z)_j.  Ends with a barrier.
+template <int T, int NR, class GetX, class GetZ>
+__device__ __forceinline__ void g_tile_products(const DevPat &P, gcdbl_p Gt, gint_p colidx, GetX &&getx, GetZ &&getz, gdbl_p gpart, gdbl_p gx, gdbl_p gz) {
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, r = lane & 15;
+    cint_p rbptr = as_const(P.gt_rbptr);
+    auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
+    // every wavefront owns a contiguous run of row blocks = a contiguous run of tiles: one flat loop with the loads of the
+    // next GT_PF tiles in flight (across row-block boundaries; clamped, unconditional)
+    constexpr int GT_PF = 4;
+    const int rb0 = (int)((long long)wave * P.gt_nrb / NW), rb1 = (int)((long long)(wave + 1) * P.gt_nrb / NW);
+    const int tb = rbptr[rb0], te = rbptr[rb1];
+    d4_t qg[GT_PF]; int qc[GT_PF][4];
+    auto load = [&](int t, d4_t &g, int (&c)[4]) {
+        g = tile_ld(Gt, t, lane);
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] = colidx[t * 16 + 4 * q + kq];
+    };
+    if (tb < te) {
+#pragma unroll
+        for (int d = 0; d < GT_PF; d++) load(min(tb + d, te - 1), qg[d], qc[d]);
+    }
+    int rb = rb0, tend = rb0 < rb1 ? rbptr[rb0 + 1] : 0;
+    double zr[NR], racc[NR];
+    auto open_rb = [&] { // z entries of the row block's 16 rows
+#pragma unroll
+        for (int k = 0; k < NR; k++) { zr[k] = (rb < rb1 && rb * 16 + r < P.m) ? getz(rb * 16 + r, k) : 0.; racc[k] = 0.; }
+    };
+    auto close_rb = [&] { // (G x) of the row block: fold the four column groups, one store per row
+#pragma unroll
+        for (int k = 0; k < NR; k++) { const double v = fold(racc[k]); if (lane < 16 && rb * 16 + r < P.m) gz[(size_t)(rb * 16 + r) * NR + k] = v; }
+    };
+    open_rb();
+    for (int t0 = tb; t0 < te; t0 += GT_PF) {
+#pragma unroll
+        for (int d = 0; d < GT_PF; d++) {
+            const int t = t0 + d;
+            if (t >= te) break;
+            while (t == tend) { close_rb(); rb++; tend = rbptr[rb + 1]; open_rb(); } // (row blocks without tiles write zeros)
+            const d4_t g = qg[d];
+            int c[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] = qc[d][q];
+            load(min(t + GT_PF, te - 1), qg[d], qc[d]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    racc[k] = madd(racc[k], g[q], getx(c[q], k));
+                    const double cs = grp_reduce_to_lane0(g[q] * zr[k], 4); // over the 16 rows of the tile: lane r = 0 of the DPP row
+                    if (r == 0) gpart[(size_t)(t * 16 + 4 * q + kq) * NR + k] = cs;
+                }
+            }
+        }
+    }
+    for (; rb < rb1; ) { close_rb(); rb++; if (rb < rb1) open_rb(); } // the last row block (and trailing ones without tiles)
+    __syncthreads();
+    typedef const i4_t EICOS_GLOBAL *gi4_p;
+    FOR_T(j, P.n) { // eight contributions per column (host pads gt_cidx with -1): all loads in flight, fixed order of the adds
+        const i4_t e0 = *reinterpret_cast<gi4_p>(P.gt_cidx + (size_t)j * 8), e1 = *reinterpret_cast<gi4_p>(P.gt_cidx + (size_t)j * 8 + 4);
+        double v[8][NR];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int e = q < 4 ? e0[q] : e1[q - 4]; // (-1: padding -- the load is unconditional, the value is dropped)
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const double w = gpart[(size_t)max(e, 0) * NR + k]; v[q][k] = e < 0 ? 0. : w; }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            double a = 0.;
+#pragma unroll
+            for (int q = 0; q < 8; q++) a += v[q][k];
+            gx[(size_t)j * NR + k] = a;
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
 // One instance (state in g_S; slab I, workspace W = Wg + ki * w_split); the factor's K stream Kt is KI-interleaved.
 template <int T, int NLDS, bool I16, int KI>
@@ -1137,16 +1222,20 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int
     auto tab_cag = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_cag); else return P.cag_sl; }();
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rA); else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return LDS_TABLE(P.lm_rG); else return P.rG_sl; }();
-    struct Pre2 { double a, b; };
-    struct Pre3 { double a, b, c; };
-    ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_yz, P.cag_yz16, P.cag_d16, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j]}; },
+    struct Pre2 { double a, b, g; };
+    struct Pre3 { double a, b, c, g; };
+    const bool gt = P.gt_on != 0; // G in tiles: one pass gives G x (gzv) and G' z (gxv); the ELL plans below then hold A only
+    gdbl_p gxv = W + P.w_gx, gzv = W + P.w_gz;
+    if (gt) g_tile_products<T, 1>(P, I + P.i_Gt, P.gt_col, [&](int c, int) { return c < 0 ? 0. : wx[c]; }, [&](int i, int) { return wz[i]; },
+                                  W + P.w_gpart, gxv, gzv);
+    ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_yz, P.cag_yz16, P.cag_d16, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j], gt ? gxv[j] : 0.}; },
                 [&](int j, double s, const Pre2 &pr) { // -G'z - A'y: (y,z) contiguous
-        const double hr = -s, c_ = pr.a, xj = pr.b;
+        const double hr = -(s + pr.g), c_ = pr.a, xj = pr.b;
         const double r = hr - tau * c_;
         rx[j] = r;
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
-    ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx, P.rA_16, P.rA_d16, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r]}; },
+    ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx, P.rA_16, P.rA_d16, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r], 0.}; },
                 [&](int r, double s, const Pre2 &pr) {
         const double b_ = pr.a, yr = pr.b;
         const double rr = s - tau * b_;
@@ -1155,10 +1244,10 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
     double q6[6] = {0, 0, 0, 0, 0, 0}; // hresz2 rz2 hz nz2 ns2 gap
-    ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx, P.rG_16, P.rG_d16, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i]}; },
+    ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx, P.rG_16, P.rG_d16, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i], gt ? gzv[i] : 0.}; },
                 [&](int i, double s, const Pre3 &pr) {
         const double si = pr.a, zi = pr.b, h_ = pr.c;
-        const double hr = si + s, r = hr - tau * h_;
+        const double hr = si + (s + pr.g), r = hr - tau * h_;
         rz[i] = r;
         q6[0] += hr * hr; q6[1] += r * r; q6[2] += h_ * zi; q6[3] += zi * zi; q6[4] += si * si; q6[5] += si * zi;
     });
@@ -1487,27 +1576,31 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         double nex[KI], ney[KI], nez[KI];
 #pragma unroll
         for (int k = 0; k < KI; k++) nex[k] = ney[k] = nez[k] = 0.;
-        struct PreK { double b, w; int o, sg; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation
+        struct PreK { double b, w; int o, sg; double g; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation, G-tile term
+        const bool gt = P.gt_on != 0; // G in tiles: one pass gives G dx and G' dz for all KI right-hand sides
+        gdbl_p gxv = Wg + P.w_gx, gzv = Wg + P.w_gz;
+        if (gt) g_tile_products<T, KI>(P, I0 + P.i_Gt, P.gt_colk, [&](int c, int k) { return X[c * KI + k]; },
+                                       [&](int i, int k) { return X[P.gt_zslot[i] * KI + k]; }, Wg + P.w_gpart, gxv, gzv);
         ell_dots_k<T, I16, KI, DUAL>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
-                    [&](int k, int j) { return PreK{ld_u32(bx[k], j), 0., ld_u32(P.ipx, j), 0}; },
+                    [&](int k, int j) { return PreK{ld_u32(bx[k], j), 0., ld_u32(P.ipx, j), 0, gt ? gxv[j * KI + k] : 0.}; },
                     [&](int k, int j, double s, const PreK &pr) {
             const int o = pr.o;
-            const double e = pr.b - s - DELTASTAT * X[o * KI + k]; // ex = bx - G'dz - A'dy - delta dx
+            const double e = pr.b - (s + pr.g) - DELTASTAT * X[o * KI + k]; // ex = bx - G'dz - A'dy - delta dx
             E[o * KI + k] = e; nex[k] = fmax(nex[k], fabs(e));
         });
         ell_dots_k<T, I16, KI, DUAL>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
-                    [&](int k, int r) { return PreK{ld_u32(by[k], r), 0., ld_u32(P.ipy, r), 0}; },
+                    [&](int k, int r) { return PreK{ld_u32(by[k], r), 0., ld_u32(P.ipy, r), 0, 0.}; },
                     [&](int k, int r, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - s + DELTASTAT * X[o * KI + k]; // ey = by - A dx + delta dy
             E[o * KI + k] = e; ney[k] = fmax(ney[k], fabs(e));
         });
         ell_dots_k<T, I16, KI, DUAL>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
-                    [&](int k, int i) { return PreK{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i)}; },
+                    [&](int k, int i) { return PreK{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i), gt ? gzv[i * KI + k] : 0.}; },
                     [&](int k, int i, double s, const PreK &pr) {
             const int o = pr.o;
             const double xo = X[o * KI + k];
-            double v = pr.b - s + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
+            double v = pr.b - (s + pr.g) + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
             if (i < l) { v += init ? xo : pr.w * xo; nez[k] = fmax(nez[k], fabs(v)); } // ... + V dz (LP part)
             E[o * KI + k] = v;
         });
@@ -2089,6 +2182,7 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
         ell_copy(cagv, P.cag_src, P.cag_slots + 1);
         ell_copy(rAv, P.rA_src, P.rA_slots + 1);
         ell_copy(rGv, P.rG_src, P.rG_slots + 1);
+        if (P.gt_on) ell_copy(I + P.i_Gt, P.gt_src, P.gt_nt * 256); // G as dense tiles (tile-internal operand order)
         // static-regularisation constants read by the factor program
         if (threadIdx.x == 0) {
             gdbl_p cst = I + P.i_cst;
@@ -2204,6 +2298,7 @@ __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int firs
         ell_copy(cagv, P.cag_src, P.cag_slots + 1);
         ell_copy(rAv, P.rA_src, P.rA_slots + 1);
         ell_copy(rGv, P.rG_src, P.rG_slots + 1);
+        if (P.gt_on) ell_copy(I + P.i_Gt, P.gt_src, P.gt_nt * 256); // G as dense tiles (tile-internal operand order)
         if (threadIdx.x == 0) { // static-regularisation constants read by the factor program
             gdbl_p cst = I + P.i_cst;
             cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 1.; // [3]: diagonal of the padding nodes (tile mode)
