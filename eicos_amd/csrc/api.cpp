@@ -207,7 +207,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             GT.rbptr[rb + 1] = GT.rbptr[rb] + ((int)cs.size() + 15) / 16;
         }
         GT.nt = GT.rbptr[nrb];
-        if (GT.nt > 0 && (double)S.nnzG >= 0.5 * 256.0 * GT.nt) {
+        if (GT.nt > 0 && ((double)S.nnzG >= 0.5 * 256.0 * GT.nt || env_int("EICOS_GTILES", 1) == 2)) { // (2: tests force it on sparse G)
             GT.on = 1;
             GT.col.assign((size_t)GT.nt * 16, -1); GT.src.assign((size_t)GT.nt * 256 + 1, -1);
             std::vector<int> ccount(S.n, 0);
@@ -321,9 +321,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.w_Kt = Wl.add((tile1 ? (size_t)(TP.nb + TP.nt) * 256 : planX.target.size()) + 8);
     D.w_Kimg = tile1 ? D.w_Kt : (tile ? Wl.add((size_t)(TP.nb + TP.nt) * 256 + 8) : 0); // hybrid: the top block's image beside the scalar stream
     D.tile = S.tile; D.nb = TP.nb; D.nt = TP.nt; D.nblev = TP.nblev; D.tl_base = TP.n0;
-    if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), inverse diagonal tiles both ways (DC, DR)
+    if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), the strictly lower part of the diagonal tiles (DL)
         D.w_LC = Wl.add((size_t)TP.nt * 256 + 8); D.w_LR = Wl.add((size_t)TP.nt * 256 + 8);
-        D.w_DC = Wl.add((size_t)TP.nb * 256); D.w_DR = Wl.add((size_t)TP.nb * 256); D.w_DL = Wl.add((size_t)TP.nb * 256);
+        D.w_DL = Wl.add((size_t)TP.nb * 256);
         D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
     }
     D.work_stride = Wl.size;

@@ -122,7 +122,7 @@ struct DevPat {
     gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op
     gint_p tl_ident;               // per block: 1 = the diagonal tile of L is the identity (skipped by the sweeps)
     gint_p tl_img_dst, tl_img_src, tl_psign; // K image scatter (slab offset -> image index); quasi-definite pivot sign per slot
-    int w_LC, w_LR, w_DC, w_DR, w_DL;    // workspace: L tiles column- / row-major, inverse diagonal tiles column- / row-major
+    int w_LC, w_LR, w_DL;                // workspace: L tiles column- / row-major, strictly lower part of the diagonal tiles (row-major)
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets
@@ -147,9 +147,9 @@ struct DevPat {
 
 // Tile-internal element order (tile mode): a 16 x 16 tile is stored so that lane l of a wavefront owns the four
 // consecutive doubles 4 l .. 4 l + 3 (two 16-byte loads per lane, 2 KB contiguous per wavefront):
-//   operand order (LC, DC): element (row r, column k) at tile_op(r, k)  -- lane (k&3)*16 + r holds K-step k>>2: exactly what
+//   operand order (LC): element (row r, column k) at tile_op(r, k)  -- lane (k&3)*16 + r holds K-step k>>2: exactly what
 //     lane l of v_mfma_f64_16x16x4_f64 needs as A[r = l&15][4 s + (l>>4)] (and, for the transposed factor, as B);
-//   result order (LR, DR, the K image): element (r, c) at tile_res(r, c) = tile_op(c, r) -- lane (r&3)*16 + c, register r>>2:
+//   result order (LR, the K image): element (r, c) at tile_res(r, c) = tile_op(c, r) -- lane (r&3)*16 + c, register r>>2:
 //     exactly the MFMA result layout C[(l>>4) + 4 reg][l&15], so an accumulator tile is stored with one 32-byte store per lane.
 constexpr int tile_op(int r, int k) { return (((k & 3) * 16 + r) << 2) + (k >> 2); }
 constexpr int tile_res(int r, int c) { return (((r & 3) * 16 + c) << 2) + (r >> 2); }

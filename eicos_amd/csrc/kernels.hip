@@ -208,6 +208,10 @@ template <int CTRL> __device__ __forceinline__ double dpp_shl_add(double v) {
 template <int C> __device__ __forceinline__ double dpp_row_bcast(double v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xF, 0xF, false); // (every lane has a source: `old` is never used)
 }
+// compile-time loop C = BEGIN, BEGIN + STEP, ... (exclusive END): the DPP controls above are immediates
+template <int C, int END, int STEP, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr ((STEP > 0 && C < END) || (STEP < 0 && C > END)) { f(std::integral_constant<int, C>{}); static_for<C + STEP, END, STEP>(f); }
+}
 __device__ __forceinline__ double grp_reduce_to_lane0(double v, int lg) { // lg is wavefront-uniform
     if (lg == 0) return v; // one lane per row (most slices): one scalar branch instead of the six of the ladder
     if (lg >= 3) {
@@ -885,8 +889,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
 // One WAVEFRONT per tile operation; levels of the block dependency graph are separated by workgroup barriers.
 //   LC[t] : unit-lower L tile t = (I, J), column-major ((r, c) at 16 c + r)  -- forward sweep + both MFMA operands
 //   LR[t] : the same tile row-major ((r, c) at 16 r + c)                      -- backward sweep
-//   DC[J] / DR[J] : inverse of the unit-lower diagonal tile L_JJ, column- / row-major (the sweeps); D, invD per slot
-//   DL[J] : the strictly lower part of L_JJ itself, plain row-major (the factorisation's triangular solves)
+//   DL[J] : the strictly lower part of the unit-lower diagonal tile L_JJ, plain row-major; D, invD per slot.  No inverse of a
+//           diagonal tile is ever formed: the factorisation (phase 2) and both sweeps solve with L_JJ by substitution.
 // v_mfma_f64_16x16x4_f64 lane maps (checked on gfx950, tools/dev/mfma_f64_layout.hip): operand A: lane l holds
 // A[row l&15][k l>>4], operand B: B[k l>>4][col l&15], result: C[row (l>>4) + 4 reg][col l&15].  A column-major tile is
 // therefore read as four fully coalesced 512-byte loads (element s*64 + l for K-step s), for A and for B alike.
@@ -911,7 +915,7 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
     iter = uni(iter);
     constexpr int NW = T / 64;
     // (D, invD of the blocks start at slot tl_base: hybrid keeps the scalar part of the vectors in front)
-    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, DL = W + P.w_DL, D = W + P.w_D + P.tl_base, invD = W + P.w_invD + P.tl_base;
+    gdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DL = W + P.w_DL, D = W + P.w_D + P.tl_base, invD = W + P.w_invD + P.tl_base;
     gcdbl_p Kt = W + P.w_Kimg;
     double *scr = g_dyn + P.tl_scratch + uni(wave) * TILE_SCR; // wave-private 16 x 17 tile in LDS
     const int nbk = P.nb, kq = lane >> 4, lc = lane & 15;
@@ -967,19 +971,8 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
             if (lane < 16) {
                 const double dv = scr[lane * 17 + lane];
                 D[J * 16 + lane] = dv; invD[J * 16 + lane] = 1. / dv;
-                // column `lane` of M = L_JJ^-1 by forward substitution (rows above the diagonal are zero)
-                double mcol[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    double sacc = (r == lane) ? 1. : 0.;
-#pragma unroll
-                    for (int k = 0; k < r; k++) sacc -= scr[r * 17 + k] * mcol[k];
-                    mcol[r] = (r < lane) ? 0. : sacc;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) { DC[(size_t)J * 256 + tile_op(r, lane)] = mcol[r]; DR[(size_t)J * 256 + tile_res(r, lane)] = mcol[r]; }
             }
-            { // L_JJ itself (strictly lower part, row-major: element e = 16 r + k) for the triangular solves of phase 2
+            { // L_JJ (strictly lower part, row-major: element e = 16 r + k) for the triangular solves of phase 2 and of the sweeps
                 d4_t lv;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const int e = lane * 4 + i, r = e >> 4, k = e & 15; lv[i] = (k < r) ? scr[r * 17 + k] : 0.; }
@@ -1049,14 +1042,16 @@ template <int T, bool LDSBAR, int NR, class WS>
 __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
     auto ws = ws0 + (size_t)P.tl_base * NR; // the blocks start at slot tl_base (hybrid: behind the scalar part of the vector)
     constexpr int NW = T / 64;
-    gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DC = W + P.w_DC, DR = W + P.w_DR, invD = W + P.w_invD + P.tl_base;
+    gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DL = W + P.w_DL, invD = W + P.w_invD + P.tl_base;
     const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, lc = lane & 15;
+    double *scr = g_dyn + P.tl_scratch + wave * TILE_SCR; // wave-private 16 x 17 tile in LDS: L_JJ of the block being closed
     auto bar = [&] { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); };
     auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
     // One sweep: per level every wavefront walks ITS flat list of tile operations (host: build_tile_sweeps) -- the tiles
     // of its blocks, each block closed by its diagonal operation -- with the tile loads of the next TILE_PF operations in
     // flight across block boundaries (they do not depend on ws).
-    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gcdbl_p val, gcdbl_p dia, bool scale) {
+    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gcdbl_p val, gcdbl_p dia, auto bwd) {
+        constexpr bool scale = decltype(bwd)::value; // backward: x_J = L_JJ^-T (y_J / D_J - ...), forward: y_J = L_JJ^-1 (b_J - ...)
         cint4_p ops = (cint4_p)(unsigned long long)ops_i;
         cint_p ptr = as_const(ptr_g);
         for (int v = 0; v < P.nblev; v++) {
@@ -1095,15 +1090,29 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                         const double idv = scale ? invD[vb * 16 + lc] : 1.;
 #pragma unroll
                         for (int k = 0; k < NR; k++) {
-                            const double r = (scale ? own[k] * idv : own[k]) - fold(acc[k]);
+                            res[k] = (scale ? own[k] * idv : own[k]) - fold(acc[k]); // (every 16-lane row holds the whole block vector)
                             acc[k] = 0.;
-                            res[k] = r;
-                            if (!(fl & TOP_IDENT)) {
-                                double oo = 0.;
+                        }
+                        if (!(fl & TOP_IDENT)) {
+                            // triangular solve with the unit-lower L_JJ by substitution inside the 16-lane row (no explicit inverse:
+                            // it costs cond(L_JJ) digits exactly when the scalings spread, in the last passes).  The tile arrives
+                            // row-major through the prefetch queue and goes through the wavefront's LDS tile: lane l & 15 needs
+                            // its ROW of L_JJ (forward: b_r -= L[r][c] y_c) or its COLUMN (backward: y_k -= L[c][k] x_c).
 #pragma unroll
-                                for (int st = 0; st < 4; st++) oo += cv[st] * __shfl(r, 4 * st + kq, 64);
-                                res[k] = fold(oo);
-                            }
+                            for (int i = 0; i < 4; i++) { const int e = lane * 4 + i; scr[(e >> 4) * 17 + (e & 15)] = cv[i]; }
+                            double lv[16];
+#pragma unroll
+                            for (int c = 0; c < 16; c++) lv[c] = scale ? scr[c * 17 + lc] : scr[lc * 17 + c];
+                            if constexpr (scale) static_for<15, 0, -1>([&](auto cc) {
+                                constexpr int c = decltype(cc)::value;
+#pragma unroll
+                                for (int k = 0; k < NR; k++) res[k] = __builtin_fma(-dpp_row_bcast<c>(res[k]), lv[c], res[k]);
+                            });
+                            else static_for<0, 15, 1>([&](auto cc) {
+                                constexpr int c = decltype(cc)::value;
+#pragma unroll
+                                for (int k = 0; k < NR; k++) res[k] = __builtin_fma(-dpp_row_bcast<c>(res[k]), lv[c], res[k]);
+                            });
                         }
                         if (lane < 16) stK<NR>(ws, vb * 16 + lane, res);
                     }
@@ -1112,8 +1121,8 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
             bar();
         }
     };
-    sweep(P.tl_fops, P.tl_fptr, LC, DC, false); // forward: block rows, levels up
-    sweep(P.tl_bops, P.tl_bptr, LR, DR, true);  // backward: block columns, levels down
+    sweep(P.tl_fops, P.tl_fptr, LC, DL, std::false_type{}); // forward: block rows, levels up
+    sweep(P.tl_bops, P.tl_bptr, LR, DL, std::true_type{});  // backward: block columns, levels down
 }
 
 // ---------------- G in dense tiles: G x and G' z in ONE pass over the values (DevPat::gt_on, host: api.cpp) ----------------

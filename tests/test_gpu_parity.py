@@ -159,6 +159,8 @@ def test_dense_front_socp():
                                  {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"},
                                  {"EICOS_KI": "2", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_THREADS": "256", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
                                  {"EICOS_LDSRES": "0"}, {"EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_TILES": "0"},
+                                 {"EICOS_TILES": "1", "EICOS_GTILES": "2"}, {"EICOS_TILES": "1", "EICOS_GTILES": "2", "EICOS_DUAL": "0", "EICOS_THREADS": "256"},
+                                 {"EICOS_TILES": "1", "EICOS_GTILES": "0"},
                                  {"EICOS_TILES": "0"}, {"EICOS_TILES": "2", "EICOS_NLDS": "0"}, {"EICOS_TILES": "2", "EICOS_THREADS": "128"}, {"EICOS_TILES": "2", "EICOS_THREADS": "512", "EICOS_IDX16": "0"}])
 def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # the launch shape is chosen per pattern/batch; force each template instantiation (KKT vectors in LDS
@@ -181,6 +183,24 @@ def test_every_kernel_variant_matches_oracle(env, monkeypatch):
             if oc == 0:
                 assert abs(gi[i]["pcost"] - oi["pcost"]) <= PCOST_RTOL * max(1.0, abs(oi["pcost"]))
         g.close(); o.close()
+
+
+def test_g_tile_products_match_the_ell_products_on_dense_fronts(monkeypatch):
+    # dense-front pattern: G goes to 16 x 16 tiles (one pass for G x and G' z); same iteration counts and solutions as with
+    # the sliced-ELL products (the sums are associated differently, so not bit for bit); m and n not multiples of 16,
+    # overlapping column windows (columns met by 4..8 tiles)
+    pat, base = dense_front_pattern(n=150, k=4, d=40)
+    d = feasible_batch(pat, base, 0, 6)
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EICOS_GTILES", flag)
+        g = eicos_amd.BatchSolver(pat, 6)
+        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"]); codes = g.solve().copy(); ia = g.info_arrays()
+        out.append((codes, ia["iter"].copy(), ia["pcost"].copy(), g.solution().copy(), g.dims()["inst_bytes"]))
+        g.close()
+    assert out[0][4] < out[1][4]                      # (tiles replace the two ELL copies of G in the instance slab)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-9) and np.allclose(out[0][3], out[1][3], rtol=1e-7, atol=1e-9)
 
 
 def test_lds_resident_variant_is_bit_identical_to_the_hbm_slab_kernel(monkeypatch):
