@@ -322,7 +322,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.w_Kimg = tile1 ? D.w_Kt : (tile ? Wl.add((size_t)(TP.nb + TP.nt) * 256 + 8) : 0); // hybrid: the top block's image beside the scalar stream
     D.tile = S.tile; D.nb = TP.nb; D.nt = TP.nt; D.nblev = TP.nblev; D.tl_base = TP.n0;
     if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), the strictly lower part of the diagonal tiles (DL)
-        D.w_LC = Wl.add((size_t)TP.nt * 256 + 8); D.w_LR = Wl.add((size_t)TP.nt * 256 + 8);
+        D.w_LC = Wl.add((size_t)TP.nt * 256 + 256); D.w_LR = Wl.add((size_t)TP.nt * 256 + 256); // (+ one tile: the dummy loads of padding operations read tile 0)
         D.w_DL = Wl.add((size_t)TP.nb * 256);
         D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
     }
@@ -456,6 +456,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     TileSweeps TSW;
     if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_PF);
     put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
+    TileFactorOps TFO;
+    if (tile) TFO = build_tile_factor_ops(TP, h->threads / 64, TILE_FPF);
+    put(D.tl_facops, TFO.ops); put(D.tl_facptr, TFO.ptr);
     put(D.tl_ident, TP.ident);
     put(D.tl_trow, TP.t_row); put(D.tl_tcol, TP.t_col); put(D.tl_tc_ptr, TP.tc_ptr); put(D.tl_tr_ptr, TP.tr_ptr); put(D.tl_tr_tile, TP.tr_tile);
     put(D.v2t, v2t);
@@ -486,7 +489,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
         const size_t scratch = tile ? (size_t)(h->threads / 64) * TILE_SCR * sizeof(double) : 0;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
-        const int wgs_by_regs = h->ki == 2 ? 1 : (h->threads == 256 ? 3 : 4) * 4 / (h->threads / 64); // waves_per_eu<T, KI>() of kernels.hip
+        const int wgs_by_regs = h->ki == 2 ? 1 : (h->threads == 256 ? 3 : (h->threads == 512 ? 2 : 4)) * 4 / (h->threads / 64); // waves_per_eu<T, KI>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
             return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + scratch + lds_static)));
         };

@@ -120,6 +120,7 @@ struct DevPat {
     gint_p tl_blev, tl_tgt_lev, tl_tgt, tl_tp, tl_pa, tl_pb, tl_pk, tl_fin_lev, tl_fin; // levels, factor targets / pairs, finalise lists
     gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view
     gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op
+    gint_p tl_facops, tl_facptr;               // per-wavefront flat schedule of the factorisation's accumulation phase (TileFactorOps)
     gint_p tl_ident;               // per block: 1 = the diagonal tile of L is the identity (skipped by the sweeps)
     gint_p tl_img_dst, tl_img_src, tl_psign; // K image scatter (slab offset -> image index); quasi-definite pivot sign per slot
     int w_LC, w_LR, w_DL;                // workspace: L tiles column- / row-major, strictly lower part of the diagonal tiles (row-major)
@@ -155,6 +156,11 @@ constexpr int tile_op(int r, int k) { return (((k & 3) * 16 + r) << 2) + (k >> 2
 constexpr int tile_res(int r, int c) { return (((r & 3) * 16 + c) << 2) + (r >> 2); }
 constexpr int TOP_DIAG = 1, TOP_IDENT = 2; // tile sweep op flags: closes its block (diagonal tile) / that diagonal tile is the identity (no load)
 constexpr int TILE_PF = 6;          // tile loads in flight per wavefront in the tile sweeps (op lists are padded to a multiple)
+#ifndef EICOS_TILE_FPF
+#define EICOS_TILE_FPF 3
+#endif
+constexpr int TILE_FPF = EICOS_TILE_FPF;         // operations (two tiles + a D block each) in flight per wavefront in the tile factorisation
+constexpr int FOP_INIT = 1, FOP_END = 2, FOP_PAD = 4, FOP_SHIFT = 4; // tile factor op flags: start a target from its K tile / finish it / padding; target id above
 constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each

@@ -67,15 +67,16 @@ __device__ constexpr double LINSYSACC = 1e-14, IRERRFACT = 6., STEPMIN = 1e-6, S
 __device__ constexpr double SIGMAMIN = 1e-4, SIGMAMAX = 1.0, SAFEGUARD = 500.;
 constexpr int EX_NOT_CONVERGED = -87;
 
-// Register budget per workgroup size = waves per SIMD the kernel is compiled for: 512 threads -> 4 (128 VGPRs,
-// two workgroups per CU), 256 threads -> 3 (168 VGPRs, three workgroups per CU: three 48 KB solve vectors are what
-// the 160 KB of LDS hold), 128 threads -> 4 (small patterns, up to eight workgroups per CU).  The AMDGPU
+// Register budget per workgroup size = waves per SIMD the kernel is compiled for: 512 threads -> 2 (256 VGPRs, one
+// workgroup per CU -- what large patterns and the tile path get anyway; the tile factorisation keeps three operations
+// of two tiles in flight per wavefront and spills at 128), 256 threads -> 3 (168 VGPRs, three workgroups per CU: three
+// 48 KB solve vectors are what the 160 KB of LDS hold), 128 threads -> 4 (small patterns, up to eight workgroups per CU).  The AMDGPU
 // attributor propagates the kernel's budget to the non-inlined stage functions.
 // Lock-step pairs (KI = 2) run as ONE workgroup per CU (both sweep vectors in LDS): 512 threads = 2 waves per SIMD -> 256 VGPRs.
 #if EICOS_LDSRES
 template <int T, int KI = 1> constexpr int waves_per_eu() { return 2; } // LDS allows at most three small workgroups per CU
 #else
-template <int T, int KI = 1> constexpr int waves_per_eu() { return KI == 2 ? T / 256 : (T == 256 ? 3 : 4); }
+template <int T, int KI = 1> constexpr int waves_per_eu() { return KI == 2 ? T / 256 : (T == 256 ? 3 : (T == 512 ? 2 : 4)); }
 #endif
 
 // Multiply-accumulate of the sparse inner loops (products, sweeps, factor program).  The file is compiled with
@@ -919,35 +920,46 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
     gcdbl_p Kt = W + P.w_Kimg;
     double *scr = g_dyn + P.tl_scratch + uni(wave) * TILE_SCR; // wave-private 16 x 17 tile in LDS
     const int nbk = P.nb, kq = lane >> 4, lc = lane & 15;
-    cint_p c_tgt = as_const(P.tl_tgt), c_tp = as_const(P.tl_tp), c_pa = as_const(P.tl_pa), c_pb = as_const(P.tl_pb), c_pk = as_const(P.tl_pk);
-    cint_p c_fin = as_const(P.tl_fin), c_tcol = as_const(P.tl_tcol), c_tl = as_const(P.tl_tgt_lev), c_fl = as_const(P.tl_fin_lev);
+    cint4_p c_fops = (cint4_p)(unsigned long long)P.tl_facops;
+    cint_p c_fptr = as_const(P.tl_facptr), c_fin = as_const(P.tl_fin), c_tcol = as_const(P.tl_tcol), c_fl = as_const(P.tl_fin_lev);
     __syncthreads();
     TICK_BEGIN;
     for (int v = 0; v < P.nblev; v++) {
-        // ---- phase 1: T = K - sum_K L_IK D_K L_JK' for every target of the level; diagonal targets are factorised ----
-        const int q1 = c_tl[v + 1];
-        for (int q = c_tl[v] + uni(wave); q < q1; q += NW) {
-            const int tg = c_tgt[q], p0 = c_tp[q], p1 = c_tp[q + 1];
-            d4_t acc = tile_ld(Kt, tg, lane); // the K image is stored in the MFMA result order
-            d4_t na, nb_, nd;
-            auto load = [&](int e, d4_t &xa, d4_t &xb, d4_t &xd) {
-                const int ta = c_pa[e], tb = c_pb[e], K = c_pk[e];
-                xa = tile_ld(LC, ta, lane); xb = tile_ld(LC, tb, lane);
+        // ---- phase 1: T = K - sum_K L_IK D_K L_JK' for every target of the level; diagonal targets are factorised.
+        // Every wavefront walks ITS flat list of operations (host: build_tile_factor_ops): per target an INIT operation (the
+        // K tile, already in the MFMA result order) and its pairs, the last one flagged END; the loads of the next TILE_FPF
+        // operations are in flight across target boundaries (unconditional: padding and INIT operations load tile 0 too) ----
+        const int o0 = c_fptr[v * NW + wave], o1 = c_fptr[v * NW + wave + 1];
+        d4_t qa[TILE_FPF], qb[TILE_FPF], qd[TILE_FPF];
+        auto load = [&](int o, d4_t &xa, d4_t &xb, d4_t &xd) {
+            const i4_t op = c_fops[min(o, o1 - 1)];
+            xa = tile_ld((op.w & FOP_INIT) ? Kt : (gcdbl_p)LC, op.x, lane); xb = tile_ld(LC, op.y, lane);
 #pragma unroll
-                for (int st = 0; st < 4; st++) xd[st] = D[K * 16 + 4 * st + kq];
-            };
-            if (p0 < p1) load(p0, na, nb_, nd);
-            for (int e = p0; e < p1; e++) {
-                const d4_t a = na, b = nb_, dd = nd;
-                load(min(e + 1, p1 - 1), na, nb_, nd); // next pair's tiles in flight behind this pair's MFMAs (unconditional: see tile_solve)
+            for (int st = 0; st < 4; st++) xd[st] = D[op.z * 16 + 4 * st + kq];
+        };
+        if (o0 < o1) {
+#pragma unroll
+            for (int u = 0; u < TILE_FPF; u++) load(o0 + u, qa[u], qb[u], qd[u]);
+        }
+        d4_t acc = {0., 0., 0., 0.};
+        for (int o = o0; o < o1; o += TILE_FPF) {
+#pragma unroll
+          for (int u = 0; u < TILE_FPF; u++) {
+            const i4_t op = c_fops[o + u];
+            const d4_t a = qa[u], b = qb[u], dd = qd[u];
+            load(o + u + TILE_FPF, qa[u], qb[u], qd[u]);
+            const int fl = op.w, tg = fl >> FOP_SHIFT;
+            if (fl & FOP_INIT) acc = a;
+            else if (!(fl & FOP_PAD)) {
 #pragma unroll
                 for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[st], b[st] * dd[st], acc, 0, 0, 0);
             }
+            if (!(fl & FOP_END)) continue;
             if (tg >= nbk) { // off-diagonal target: park T in its own L slot, result order = the accumulator as it stands
                 *reinterpret_cast<gd4_p>(LR + (size_t)(tg - nbk) * 256 + lane * 4) = acc;
                 continue;
             }
-            // ---- diagonal target: dense LDL' of the 16 x 16 tile in LDS (lower triangle), then the inverse of L_JJ ----
+            // ---- diagonal target: dense LDL' of the 16 x 16 tile in LDS (lower triangle) ----
             const int J = tg;
 #pragma unroll
             for (int r = 0; r < 4; r++) scr[(kq + 4 * r) * 17 + lc] = acc[r];
@@ -978,6 +990,7 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
                 for (int i = 0; i < 4; i++) { const int e = lane * 4 + i, r = e >> 4, k = e & 15; lv[i] = (k < r) ? scr[r * 17 + k] : 0.; }
                 *reinterpret_cast<gd4_p>(DL + (size_t)J * 256 + lane * 4) = lv;
             }
+          }
         }
         __syncthreads();
         // ---- phase 2: L_IJ = T_IJ L_JJ^-T D_J^-1 for the off-diagonal tiles of the level's block columns, as a triangular

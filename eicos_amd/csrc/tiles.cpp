@@ -108,6 +108,32 @@ TilePlan build_tile_plan(const Symbolic &S) {
     return T;
 }
 
+TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf) {
+    TileFactorOps F;
+    F.ptr.assign(1, 0);
+    for (int v = 0; v < T.nblev; v++) {
+        const int q0 = T.tgt_lev_ptr[v], q1 = T.tgt_lev_ptr[v + 1];
+        // weight of a target: its operations, plus the dense 16 x 16 LDL' a diagonal target ends with (about eight operations' time)
+        auto weight = [&](int q) { return 1 + (T.tp_ptr[q + 1] - T.tp_ptr[q]) + (T.tgt[q] < T.nb ? 8 : 0); };
+        std::vector<int> order(q1 - q0);
+        std::iota(order.begin(), order.end(), q0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight(a) > weight(b); });
+        std::vector<std::vector<int>> mine(NW);
+        std::vector<long> load(NW, 0);
+        for (int q : order) { const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin()); mine[w].push_back(q); load[w] += weight(q); }
+        for (int w = 0; w < NW; w++) {
+            for (int q : mine[w]) {
+                const int tg = T.tgt[q], p0 = T.tp_ptr[q], p1 = T.tp_ptr[q + 1];
+                F.ops.insert(F.ops.end(), {tg, 0, 0, FOP_INIT | (p0 == p1 ? FOP_END : 0) | (tg << FOP_SHIFT)});
+                for (int e = p0; e < p1; e++) F.ops.insert(F.ops.end(), {T.pa[e], T.pb[e], T.pk[e], (e + 1 == p1 ? FOP_END : 0) | (tg << FOP_SHIFT)});
+            }
+            while (((int)F.ops.size() / 4 - F.ptr.back()) % pf) F.ops.insert(F.ops.end(), {0, 0, 0, FOP_PAD}); // (unconditional loads: see build_tile_sweeps)
+            F.ptr.push_back((int)F.ops.size() / 4);
+        }
+    }
+    return F;
+}
+
 TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
     TileSweeps W;
     W.NW = NW;

@@ -56,6 +56,17 @@ struct TileSweeps {
 };
 TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf /* list lengths are padded to a multiple of pf */);
 
+// Per-wavefront schedule of the factorisation's accumulation phase (T_IJ = K_IJ - sum_K L_IK D_K L_JK'): the targets of a
+// level are dealt to the wavefronts (most pairs first) and every wavefront gets ONE flat list of operations per level -- per
+// target an INIT operation (the target's K tile) followed by its pairs, the last one flagged END -- so that the loads of the
+// next TILE_FPF operations are in flight across target boundaries (one operation = two tiles + the D values of a block).
+// op = {tile A (INIT: the target's tile in the K image), tile B, source block K, flags | target << FOP_SHIFT}
+struct TileFactorOps {
+    std::vector<int> ops;  // 4 ints per op
+    std::vector<int> ptr;  // [nblev * NW + 1]
+};
+TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf);
+
 TilePlan build_tile_plan(const Symbolic &S);
 
 } // namespace eicos
