@@ -176,7 +176,12 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         int ki_want = 1; // measured: pairs do not pay on the MPC pattern -> opt-in through EICOS_KI=2
         ki_want = env_int("EICOS_KI", ki_want);
         h->ki = (ki_want == 2 && !S.tile && batch >= 2) ? 2 : 1;
-        const int dflt = h->ki == 2 ? 512 : (dimK < 400 ? 128 : ((dimK < 2000 || throughput_bound) ? 256 : 512));
+        // one workgroup per CU (batch <= CUs): latency-bound, more wavefronts per instance pay earlier (measured at batch 256 with
+        // the 256-VGPR build of the 512-thread kernels: lp_blend / lp_adlittle, dim_K ~ 300: 256 threads +5..8 % over 128;
+        // lp_beaconfd / lp_bandm / lp_agg, dim_K 763..1718: 512 threads +7..12 % over 256)
+        const int dflt = h->ki == 2 ? 512
+                         : throughput_bound ? (dimK < 400 ? 128 : 256)
+                                            : (dimK < 250 ? 128 : (dimK < 700 ? 256 : 512));
         const int t = env_int("EICOS_THREADS", dflt);
         h->threads = (t == 128 || t == 256 || t == 512) ? t : dflt;
         if (h->threads < 256) h->ki = 1;
