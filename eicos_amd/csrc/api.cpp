@@ -329,8 +329,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (tile) { // unit-lower L tiles column-major (LC) and row-major (LR), the strictly lower part of the diagonal tiles (DL)
         D.w_LC = Wl.add((size_t)TP.nt * 256 + 256); D.w_LR = Wl.add((size_t)TP.nt * 256 + 256); // (+ one tile: the dummy loads of padding operations read tile 0)
         D.w_DL = Wl.add((size_t)TP.nb * 256);
-        D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
     }
+    D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
     D.work_stride = Wl.size;
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
     std::vector<int> col_of(S.nnzL);
@@ -518,10 +518,14 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         int ki = h->ki; // wanted (decided with the workgroup size, above); needs both vectors + the tables in LDS
         if (ki != 2 || tile || fit < 2 || h->threads < 256 || batch < 2) ki = 1; // (tile / hybrid factor paths are single-instance)
         h->ki = ki;
-        // Dual right-hand-side solves (pure tile mode: bandwidth-bound on streaming L and G): needs two vectors in LDS
-        int dual = (tile1 && fit == 2) ? 1 : 0;
+        // Dual right-hand-side solves (the two independent systems of the initialisation and of every pass share one
+        // sweep over the factor): needs two vectors in LDS.  Pure tile mode (bandwidth-bound on streaming L and G): always.
+        // Scalar / hybrid programs: when the batch fits one workgroup per CU -- the sweeps are then a dependent chain of level
+        // steps, and a step for two right-hand sides costs far less than two steps (not for the 128-thread patterns: they
+        // take the LDS-resident build)
+        int dual = (fit == 2 && ki == 1 && (tile1 || (batch <= prop.multiProcessorCount && h->threads >= 256))) ? 1 : 0;
         dual = env_int("EICOS_DUAL", dual);
-        if (!tile1 || fit < 2) dual = 0;
+        if (fit < 2 || ki != 1) dual = 0;
         if (dual) h->nlds = 1;
         D.dual = dual;
         if (ki == 2) h->nlds = 1;

@@ -474,7 +474,8 @@ __device__ __forceinline__ void lds_barrier() {
 // SOLO: the narrow top of the elimination tree, laid out for 64 lanes and run by wavefront 0 alone -- no
 // workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
-template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, class SM, class WS>
+// VSH (dual right-hand sides of ONE instance): the vector ws is KI-interleaved, the factor (eval, invD) is a single one.
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
     // KI > 1: the workgroup sweeps KI instances in lock-step -- slice descriptors and gather indices are shared, the value
@@ -497,12 +498,22 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
-            ldK_g<KI, true>(eval, slot, o.val[kk]); // streamed once per sweep: do not displace the index arrays in L2
+            if constexpr (VSH) { // one value for both right-hand sides
+                double v1[1];
+                ldK_g<1, true>(eval, slot, v1);
+#pragma unroll
+                for (int k = 0; k < KI; k++) o.val[kk][k] = v1[0];
+            } else ldK_g<KI, true>(eval, slot, o.val[kk]); // streamed once per sweep: do not displace the index arrays in L2
         }
         const int r = act ? o.row0 + (t >> o.lg) : 0;
         if constexpr (FORWARD) { // forward is L y = b with unit-lower L: no pivot needed
 #pragma unroll
             for (int k = 0; k < KI; k++) o.d[k] = 0.;
+        } else if constexpr (VSH) {
+            double d1[1];
+            ldK_g<1, false>(invD, r, d1);
+#pragma unroll
+            for (int k = 0; k < KI; k++) o.d[k] = d1[0];
         } else ldK_g<KI, false>(invD, r, o.d);
         ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
@@ -1500,7 +1511,8 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rA; else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rG; else return P.rG_sl; }();
     gdbl_p dxr = Wg + (size_t)KI * P.w_dxr;
-    gdbl_p UF = Wg + (size_t)KI * P.w_UF, UB = Wg + (size_t)KI * P.w_UB, invD = Wg + (size_t)KI * P.w_invD;
+    constexpr int KF = DUAL ? 1 : KI; // instances whose factors are interleaved (dual: one factor, two right-hand sides)
+    gdbl_p UF = Wg + (size_t)KF * P.w_UF, UB = Wg + (size_t)KF * P.w_UB, invD = Wg + (size_t)KF * P.w_invD;
     __syncthreads();
     unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
     auto tick = [&](int slot) { // the lock-step time is booked on every participating instance
@@ -1541,37 +1553,37 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
             if constexpr (KI == 1 || DUAL) { if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV); }
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-            tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
+            tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
             if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down
-                if constexpr (KI == 1) {
-                    if (wave0) tri_sweep<T, true, true, true, I16, KI>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                if constexpr (KI == 1 || DUAL) {
+                    if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
-                    tri_sweep<T, true, true, false, I16, KI>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                    tile_solve<T, true, 1>(P, Wg, SV);
-                    if (wave0) tri_sweep<T, false, true, true, I16, KI>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                    tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tile_solve<T, true, KI>(P, Wg, SV);
+                    if (wave0) tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
-                tri_sweep<T, true, true, true, I16, KI>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                tri_sweep<T, false, true, true, I16, KI>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
             __syncthreads();
-            tri_sweep<T, false, true, false, I16, KI>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            tri_sweep<T, false, true, false, I16, KI, DUAL>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
         } else {
-            tri_sweep<T, true, false, false, I16, KI>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+            tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
             if (P.tile == 2) {
-                if constexpr (KI == 1) {
-                    if (wave0) tri_sweep<T, true, false, true, I16, KI>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                if constexpr (KI == 1 || DUAL) {
+                    if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
-                    tri_sweep<T, true, false, false, I16, KI>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                    tile_solve<T, false, 1>(P, Wg, SV);
-                    if (wave0) tri_sweep<T, false, false, true, I16, KI>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                    tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tile_solve<T, false, KI>(P, Wg, SV);
+                    if (wave0) tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
-                tri_sweep<T, true, false, true, I16, KI>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                tri_sweep<T, false, false, true, I16, KI>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
             __syncthreads();
-            tri_sweep<T, false, false, false, I16, KI>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            tri_sweep<T, false, false, false, I16, KI, DUAL>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
         }
         // x = first solve / x += dx_ref (ref :1602); an instance that has stopped keeps its iterate
         if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
