@@ -521,9 +521,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // Dual right-hand-side solves (the two independent systems of the initialisation and of every pass share one
         // sweep over the factor): needs two vectors in LDS.  Pure tile mode (bandwidth-bound on streaming L and G): always.
         // Scalar / hybrid programs: when the batch fits one workgroup per CU -- the sweeps are then a dependent chain of level
-        // steps, and a step for two right-hand sides costs far less than two steps (not for the 128-thread patterns: they
-        // take the LDS-resident build)
-        int dual = (fit == 2 && ki == 1 && (tile1 || (batch <= prop.multiProcessorCount && h->threads >= 256))) ? 1 : 0;
+        // steps, and a step for two right-hand sides costs far less than two steps
+        int dual = (fit == 2 && ki == 1 && (tile1 || batch <= prop.multiProcessorCount)) ? 1 : 0;
         dual = env_int("EICOS_DUAL", dual);
         if (fit < 2 || ki != 1) dual = 0;
         if (dual) h->nlds = 1;
@@ -543,7 +542,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // DESIGN.md 5.1).  Only for batches that fit the grid in one round -- beyond that the eight small workgroups per CU
         // of the HBM-slab kernel hide more latency than the <= 3 that LDS holds here (measured, lp_afiro batch 2048).
         h->ldsres = 0; D.lr_inst = D.lr_work = 0;
-        if (!tile && ki == 1 && !dual && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1)) {
+        if (!tile && ki == 1 && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1)) {
             const size_t base = (h->dyn_lds + 15) & ~(size_t)15, islab = (D.inst_stride + 1) & ~(size_t)1, wslab = (D.work_stride + 1) & ~(size_t)1;
             const size_t total = base + (islab + wslab) * sizeof(double);
             const size_t per_cu = (160 * 1024) / (total + lds_static); // workgroups per CU that LDS allows
