@@ -186,12 +186,13 @@ class Job:
         cores = usable_cores()
         sub = lambda k, a, b: data[k][a:b]
         run = lambda a, b: orc.batch_solve(pat, sub("Gpr", a, b), sub("Apr", a, b), sub("c", a, b), sub("h", a, b), sub("b", a, b), cores)
-        # bounded sample: a pilot of one instance per core sizes the sample to ~15 s of CPU work (capped at four
-        # passes over the batch), so that small and large patterns are both timed over a comparable span
+        # bounded sample: a pilot of one instance per core sizes the sample to 10..30 s of CPU work (capped at four passes over
+        # the batch; the pilot runs cold and overestimates the time per instance by up to 3x, hence the target of 30), so that
+        # small and large patterns are both timed over a comparable span
         npil = int(min(B, cores))
         r0 = run(0, npil)
         per_inst_cpu = (r0["seconds"] + r0["update_seconds"]) * min(cores, npil) / npil
-        want = int(max(npil, min(4 * B, 15.0 / max(per_inst_cpu, 1e-9))))
+        want = int(max(npil, min(4 * B, 30.0 / max(per_inst_cpu, 1e-9))))
         reps, ns = (1, want) if want <= B else (min(4, -(-want // B)), B)
         tot_iters, wall, match, maxdiff = 0, 0.0, True, 0
         for _ in range(reps):
