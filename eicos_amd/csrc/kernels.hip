@@ -984,12 +984,13 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
                     if (sg * dj <= g_S.dyn_eps) { dj = sg * g_S.dyn_delta; if (lane == 0) scr[j * 17 + j] = dj; }
                 }
                 if (dj == 0. && lane == 0) g_S.fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
+                const double idj = 1. / dj; // ONE division per column (an fp64 division is ~40 instructions; the scalar program also multiplies by 1/D)
 #pragma unroll
-                for (int r = 0; r < 4; r++) { // trailing update of the lower triangle with the unscaled column j
+                for (int r = 0; r < 4; r++) { // trailing update of the lower triangle with column j of L times the unscaled column j
                     const int rr = kq + 4 * r;
-                    if (lc > j && rr >= lc) scr[rr * 17 + lc] -= (scr[rr * 17 + j] / dj) * scr[lc * 17 + j];
+                    if (lc > j && rr >= lc) scr[rr * 17 + lc] -= (scr[rr * 17 + j] * idj) * scr[lc * 17 + j];
                 }
-                if (lane > j && lane < 16) scr[lane * 17 + j] = scr[lane * 17 + j] / dj; // column j of L
+                if (lane > j && lane < 16) scr[lane * 17 + j] = scr[lane * 17 + j] * idj; // column j of L
             }
             if (lane < 16) {
                 const double dv = scr[lane * 17 + lane];
@@ -1050,7 +1051,11 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
     }
     if (tid == 0 && P.tile == 1) wi.n_factor++; // (hybrid: counted by the scalar part)
     __syncthreads();
-    TICK_END(TK_FACTOR);
+    if (threadIdx.x == 0) { // (hybrid: the tile part is also booked on its own slot, for the phase breakdown of tools/dev/gpu_sweep.py)
+        const unsigned long long t1_ = wall_clock64();
+        g_S.tick[TK_FACTOR] += t1_ - tk0_;
+        if (P.tile == 2) g_S.tick[TK_FA] += t1_ - tk0_;
+    }
     if (g_S.fl[FL_FATAL]) return ST_DONE; // ref :901-905,1166-1170 (no backscale)
     return (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
 }

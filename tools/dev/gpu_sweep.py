@@ -26,4 +26,4 @@ print(f"{name} B={B} {tag}: ms={min(ms):.2f} (all {['%.1f'%m for m in ms]}) iter
 if B <= dm['resident_blocks']:
     tr = g.debug_trace(0)[-1]
     print("   phase us (inst 0): factor %.0f ldl(excl fwd) %.0f fwd %.0f kkt-resid %.0f kkt-post %.0f resid-stage %.0f total %.0f" % (tr[0], tr[1], tr[5], tr[2], tr[3], tr[4], tr[6]), " per iter:", ["%.0f" % (v / max(1, ia['iter'][0])) for v in (tr[0], tr[1], tr[5], tr[2], tr[3], tr[4], tr[6])], "nsolve", ia['n_ldlsolve'][0], "nfactor", ia['n_factor'][0])
-    print("   factor us per call: phaseA %.1f wait1 %.1f phaseB %.1f wait2 %.1f" % tuple(tr[7:11] / max(1, ia['n_factor'][0])))
+    print("   factor us per call: hybrid tile part %.1f (of %.1f)" % (tr[7] / max(1, ia['n_factor'][0]), tr[0] / max(1, ia['n_factor'][0])))
