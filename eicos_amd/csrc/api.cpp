@@ -20,6 +20,7 @@
 #include "symbolic.hpp"
 #include "plans.hpp"
 #include "tiles.hpp"
+#include "envknob.hpp"
 
 using namespace eicos;
 
@@ -141,7 +142,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         };
         if (haveG) take(Gjc, Gir, m, P.Gjc, P.Gir, "G"); else P.Gjc.assign(n + 1, 0);
         if (haveA) take(Ajc, Air, p, P.Ajc, P.Air, "A"); else P.Ajc.assign(n + 1, 0);
-        { const char *tv = getenv("EICOS_TILES"); h->sym = analyze(P, -1, tv ? atoi(tv) : -1); }
+        // (experiment knobs, envknob.hpp: honoured only under EICOS_EXPERIMENT=1, range-checked)
+        h->sym = analyze(P, env_knob("EICOS_ORDER", -1, 0, 16), env_knob("EICOS_TILES", -1, 0, 2));
         if (h->sym.tile) h->tiles = build_tile_plan(h->sym);
     } catch (const std::invalid_argument &e) { delete h; return fail(EICOS_E_INVALID, e.what()); }
     catch (const std::runtime_error &e) { delete h; return fail(EICOS_E_UNSUPPORTED, e.what()); }
@@ -161,7 +163,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = NV; D.mt = S.mt; D.nV = S.nV;
     D.nnzA = S.nnzA; D.nnzG = S.nnzG; D.nnzL = S.nnzL; D.nlev = S.nlev;
 
-    auto env_int = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
+    auto env_int = [](const char *k, int dflt, int lo, int hi) { return env_knob(k, dflt, lo, hi); };
     {
         // workgroup size by problem size (measured, batch 256: dim_K 129 -> 128, 1249 -> 256, >= 3815 -> 512 threads);
         // batches beyond one workgroup per CU are throughput-bound: 256 threads issue a third fewer wavefront-slices
@@ -174,7 +176,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // lock-step pairs (see the LDS sizing below): wanted when there are more instances than CUs and two sweep vectors
         // (+ ~24 KB of tables) fit the 160 KB of LDS; they run as ONE 512-thread workgroup per CU
         int ki_want = 1; // measured: pairs do not pay on the MPC pattern -> opt-in through EICOS_KI=2
-        ki_want = env_int("EICOS_KI", ki_want);
+        ki_want = env_int("EICOS_KI", ki_want, 1, 2);
         h->ki = (ki_want == 2 && !S.tile && batch >= 2) ? 2 : 1;
         // one workgroup per CU (batch <= CUs): latency-bound, more wavefronts per instance pay earlier (measured at batch 256 with
         // the 256-VGPR build of the 512-thread kernels: lp_blend / lp_adlittle, dim_K ~ 300: 256 threads +5..8 % over 128;
@@ -182,7 +184,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const int dflt = h->ki == 2 ? 512
                          : throughput_bound ? (dimK < 400 ? 128 : 256)
                                             : (dimK < 250 ? 128 : (dimK < 700 ? 256 : 512));
-        const int t = env_int("EICOS_THREADS", dflt);
+        const int t = env_int("EICOS_THREADS", dflt, 128, 512);
         h->threads = (t == 128 || t == 256 || t == 512) ? t : dflt;
         if (h->threads < 256) h->ki = 1;
     }
@@ -201,7 +203,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // evaluation instead of once in column form and once in row form, with no index bytes.  Taken when the tiles are at
     // least half full; the sliced-ELL plans of the products then hold A only.
     struct GTiles { int on = 0, nrb = 0, nt = 0, W = 0; std::vector<int> rbptr, col, src, cidx; } GT;
-    if (S.tile == 1 && S.nnzG > 0 && env_int("EICOS_GTILES", 1)) {
+    if (S.tile == 1 && S.nnzG > 0 && env_int("EICOS_GTILES", 1, 0, 2)) {
         const int nrb = (S.m + 15) / 16;
         GT.nrb = nrb; GT.rbptr.assign(nrb + 1, 0);
         std::vector<std::vector<int>> rbcols(nrb);
@@ -212,7 +214,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             GT.rbptr[rb + 1] = GT.rbptr[rb] + ((int)cs.size() + 15) / 16;
         }
         GT.nt = GT.rbptr[nrb];
-        if (GT.nt > 0 && ((double)S.nnzG >= 0.5 * 256.0 * GT.nt || env_int("EICOS_GTILES", 1) == 2)) { // (2: tests force it on sparse G)
+        if (GT.nt > 0 && ((double)S.nnzG >= 0.5 * 256.0 * GT.nt || env_int("EICOS_GTILES", 1, 0, 2) == 2)) { // (2: tests force it on sparse G)
             GT.on = 1;
             GT.col.assign((size_t)GT.nt * 16, -1); GT.src.assign((size_t)GT.nt * 256 + 1, -1);
             std::vector<int> ccount(S.n, 0);
@@ -385,7 +387,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             fac_w16[4 * e] = wa[2 * e]; fac_w16[4 * e + 1] = wa[2 * e + 1]; fac_w16[4 * e + 2] = wb[2 * e]; fac_w16[4 * e + 3] = wb[2 * e + 1];
         }
     }
-    D.idx16 = (idx16_ok && env_int("EICOS_IDX16", 1)) ? 1 : 0;
+    D.idx16 = (idx16_ok && env_int("EICOS_IDX16", 1, 0, 1)) ? 1 : 0;
     std::vector<int> fsl_i = meta_ints(planF.sl, f_o16), bsl_i = meta_ints(planB.sl, b_o16), fac_sl_i = meta_ints(planX.sl, x_o16);
     std::vector<int> cag_sl_i = meta_ints(pcag.sl, cag_o16), rA_sl_i = meta_ints(prA.sl, rA_o16), rG_sl_i = meta_ints(prG.sl, rG_o16);
 
@@ -499,7 +501,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + scratch + lds_static)));
         };
         // the factor program's table goes to LDS too when it is small and does not cost a resident workgroup
-        if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total) && env_int("EICOS_FAC_LDS", 1)) {
+        if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total) && env_int("EICOS_FAC_LDS", 1, 0, 1)) {
             D.lm_fac = D.lm_total; D.lm_total += D.fac_ns;
         } else D.lm_fac = -1;
         const size_t meta = (size_t)D.lm_total * sizeof(PackedSlice) + scratch;
@@ -511,7 +513,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // more instances than CUs: keep only E in LDS so that several workgroups share a CU (measured)
         int want = fit;
         if (batch > prop.multiProcessorCount && fit == 2 && 2 * (vec + meta + 4096) <= 160 * 1024) want = 1;
-        h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want)));
+        h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want, 0, 2)));
         // Lock-step pairs: with more instances than CUs, one 512-thread workgroup per CU solves TWO
         // instances at once -- slice decoding, index loads, barriers and the dependent chain of the sparse sweeps are shared,
         // values / gathers are 16-byte accesses over interleaved arrays.  Needs both sweep vectors in LDS.
@@ -523,7 +525,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // Scalar / hybrid programs: when the batch fits one workgroup per CU -- the sweeps are then a dependent chain of level
         // steps, and a step for two right-hand sides costs far less than two steps
         int dual = (fit == 2 && ki == 1 && (tile1 || batch <= prop.multiProcessorCount)) ? 1 : 0;
-        dual = env_int("EICOS_DUAL", dual);
+        dual = env_int("EICOS_DUAL", dual, 0, 1);
         if (fit < 2 || ki != 1) dual = 0;
         if (dual) h->nlds = 1;
         D.dual = dual;
@@ -542,7 +544,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // DESIGN.md 5.1).  Only for batches that fit the grid in one round -- beyond that the eight small workgroups per CU
         // of the HBM-slab kernel hide more latency than the <= 3 that LDS holds here (measured, lp_afiro batch 2048).
         h->ldsres = 0; D.lr_inst = D.lr_work = 0;
-        if (!tile && ki == 1 && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1)) {
+        if (!tile && ki == 1 && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1, 0, 1)) {
             const size_t base = (h->dyn_lds + 15) & ~(size_t)15, islab = (D.inst_stride + 1) & ~(size_t)1, wslab = (D.work_stride + 1) & ~(size_t)1;
             const size_t total = base + (islab + wslab) * sizeof(double);
             const size_t per_cu = (160 * 1024) / (total + lds_static); // workgroups per CU that LDS allows
@@ -576,10 +578,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
             if (cost < best - 1e-12) { best = cost; best_r = r; }
         }
-        const int forced = env_int("EICOS_FORCE_BLOCKS_PER_CU", 0); // experiments: override the estimate (within what fits)
+        const int forced = env_int("EICOS_FORCE_BLOCKS_PER_CU", 0, 0, 8); // experiments: override the estimate (within what fits)
         bpc = forced > 0 ? std::min(forced, bpc) : best_r;
     }
-    bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc)));
+    bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min((batch + h->ki - 1) / h->ki, resident);
     h->order_min = prop.multiProcessorCount;
@@ -588,7 +590,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const size_t need = ((size_t)S.nnzA + S.nnzG + S.n + S.p + S.m + 8) * sizeof(double);
         const size_t need_max = ((size_t)S.n + S.p + S.m + 8) * sizeof(double); // the row / column maxima alone
         const bool small_vecs = S.n <= 8 * 512 && S.p <= 8 * 512 && S.m <= 16 * 512;
-        const int mode = env_int("EICOS_UPDATE_LDS", 1); // 0: thread-per-column kernel, 2: force the streamed-values variant
+        const int mode = env_int("EICOS_UPDATE_LDS", 1, 0, 2); // 0: thread-per-column kernel, 2: force the streamed-values variant
         if (need <= 156 * 1024 && small_vecs && mode == 1) { h->upd_lds = need; h->upd_vals_lds = 1; h->upd_grid = std::min(batch, prop.multiProcessorCount); }
         else if (need_max <= 156 * 1024 && small_vecs && mode >= 1) { // values streamed in place, maxima in LDS: as many 512-thread workgroups per CU as fit (<= 4)
             h->upd_lds = need_max; h->upd_vals_lds = 0;

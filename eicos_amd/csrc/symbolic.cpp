@@ -1,5 +1,6 @@
 // Host-side symbolic analysis (see symbolic.hpp).  Plain C++17, no GPU code.
 #include "symbolic.hpp"
+#include "envknob.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -25,21 +26,25 @@ void transpose_pattern(int rows, int cols, const ivec &jc, const ivec &ir, ivec 
 // mode 1: each round eliminates a maximal independent set of minimum-degree nodes
 // (multiple elimination), which keeps the elimination tree bushy -- tree height is the
 // number of dependent steps of every GPU triangular solve, so it matters as much as fill.
-ivec order_min_degree(int N, const ivec &er, const ivec &ec, int mode) {
+// `hold` (optional): hold[v] = w >= 0 keeps node w out of the ordering until node v (and every other node that names w)
+// has been eliminated -- used for the two expansion columns of a second-order cone (see analyze_mode).
+ivec order_min_degree(int N, const ivec &er, const ivec &ec, int mode, const ivec *hold = nullptr) {
     std::vector<ivec> adj(N);
     for (size_t e = 0; e < er.size(); e++)
         if (er[e] != ec[e]) { adj[er[e]].push_back(ec[e]); adj[ec[e]].push_back(er[e]); }
     for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
     std::vector<char> dead(N, 0);
+    ivec blocked(N, 0); // number of nodes that must be eliminated before this one becomes eligible
+    if (hold) for (int v = 0; v < N; v++) if ((*hold)[v] >= 0) blocked[(*hold)[v]]++;
     ivec order; order.reserve(N);
     ivec mark(N, -1), cand, chosen, merged, nv;
     int round = 0, alive = N;
     while (alive > 0) {
         size_t mind = (size_t)-1;
-        for (int v = 0; v < N; v++) if (!dead[v]) mind = std::min(mind, adj[v].size());
+        for (int v = 0; v < N; v++) if (!dead[v] && !blocked[v]) mind = std::min(mind, adj[v].size());
         chosen.clear();
         if (mode == 0) {
-            for (int v = 0; v < N; v++) if (!dead[v] && adj[v].size() == mind) { chosen.push_back(v); break; }
+            for (int v = 0; v < N; v++) if (!dead[v] && !blocked[v] && adj[v].size() == mind) { chosen.push_back(v); break; }
         } else {
             // mode = 1 + slack: nodes within `slack` of the minimum degree are eligible too,
             // lowest degree first (plain minimum degree peels chain-like graphs from their
@@ -47,7 +52,7 @@ ivec order_min_degree(int N, const ivec &er, const ivec &ec, int mode) {
             const size_t slack = (size_t)(mode - 1);
             cand.clear();
             for (size_t d = mind; d <= mind + slack; d++)
-                for (int v = 0; v < N; v++) if (!dead[v] && adj[v].size() == d) cand.push_back(v);
+                for (int v = 0; v < N; v++) if (!dead[v] && !blocked[v] && adj[v].size() == d) cand.push_back(v);
             for (int v : cand) {
                 if (mark[v] == round) continue;
                 chosen.push_back(v);
@@ -57,6 +62,7 @@ ivec order_min_degree(int N, const ivec &er, const ivec &ec, int mode) {
         }
         for (int v : chosen) {
             dead[v] = 1; order.push_back(v); alive--;
+            if (hold && (*hold)[v] >= 0) blocked[(*hold)[v]]--;
             nv.swap(adj[v]); adj[v].clear();
             for (int u : nv) {
                 merged.clear();
@@ -100,7 +106,7 @@ void etree_rows(int N, const std::vector<ivec> &up, ivec &parent, std::vector<iv
 
 } // namespace
 
-static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program, bool hybrid = false);
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program, bool hybrid = false, bool cone_order = false);
 
 // order_mode < 0: try several slacks and keep the cheapest under a simple cost model:
 // every level costs the GPU one workgroup barrier + a dependent memory round trip, which is
@@ -109,23 +115,35 @@ Symbolic analyze(const ProblemPattern &P, int order_mode, int tile) {
     const std::vector<int> modes = order_mode >= 0 ? std::vector<int>{order_mode} : std::vector<int>{1, 2, 3, 4, 6};
     constexpr double LEVEL_COST = 64.0;
     int best_mode = modes[0];
+    // Cone-ordered candidates (the expansion columns of every second-order cone after the cone's rows, see analyze_mode):
+    // taken when that order is free under the cost model -- at most one level or 2 % dearer than the best unconstrained
+    // order -- which is the case for small patterns; on MPC-SOC it costs 9 % fill and 16 % factor pairs, on the dense-front
+    // config 35 % tiles, and the unconstrained order stays.  EICOS_CONE_ORDER (experiment knob): 0 never, 1 always.
+    const int cone_knob = env_knob("EICOS_CONE_ORDER", -1, 0, 1);
     if (tile != 1) { // structure only (no factor program): pick the ordering, see how dense L is
-        double best_cost = -1;
+        double best_cost = -1, best_cost_c = -1;
         long long best_nnzL = 0;
+        int best_mode_c = modes[0];
         const int N = P.n + P.p + P.m + 2 * P.nc;
         for (int mode : modes) {
             Symbolic S = analyze_mode(P, mode, false, false);
             const double cost = S.nnzL + LEVEL_COST * S.nlev;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_mode = mode; best_nnzL = S.nnzL; }
+            if (P.nc > 0 && cone_knob != 0) {
+                Symbolic C = analyze_mode(P, mode, false, false, false, true);
+                const double cc = C.nnzL + LEVEL_COST * C.nlev;
+                if (best_cost_c < 0 || cc < best_cost_c) { best_cost_c = cc; best_mode_c = mode; }
+            }
         }
         if (tile < 0) tile = (N > 0 && best_nnzL >= 16LL * N) ? 1 : 2; // ~16+ entries per column of L: dense fronts; else hybrid if it pays
-        if (tile == 0 || tile == 2) return analyze_mode(P, best_mode, false, true, tile == 2);
+        const bool cone_order = best_cost_c >= 0 && (cone_knob == 1 || best_cost_c <= std::max(best_cost + LEVEL_COST, 1.02 * best_cost));
+        if (tile == 0 || tile == 2) return analyze_mode(P, cone_order ? best_mode_c : best_mode, false, true, tile == 2, cone_order);
     }
     // tile path: the cost is the number of 16 x 16 tiles (bytes streamed per solve) plus the block levels (barriers)
     Symbolic best;
     double best_cost = -1;
     for (int mode : modes) {
-        Symbolic S = analyze_mode(P, mode, true, false);
+        Symbolic S = analyze_mode(P, mode, true, false, false, cone_knob == 1);
         long long nt = 0;
         { // count the off-diagonal tiles of L
             std::vector<int> blk(S.N);
@@ -143,7 +161,7 @@ Symbolic analyze(const ProblemPattern &P, int order_mode, int tile) {
     return best;
 }
 
-static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program, bool hybrid) {
+static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile, bool program, bool hybrid, bool cone_order) {
     Symbolic S;
     S.order_mode = order_mode;
     S.tile = tile ? 1 : 0;
@@ -193,7 +211,23 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     const int N = S.N;
 
     // ---- ordering, then renumber so that etree levels are contiguous ----
-    ivec perm0 = order_min_degree(N, S.K_row, S.K_col, order_mode);
+    // Second-order cones: the two expansion columns of a cone (v, then u: src/eicos.cpp:1848-1876) are ordered AFTER the
+    // cone's own rows, v before u -- the order the reference's column layout has them in and the one the sparse expansion
+    // is designed for: eliminating v first turns the cone's diagonal block -eta^2 I into -eta^2 (I - v1^2 q q'), whose
+    // pivots cancel (measured on unboundedMaxSqrt, 300 copies perturbed by 1e-16: v and u first -> 300 x NUMERICS; cone
+    // rows first -> 140..157 x the DINF certificate the reference's test asserts, the CPU oracle: 182).
+    ivec hold;
+    if (S.nc > 0 && cone_order) {
+        hold.assign(N, -1);
+        int k0 = S.n + S.p + S.l;
+        for (int c = 0; c < S.nc; c++) {
+            const int d = P.q[c];
+            for (int i = 0; i < d; i++) hold[k0 + i] = k0 + d; // every cone row holds back v
+            hold[k0 + d] = k0 + d + 1;                          // v holds back u
+            k0 += d + 2;
+        }
+    }
+    ivec perm0 = order_min_degree(N, S.K_row, S.K_col, order_mode, hold.empty() ? nullptr : &hold);
     ivec iperm0(N);
     for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
     std::vector<ivec> rows;
@@ -331,7 +365,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     // ---- hybrid: does the scalar schedule end in a chain worth handing to the tile path? ----
     if (!tile && program && hybrid && N > 0) {
         int cut = S.nlev;
-        const int wmax = getenv("EICOS_HYB_W") ? atoi(getenv("EICOS_HYB_W")) : 4; // (tuning knob)
+        const int wmax = env_knob("EICOS_HYB_W", 4, 1, 64); // (experiment knob, envknob.hpp)
         while (cut > 0 && S.lev_ptr[cut] - S.lev_ptr[cut - 1] <= wmax) cut--; // maximal tail of levels with <= 4 nodes
         const int nD = N - S.lev_ptr[cut], nbD = (nD + 15) / 16;
         // worth it: the tail is long (each of its levels costs the sweeps a dependent step, one block costs about two)

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the tests reach every kernel variant through the library's experiment knobs (EICOS_THREADS, EICOS_TILES, ...): those are
+# honoured only under this opt-in (eicos_amd/csrc/envknob.hpp), so that a host application's environment cannot switch paths
+os.environ["EICOS_EXPERIMENT"] = "1"
 
 
 def pytest_configure(config):

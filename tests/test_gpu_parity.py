@@ -35,13 +35,15 @@ def test_fixture_matches_oracle(name, expected):
         codes = g.solve(); gi = g.info()
         assert oc in expected[name]["exit_codes"]
         if name in CHAOTIC:
-            # Unbounded problem: the iterates diverge (x/tau -> inf), the KKT systems become arbitrarily
-            # ill-conditioned and after ~7 passes rounding differences (different elimination order and
-            # reduction trees) are amplified into different line-search outcomes.  Pin the trajectory while
-            # it is well defined and accept either the certificate or the safeguard exit afterwards.
+            # Unbounded problem: the iterates diverge (x/tau -> inf), the KKT systems become arbitrarily ill-conditioned and
+            # after ~7 passes rounding differences are amplified into different line-search outcomes (see
+            # test_unbounded_max_sqrt_exit_distribution_matches_the_oracles below).  The trajectory is pinned while it is well
+            # defined; the exit code on the exact data is the one the reference's header asserts (DINF,
+            # test/unboundedProblems/unboundedMaxSqrt.h:33) -- since round 3 the expansion columns of a cone are eliminated
+            # after the cone's rows (symbolic.cpp), which is what decides this fixture.
             tg, to = g.debug_trace(0), o.trace()
             assert np.allclose(tg[:6, :11], to[:6, :11], rtol=1e-7, atol=1e-12)
-            assert set(codes) <= {oc, oc + 10, -2}, (name, codes, oc)
+            assert list(codes) == [oc] * 3 and oc == 2, (name, codes, oc)
             continue
         assert list(codes) == [oc] * 3, (name, codes, oc)
         for i in range(3):
@@ -535,37 +537,93 @@ def test_config4_dense_front_full_size():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["lp_afiro", "lp_blend", "lp_bandm", "lp_agg"])
+NETLIB = ["lp_afiro", "lp_adlittle", "lp_blend", "lp_bandm", "lp_beaconfd", "lp_agg", "lp_agg2", "lp_agg3", "lp_bnl1", "lp_25fv47"]
+
+
+def _perturbed_outcomes(pat, d, i, eps, T, cores):
+    """(exit code, iterations) of T copies of instance i with ALL data perturbed by eps (relative), on the oracle and on the GPU."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1000 + int(i))
+    dd = [d[k][i][None, :] * (1 + eps * rng.uniform(-1, 1, (T,) + d[k][i].shape)) for k in ("Gpr", "Apr", "c", "h", "b")]
+    r = orc.batch_solve(pat, *dd, cores)
+    g = eicos_amd.BatchSolver(pat, T); g.update(*dd); gc = g.solve(); gi = g.info_arrays(); g.close()
+    return set(zip(r["exitcodes"].tolist(), r["iters"].tolist())), set(zip(gc.tolist(), gi["iter"].tolist()))
+
+
+def _within(res, outcomes):
+    """res = (code, iterations) lies inside the spread of `outcomes`: same exit code, iteration count within its range +-1."""
+    its = [it for (c, it) in outcomes if c == res[0]]
+    return bool(its) and min(its) - 1 <= res[1] <= max(its) + 1
+
+
+@pytest.mark.parametrize("name", NETLIB)
 def test_config3_lpnetlib_batch256(name):
     # BASELINE.json configs[3] at its stated size: batch 256 of perturbed instances per Netlib pattern (SURVEY.md 8d
-    # config 4); instance 0 is the unperturbed problem.  Exit code and iteration count against the oracle on a sample
-    # that includes every instance the GPU did not report OPTIMAL (perturbation makes some instances ill-posed).
+    # config 4), ALL TEN patterns, ALL 256 instances against the oracle: same exit code, iteration count +-1 (SURVEY 8d).
+    # Perturbation makes a few instances ill-posed: they stall for tens of passes and the pass in which the stall ends
+    # (full-accuracy exit, reduced-accuracy exit, iteration limit) is decided by rounding.  An instance may differ from the
+    # oracle ONLY if that is shown right here: under relative perturbations of its data by 1e-16 .. 1e-14 the ORACLE's own
+    # outcome must flip (>= 2 distinct outcomes) and the two sides must land in each other's spread; anything else is a bug.
+    import os
+    from oracle import oracle as orc
     pat, sets = load_fixture(name)
     B = 256
+    cores = len(os.sched_getaffinity(0))
     d = perturbed_batch(pat, sets[0], 0, B)
     g = eicos_amd.BatchSolver(pat, B)
     g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
     codes = g.solve(); ia = g.info_arrays(); x = g.solution(); y, z, s = g.duals()
+    g.close()
     assert codes[0] == 0
     opt = codes == 0
-    assert opt.sum() >= 0.8 * B
+    assert opt.sum() >= 0.6 * B
     assert np.all(ia["pres"][opt] < 1e-8) and np.all(ia["dres"][opt] < 1e-8)
     pc = np.einsum("ij,ij->i", d["c"], x); dc = -np.einsum("ij,ij->i", d["h"], z) - np.einsum("ij,ij->i", d["b"], y)
     assert np.all(np.abs(pc - dc)[opt] <= 1e-6 * np.maximum(1, np.abs(pc))[opt])
     assert np.all(s[opt] > -1e-9) and np.all(z[opt] > -1e-9)
-    sample = sorted(set(np.linspace(0, B - 1, 12).astype(int)) | set(np.flatnonzero(~opt)[:12]))
-    for i in sample:
-        o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
-        oc = o.solve(); oi = o.info()
-        assert codes[i] == oc, (name, i, codes[i], oc)
-        assert abs(ia["iter"][i] - oi["iter"]) <= 1, (name, i, ia["iter"][i], oi["iter"])
-        if oc == 0:
-            # |pcost| ~ 4e7 on lp_agg: agreement at the solver's own relative-gap tolerance when both sides stop at the same
-            # pass; when rounding moves the exit by one pass the objectives differ by that last step's progress
-            # (feasibility tolerances of 1e-8 relative to norms of 1e7 leave the objective itself determined to ~1e-7)
-            tol = 2e-7 if ia["iter"][i] == oi["iter"] else 5e-7
-            assert abs(ia["pcost"][i] - oi["pcost"]) <= tol * max(1.0, abs(oi["pcost"])), (name, i, ia["pcost"][i], oi["pcost"])
-        o.close()
+    r = orc.batch_solve(pat, d["Gpr"], d["Apr"], d["c"], d["h"], d["b"], cores)
+    it_o, it_g = r["iters"].astype(int), ia["iter"].astype(int)
+    differs = np.flatnonzero((r["exitcodes"] != codes) | (np.abs(it_o - it_g) > 1))
+    assert len(differs) <= 6, (name, differs)  # (at most 4 of 256 on any pattern when this was written)
+    for i in differs:
+        res_g, res_o = (int(codes[i]), int(it_g[i])), (int(r["exitcodes"][i]), int(it_o[i]))
+        spread_o, spread_g = set(), set()
+        for eps in (1e-16, 1e-15, 1e-14):
+            so, sg = _perturbed_outcomes(pat, d, i, eps, 32, cores)
+            spread_o |= so; spread_g |= sg
+        assert len(spread_o) >= 2, (name, i, res_g, res_o, "the oracle does not flip under perturbation: a real difference")
+        assert _within(res_g, spread_o) or _within(res_o, spread_g), (name, i, res_g, res_o, sorted(spread_o), sorted(spread_g))
+    same = np.setdiff1d(np.arange(B), differs)
+    okb = same[(codes[same] == 0) & (it_o[same] == it_g[same])]
+    # |pcost| ~ 4e7 on lp_agg: agreement at the solver's own relative-gap tolerance when both sides stop at the same pass
+    assert np.all(np.abs(ia["pcost"][okb] - r["pcost"][okb]) <= 2e-7 * np.maximum(1.0, np.abs(r["pcost"][okb]))), name
+
+
+def test_unbounded_max_sqrt_exit_distribution_matches_the_oracles():
+    # VERDICT r2 item 1a.  300 copies of unboundedMaxSqrt perturbed by 1e-16 (the batch of
+    # tests/test_oracle_golden.py::test_unbounded_max_sqrt_exit_is_rounding_determined): the oracle returns DINF on ~60 %
+    # and the safeguard exit NUMERICS on the rest.  The GPU must show the same two outcomes in comparable proportion
+    # (measured: 140 x DINF / 160 x NUMERICS vs the oracle's 182 / 118; before the cone-aware elimination order of round 3:
+    # 40 / 260, and 0 / 300 with both expansion columns eliminated first) -- and DINF on the exact data.
+    import os
+    from oracle import oracle as orc
+    pat, sets = load_fixture("unboundedMaxSqrt")
+    v = sets[0]
+    B = 300
+    rng = np.random.default_rng(1)
+    Gp, cp, hp = [], [], []
+    for _ in range(B):
+        pert = lambda a: a * (1 + 1e-16 * rng.uniform(-1, 1, a.shape))
+        Gp.append(pert(v.Gpr)); cp.append(pert(v.c)); hp.append(pert(v.h))
+    rp = lambda a: np.repeat(a[None, :], B, 0)
+    dd = (np.array(Gp), rp(v.Apr), np.array(cp), np.array(hp), rp(v.b))
+    r = orc.batch_solve(pat, *dd, len(os.sched_getaffinity(0)))
+    g = eicos_amd.BatchSolver(pat, B); g.update(*dd); codes = g.solve(); g.close()
+    assert set(codes) <= {2, 12, -2} and set(r["exitcodes"]) <= {2, 12, -2}
+    n_g, n_o = int((codes == 2).sum()), int((r["exitcodes"] == 2).sum())
+    assert 0.25 * B <= n_g <= 0.85 * B and 0.25 * B <= n_o <= 0.85 * B, (n_g, n_o)
+    g = eicos_amd.BatchSolver(pat, 1); g.update(*[a[None, :] for a in (v.Gpr, v.Apr, v.c, v.h, v.b)])
+    assert g.solve()[0] == 2  # test/unboundedProblems/unboundedMaxSqrt.h:33
     g.close()
 
 
@@ -583,12 +641,6 @@ def test_ecos_shim_runs_every_registered_reference_test(tmp_path, expected):
     with open(manifest, "w") as f:
         for name in ALL_FIXTURES:
             codes = list(expected[name]["exit_codes"])
-            if name in CHAOTIC:
-                # unboundedMaxSqrt: the reference's header asserts DINF (2), but the outcome is decided by rounding -- the
-                # CPU oracle itself flips between 2 and -2 under 1e-16 relative perturbations of the data
-                # (tests/test_oracle_golden.py::test_unbounded_max_sqrt_exit_is_rounding_determined) -- so the safeguard
-                # exit and the reduced-accuracy certificate are accepted too, as in test_fixture_matches_oracle
-                codes += [12, -2]
             f.write(f"{name} {os.path.join(ROOT, 'tests', 'golden', name + '.epb')} {','.join(str(c) for c in codes)}\n")
     out = subprocess.run([exe, str(manifest)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
