@@ -176,8 +176,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // lock-step pairs (see the LDS sizing below): wanted when there are more instances than CUs and two sweep vectors
         // (+ ~24 KB of tables) fit the 160 KB of LDS; they run as ONE 512-thread workgroup per CU
         int ki_want = 1; // measured: pairs do not pay on the MPC pattern -> opt-in through EICOS_KI=2
-        ki_want = env_int("EICOS_KI", ki_want, 1, 2);
-        h->ki = (ki_want == 2 && !S.tile && batch >= 2) ? 2 : 1;
+        h->ki = ki_want;
         // one workgroup per CU (batch <= CUs): latency-bound, more wavefronts per instance pay earlier (measured at batch 256 with
         // the 256-VGPR build of the 512-thread kernels: lp_blend / lp_adlittle, dim_K ~ 300: 256 threads +5..8 % over 128;
         // lp_beaconfd / lp_bandm / lp_agg, dim_K 763..1718: 512 threads +7..12 % over 256)
@@ -324,6 +323,23 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (!tile1) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
     else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); }
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
+    {   // level 0 of the factor program: the leaves of the elimination tree have no pairs; the kernel streams over their targets
+        // (diagonals first: the per-level task order is stable for equal pair counts) instead of walking their slices
+        D.fac_s1 = 0; D.fac_nd0 = 0; D.fac_nt0 = 0;
+        if (!tile1 && !planX.sl.empty() && env_int("EICOS_FAC_L0", 1, 0, 1)) {
+            size_t s1 = 1;
+            while (s1 < planX.sl.size() && !(planX.sl[s1].newlev & 1)) s1++;
+            const int nt0 = s1 < planX.sl.size() ? planX.sl[s1].row0 : (int)planX.target.size();
+            bool pairless = true, diag_first = true;
+            int nd0 = 0;
+            for (int t = 0; t < nt0; t++) {
+                const int tgt = planX.target[t];
+                if (S.tp[tgt + 1] != S.tp[tgt]) pairless = false;
+                if (tgt < S.N) { if (t != nd0) diag_first = false; nd0++; }
+            }
+            if (pairless && diag_first) { D.fac_s1 = (int)s1; D.fac_nd0 = nd0; D.fac_nt0 = nt0; }
+        }
+    }
     // KKT entries in target order: the factor's only per-target value stream; tile mode: the dense tile image
     D.w_Kt = Wl.add((tile1 ? (size_t)(TP.nb + TP.nt) * 256 : planX.target.size()) + 8);
     D.w_Kimg = tile1 ? D.w_Kt : (tile ? Wl.add((size_t)(TP.nb + TP.nt) * 256 + 8) : 0); // hybrid: the top block's image beside the scalar stream

@@ -107,6 +107,7 @@ struct DevPat {
     // K value in the instance slab, destination (>= 0: UB slot, < 0: -(diagonal index)-1) and UF slot
     const PackedSlice EICOS_GLOBAL *fac_sl;
     int fac_ns, fac_slots, fac_nt; // slices, pair slots, targets
+    int fac_s1, fac_nd0, fac_nt0;  // level 0 (no pairs): its slices are [0, fac_s1), its targets [0, fac_nt0), the first fac_nd0 of them diagonals
     int w_Kt;                      // [fac_nt] KKT entry of every target, in target order (workspace slab)
     gint_p v2t;                    // [nV] scaling-block entry -> its target
     gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;

@@ -796,13 +796,53 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
         ldK_g<KI, false>(Kt, t, o.kv);
         o.dst = ld_u32(P.fac_dst, t);
     };
+    // ---- level 0 (the leaves of the elimination tree: two thirds of the nodes of an MPC pattern) has no pairs at all:
+    // D_j = K_jj, U_ij = K_ij, L_ij = K_ij / D_j.  Two streaming passes over its targets (diagonals first, host: api.cpp)
+    // instead of a slice step per 256 targets: coalesced reads of the K stream, eight targets per thread in flight ----
+    const int sbeg = P.fac_s1;
+    if (P.fac_nt0 > 0) {
+        struct F0 { int dst; double kv[KI]; };
+        for_t_pre<T, 8>(P.fac_nd0, [&](int t) { F0 r; r.dst = ld_u32(P.fac_dst, t); ldK_g<KI, false>(Kt, t, r.kv); return r; }, [&](int t, const F0 &r) {
+            double val[KI], iv[KI];
 #pragma unroll
-    for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(d, ns - 1)), q[d]);
-    Sl pm = fmeta(min(FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
+            for (int k = 0; k < KI; k++) val[k] = r.kv[k];
+            if (r.dst >= IMG_BASE) { if constexpr (KI == 1) Kimg[r.dst - IMG_BASE] = val[0]; return; }
+            const int e = -r.dst - 1, j = e & (DIAG_POS - 1);
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                if (g_S.dyn_delta > 0.) { const double sg = (e & DIAG_POS) ? 1. : -1.; if (sg * val[k] <= g_S.dyn_eps) val[k] = sg * g_S.dyn_delta; }
+                iv[k] = 1. / val[k];
+                if (val[k] == 0.) inst_state<KI>(k).fl[FL_FATAL] = 1;
+            }
+            stK<KI>(D, j, val); stK<KI>(invD, j, iv);
+        });
+        __syncthreads();
+        struct F1 { int dst, dstF; double kv[KI], d[KI]; };
+        for_t_pre<T, 8>(P.fac_nt0 - P.fac_nd0, [&](int q) {
+            const int t = P.fac_nd0 + q;
+            F1 r; r.dst = ld_u32(P.fac_dst, t); r.dstF = ld_u32(P.fac_dstF, t);
+            ldK_g<KI, false>(Kt, t, r.kv); ldK<KI>(invD, ld_u32(P.fac_col, t), r.d);
+            return r;
+        }, [&](int q, const F1 &r) {
+            if (r.dst >= IMG_BASE) { if constexpr (KI == 1) Kimg[r.dst - IMG_BASE] = r.kv[0]; return; }
+            stK<KI>(U, r.dst, r.kv);
+            if (r.dstF >= 0) {
+                double o[KI];
+#pragma unroll
+                for (int k = 0; k < KI; k++) o[k] = r.kv[k] * r.d[k];
+                stK<KI>(UF, r.dstF, o);
+            }
+        });
+        __syncthreads();
+    }
+    if (sbeg < ns) {
+#pragma unroll
+    for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(sbeg + d, ns - 1)), q[d]);
+    Sl pm = fmeta(min(sbeg + FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
     double gu[ELL_KMAX][KI], gl[ELL_KMAX][KI];
     bool have = false;
-    for (int s0 = 0; s0 < ns; s0 += FAC_DEPTH) {
+    for (int s0 = sbeg; s0 < ns; s0 += FAC_DEPTH) {
 #pragma unroll
         for (int d = 0; d < FAC_DEPTH; d++) {
             const int sidx = s0 + d;
@@ -887,6 +927,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                 __syncthreads();
             }
         }
+    }
     }
     }
     if (tid == 0) {
@@ -2406,9 +2447,6 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
 template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        if constexpr (T >= 256) { // lock-step pairs: one LDS vector per instance (NLDS = 1), 256 or 512 threads
-            if (ki == 2) return idx16 ? f((const void *)k_solve<T, 1, true, 2>) : f((const void *)k_solve<T, 1, false, 2>);
-        }
         if (idx16) {
             if (nlds >= 2) return f((const void *)k_solve<T, 2, true, 1>);
             if (nlds == 1) return f((const void *)k_solve<T, 1, true, 1>);

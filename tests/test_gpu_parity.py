@@ -159,7 +159,7 @@ def test_dense_front_socp():
                                  {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_IDX16": "0"}, {"EICOS_IDX16": "0", "EICOS_NLDS": "0"},
                                  {"EICOS_TILES": "1"}, {"EICOS_TILES": "1", "EICOS_NLDS": "0"}, {"EICOS_TILES": "1", "EICOS_THREADS": "128", "EICOS_NLDS": "2"},
                                  {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"},
-                                 {"EICOS_KI": "2", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_THREADS": "256", "EICOS_TILES": "0"}, {"EICOS_KI": "2", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
+                                 {"EICOS_FAC_L0": "0"}, {"EICOS_FAC_L0": "0", "EICOS_TILES": "0", "EICOS_THREADS": "256"},
                                  {"EICOS_LDSRES": "0"}, {"EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_TILES": "0"},
                                  {"EICOS_TILES": "1", "EICOS_GTILES": "2"}, {"EICOS_TILES": "1", "EICOS_GTILES": "2", "EICOS_DUAL": "0", "EICOS_THREADS": "256"},
                                  {"EICOS_TILES": "1", "EICOS_GTILES": "0"},
@@ -170,14 +170,11 @@ def test_every_kernel_variant_matches_oracle(env, monkeypatch):
     # path, which is normally taken only when L is dense) through an LP, an SOC and an infeasible fixture
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    # (EICOS_KI=2: lock-step pairs -- two instances per workgroup; a batch of 3 also exercises a group with an empty slot)
-    B = 3 if "EICOS_KI" in env else 2
+    B = 2
     for name in ("lp_bandm", "issue98", "infeasible1", "update_data"):
         pat, sets = load_fixture(name)
         o = OracleSolver(pat, sets[0]); oc = o.solve(); oi = o.info()
         g = eicos_amd.BatchSolver(pat, B); g.update(*rep(sets[0], B))
-        if "EICOS_KI" in env:
-            assert g.dims()["instances_per_block"] == 2
         codes = g.solve(); gi = g.info()
         assert list(codes) == [oc] * B, (env, name, codes, oc)
         for i in range(B):
@@ -232,27 +229,6 @@ def test_lds_resident_variant_is_bit_identical_to_the_hbm_slab_kernel(monkeypatc
             g.close()
         for a_, b_ in zip(out[0], out[1]):
             assert np.array_equal(a_, b_, equal_nan=True), name
-
-
-def test_lockstep_pairs_match_oracle_on_a_heterogeneous_batch(monkeypatch):
-    # EICOS_KI=2 (opt-in): instances with different iteration counts and refinement counts share a workgroup -- the
-    # one that stops refining / finishes first must keep its result while its partner goes on; odd batch -> last group
-    # has an empty slot; SOC variant exercises the per-instance cone code between the lock-step stages
-    monkeypatch.setenv("EICOS_KI", "2")
-    pat, sets = load_fixture("MPC02")
-    for p_ in (pat, mpc_soc_variant(pat, sets[0])):
-        B = 37
-        d = feasible_batch(p_, sets[0], 0, B, seed=11)
-        ia = _check_batch(p_, d, B, 5, x_rtol=1e-7)
-        assert len(np.unique(ia["iter"])) > 1
-    # the same batch solved with single-instance workgroups gives the same iteration counts
-    monkeypatch.setenv("EICOS_KI", "1")
-    g = eicos_amd.BatchSolver(pat, 37); dd = feasible_batch(pat, sets[0], 0, 37, seed=11)
-    g.update(dd["Gpr"], dd["Apr"], dd["c"], dd["h"], dd["b"]); g.solve()
-    it1 = g.info_arrays()["iter"].copy(); g.close()
-    monkeypatch.setenv("EICOS_KI", "2")
-    g = eicos_amd.BatchSolver(pat, 37); g.update(dd["Gpr"], dd["Apr"], dd["c"], dd["h"], dd["b"]); g.solve()
-    assert np.array_equal(g.info_arrays()["iter"], it1); g.close()
 
 
 @pytest.mark.parametrize("seed,n,p,l,q", [(1, 12, 3, 6, [4, 3]), (2, 20, 5, 0, [5, 5, 5]), (3, 9, 0, 4, [6]),

@@ -62,10 +62,34 @@ __global__ __launch_bounds__(T, (T == 256 ? 3 : (T == 512 ? 2 : 4))) void k_lean
     }
 }
 
+template <int T, int Q>
+__global__ __launch_bounds__(T, (T == 256 ? 3 : (T == 512 ? 2 : 4))) void k_lean2(LeanDev L, const double *UF, const double *UB, const double *invD, size_t sUF, size_t sUB, size_t sD,
+                                                        const double *rhs, double *out, int N, int Npad, int reps) {
+    const lean::gbytes_p uf = (lean::gbytes_p)(UF + (size_t)blockIdx.x * sUF), ub = (lean::gbytes_p)(UB + (size_t)blockIdx.x * sUB);
+    const lean::gbytes_p id = (lean::gbytes_p)(invD + (size_t)blockIdx.x * sD);
+    double *ws = l_dyn;
+    const unsigned dummy = (unsigned)Npad * 8u; // T doubles of scratch behind the vector
+    const bool wave0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
+    for (int r = 0; r < reps; r++) {
+        for (int i = threadIdx.x; i < Npad; i += T) ws[i] = i < N ? rhs[i] * (1. + 1e-3 * r) : 0.;
+        __syncthreads();
+        lean::sweep2<T, true, false, Q>(L.fdesc, L.nfs, L.fidx, uf, id, ws, dummy);
+        if (wave0) {
+            lean::sweep2<T, true, true, Q>(L.fdesc + L.nfs, L.nfs_solo, L.fidx, uf, id, ws, dummy);
+            lean::sweep2<T, false, true, Q>(L.bdesc, L.nbs_solo, L.bidx, ub, id, ws, dummy);
+        }
+        __syncthreads();
+        lean::sweep2<T, false, false, Q>(L.bdesc + L.nbs_solo, L.nbs, L.bidx, ub, id, ws, dummy);
+        if (r == reps - 1) for (int i = threadIdx.x; i < N; i += T) out[(size_t)blockIdx.x * N + i] = ws[i];
+        __syncthreads();
+    }
+}
+
 int main(int argc, char **argv) {
     const std::string path = argc > 1 ? argv[1] : "tests/golden/MPC02.epb";
     const int grid = argc > 2 ? atoi(argv[2]) : 512, reps = argc > 3 ? atoi(argv[3]) : 200;
     const int T = argc > 4 ? atoi(argv[4]) : 256;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     ProblemPattern P;
     if (!read_epb(path, P)) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 2; }
     Symbolic S = analyze(P, -1, 0);
@@ -76,7 +100,7 @@ int main(int argc, char **argv) {
     // ---- values: a well-conditioned random unit-lower L (forward slot order), U = L D (backward slot order), 1/D ----
     unsigned long long st = 12345;
     auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return ((st >> 11) & 0xFFFFFFFFFFFFull) / (double)(1ull << 48); };
-    std::vector<double> Lv(S.nnzL), D(N), invD(N + 8, 0.0), rhs(N);
+    std::vector<double> Lv(S.nnzL), D(N), invD(N + 8 + 512, 0.0), rhs(N);
     std::vector<int> rowlen(N, 0);
     for (int j = 0; j < N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) rowlen[S.Li[e]]++;
     for (int j = 0; j < N; j++) for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) Lv[e] = (rnd() - 0.5) / std::max(1, rowlen[S.Li[e]]);
@@ -113,11 +137,11 @@ int main(int argc, char **argv) {
 
     // ---- device buffers: one factor copy per workgroup ----
     double *dUF, *dUB, *dD, *drhs, *dout;
-    CK(hipMalloc(&dUF, padF * sizeof(double) * grid)); CK(hipMalloc(&dUB, padB * sizeof(double) * grid)); CK(hipMalloc(&dD, (size_t)(N + 8) * sizeof(double) * grid));
+    CK(hipMalloc(&dUF, padF * sizeof(double) * grid)); CK(hipMalloc(&dUB, padB * sizeof(double) * grid)); CK(hipMalloc(&dD, (size_t)(N + 8 + 512) * sizeof(double) * grid));
     for (int g = 0; g < grid; g++) {
         CK(hipMemcpy(dUF + (size_t)g * padF, UF.data(), padF * sizeof(double), hipMemcpyHostToDevice));
         CK(hipMemcpy(dUB + (size_t)g * padB, UB.data(), padB * sizeof(double), hipMemcpyHostToDevice));
-        CK(hipMemcpy(dD + (size_t)g * (N + 8), invD.data(), (size_t)(N + 8) * sizeof(double), hipMemcpyHostToDevice));
+        CK(hipMemcpy(dD + (size_t)g * (N + 8 + 512), invD.data(), (size_t)(N + 8 + 512) * sizeof(double), hipMemcpyHostToDevice));
     }
     CK(hipMalloc(&drhs, N * sizeof(double))); CK(hipMemcpy(drhs, rhs.data(), N * sizeof(double), hipMemcpyHostToDevice));
     CK(hipMalloc(&dout, (size_t)grid * N * sizeof(double)));
@@ -136,7 +160,7 @@ int main(int argc, char **argv) {
         for (int it = 0; it < 2; it++) {
             CK(hipMemset(dout, 0, (size_t)grid * N * sizeof(double)));
             CK(hipEventRecord(e0));
-            launch_base(T, grid, bp, dUF, dUB, dD, padF, padB, (size_t)(N + 8), drhs, dout, N, Npad, pf.slots, pb.slots, reps);
+            launch_base(T, grid, bp, dUF, dUB, dD, padF, padB, (size_t)(N + 8 + 512), drhs, dout, N, Npad, pf.slots, pb.slots, reps);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (it) check("baseline tri_sweep", ms);
@@ -144,7 +168,7 @@ int main(int argc, char **argv) {
         free_base_plan(bp);
     }
     // ---- lean: descriptors + byte-offset indices ----
-    auto run_lean = [&](int Q) {
+    auto run_lean = [&](int Q, int ver) {
         auto build = [&](const TriPlan &pl, std::vector<int> &desc, std::vector<unsigned short> &idx) {
             // pad the slice list to a multiple of Q per part is already done for TRI_DEPTH; re-pad to Q
             std::vector<SliceMeta> sl = pl.sl;
@@ -168,8 +192,9 @@ int main(int argc, char **argv) {
             // split at n_a, pad both to multiples of Q with empty slices (lanes 0, all offsets -> zero region)
             std::vector<int> a(desc.begin(), desc.begin() + (size_t)n_a * 8), b(desc.begin() + (size_t)n_a * 8, desc.begin() + (size_t)(n_a + n_b) * 8);
             int e[8] = {0, (pl.slots + T) * 8, (pl.slots + T) * 8, (pl.slots + T) * 8, (pl.slots + T) * 8, 0, 0, 0};
-            while ((a.size() / 8) % Q) a.insert(a.end(), e, e + 8);
-            while ((b.size() / 8) % Q) b.insert(b.end(), e, e + 8);
+            const int mult = ver == 2 ? 12 : Q;
+            while ((a.size() / 8) % mult) a.insert(a.end(), e, e + 8);
+            while ((b.size() / 8) % mult) b.insert(b.end(), e, e + 8);
             n_a = (int)a.size() / 8; n_b = (int)b.size() / 8;
             desc = a; desc.insert(desc.end(), b.begin(), b.end());
         };
@@ -181,25 +206,32 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(dfd, fd.data(), fd.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dbd, bd.data(), bd.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dfi, fi.data(), fi.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dbi, bi.data(), bi.size() * 2, hipMemcpyHostToDevice));
         LeanDev L{(lean::cdesc_p)(unsigned long long)dfd, (lean::cdesc_p)(unsigned long long)dbd, nfs, nfs_solo, nbs_solo, nbs, (lean::gbytes_p)dfi, (lean::gbytes_p)dbi};
-        const size_t lds = (size_t)Npad * 8 + base_table_bytes(pf, pb); // same LDS footprint as the baseline (occupancy)
+        const size_t lds = (size_t)Npad * 8 + std::max(base_table_bytes(pf, pb), (size_t)T * 8); // same LDS footprint as the baseline (occupancy); scratch for the masked-off stores
         for (int it = 0; it < 2; it++) {
             CK(hipMemset(dout, 0, (size_t)grid * N * sizeof(double)));
             CK(hipEventRecord(e0));
             auto go = [&](auto kern) {
                 CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, 0, L, dUF, dUB, dD, padF, padB, (size_t)(N + 8), drhs, dout, N, Npad, reps);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, 0, L, dUF, dUB, dD, padF, padB, (size_t)(N + 8 + 512), drhs, dout, N, Npad, reps);
             };
+            if (ver == 1) {
             if (T == 256) { if (Q == 3) go(k_lean<256, 3>); else if (Q == 4) go(k_lean<256, 4>); else go(k_lean<256, 5>); }
             else if (T == 512) { if (Q == 3) go(k_lean<512, 3>); else if (Q == 4) go(k_lean<512, 4>); else go(k_lean<512, 5>); }
             else { if (Q == 3) go(k_lean<128, 3>); else if (Q == 4) go(k_lean<128, 4>); else go(k_lean<128, 5>); }
+            } else {
+            if (T == 256) { if (Q == 3) go(k_lean2<256, 3>); else if (Q == 4) go(k_lean2<256, 4>); else go(k_lean2<256, 6>); }
+            else if (T == 512) { if (Q == 3) go(k_lean2<512, 3>); else if (Q == 4) go(k_lean2<512, 4>); else go(k_lean2<512, 6>); }
+            else { if (Q == 3) go(k_lean2<128, 3>); else if (Q == 4) go(k_lean2<128, 4>); else go(k_lean2<128, 6>); }
+            }
             CK(hipGetLastError());
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            char tag[64]; snprintf(tag, sizeof tag, "lean Q=%d", Q);
+            char tag[64]; snprintf(tag, sizeof tag, "lean v%d Q=%d", ver, Q);
             if (it) check(tag, ms);
         }
         hipFree(dfd); hipFree(dbd); hipFree(dfi); hipFree(dbi);
     };
-    for (int Q : {3, 4, 5}) run_lean(Q);
+    for (int Q : {4}) run_lean(Q, 1);
+    for (int Q : {3, 4, 6}) run_lean(Q, 2);
     return 0;
 }
