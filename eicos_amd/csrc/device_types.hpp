@@ -63,7 +63,20 @@ static_assert(ELL_KMAX == 4, "the packed index entries hold four 16-bit indices 
 #define EICOS_FAC_DEPTH 2
 #endif
 constexpr int TRI_DEPTH = EICOS_TRI_DEPTH; // ... this many slices ahead of their use (plans are padded to a multiple)
+#ifndef EICOS_TRI_TRIP
+#define EICOS_TRI_TRIP 6
+#endif
+constexpr int TRI_TRIP = EICOS_TRI_TRIP;   // slices per trip of the (unrolled) sweep loops, see ELL_TRIP; plans are padded to a multiple
+static_assert(TRI_TRIP % TRI_DEPTH == 0, "the register queue rotates inside a trip");
 constexpr int ELL_DEPTH = EICOS_ELL_DEPTH; // same for the matrix-vector products
+// Slices per trip of the (unrolled) product loops; plans are padded to a multiple.  The compiler's s_waitcnt insertion is
+// exact inside a trip but drains the whole load queue at the loop head (s_waitcnt vmcnt(0)), so a trip of ELL_DEPTH slices
+// exposes a full memory round trip every ELL_DEPTH slices.
+#ifndef EICOS_ELL_TRIP
+#define EICOS_ELL_TRIP 6
+#endif
+constexpr int ELL_TRIP = EICOS_ELL_TRIP;
+static_assert(ELL_TRIP % ELL_DEPTH == 0, "the register queue rotates inside a trip");
 constexpr int FAC_DEPTH = EICOS_FAC_DEPTH; // and for the static part of the factor program (no padding needed)
 
 // Everything the kernels need to know about the (shared) pattern.  All pointers are device

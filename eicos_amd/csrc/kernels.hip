@@ -359,10 +359,10 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
     };
 #pragma unroll
     for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
-    for (int s0 = 0; s0 < ns; s0 += ELL_DEPTH) {
+    for (int s0 = 0; s0 < ns; s0 += ELL_TRIP) {
 #pragma unroll
-        for (int d = 0; d < ELL_DEPTH; d++) {
-            const int s = s0 + d;
+        for (int u = 0; u < ELL_TRIP; u++) {
+            const int d = u % ELL_DEPTH, s = s0 + u;
             const Sl m = meta(s);
             int ci[ELL_KMAX]; double cv[ELL_KMAX];
             const R cr = qr[d];
@@ -419,10 +419,10 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
     };
 #pragma unroll
     for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
-    for (int s0 = 0; s0 < ns; s0 += ELL_DEPTH) {
+    for (int s0 = 0; s0 < ns; s0 += ELL_TRIP) {
 #pragma unroll
-        for (int d = 0; d < ELL_DEPTH; d++) {
-            const int s = s0 + d;
+        for (int u = 0; u < ELL_TRIP; u++) {
+            const int d = u % ELL_DEPTH, s = s0 + u;
             const Sl m = meta(s);
             int ci[ELL_KMAX]; double cv[ELL_KMAX][KI]; R cr[KI];
 #pragma unroll
@@ -517,14 +517,14 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
         } else ldK_g<KI, false>(invD, r, o.d);
         ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
-    // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
+    // ns is a multiple of TRI_TRIP (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
 #pragma unroll
     for (int d = 0; d < TRI_DEPTH; d++) load(d < ns ? d : 0, q[d]);
-    for (int s0 = 0; s0 < ns; s0 += TRI_DEPTH) {
+    for (int s0 = 0; s0 < ns; s0 += TRI_TRIP) {
 #pragma unroll
-        for (int d = 0; d < TRI_DEPTH; d++) {
-            const int s = s0 + d;
+        for (int u = 0; u < TRI_TRIP; u++) {
+            const int d = u % TRI_DEPTH, s = s0 + u;
             const Slot c = q[d];
             load(min(s + TRI_DEPTH, ns - 1), q[d]);
             if (c.newlev) {
@@ -835,12 +835,20 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
         });
         __syncthreads();
     }
+#ifdef EICOS_FAC_TICKS
+    unsigned long long tq_ = (tid == 0) ? wall_clock64() : 0ull;
+    if (tid == 0) g_S.tick[8] += tq_ - tk0_;
+#define FTICK(slot) do { if (tid == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tq_; tq_ = t1_; } } while (0)
+#else
+#define FTICK(slot) do {} while (0)
+#endif
     if (sbeg < ns) {
 #pragma unroll
     for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(sbeg + d, ns - 1)), q[d]);
     Sl pm = fmeta(min(sbeg + FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
-    double gu[ELL_KMAX][KI], gl[ELL_KMAX][KI];
+    double gu[2][ELL_KMAX][KI], gl[2][ELL_KMAX][KI];
+    static_assert(FAC_DEPTH % 2 == 0, "operand register sets alternate with the queue slot");
     bool have = false;
     for (int s0 = sbeg; s0 < ns; s0 += FAC_DEPTH) {
 #pragma unroll
@@ -855,20 +863,19 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             const bool act = tid < c.lanes;
             // gathered factor values: slices of one level are independent, so the next slice's gathers are
             // issued before this slice's arithmetic waits on its own (one L2 round trip per level, not per slice)
+            // (two operand register sets, by the parity of the slice's queue slot: no copies between a slice's gathers and its use)
+            double (&cu)[ELL_KMAX][KI] = gu[d & 1], (&cl)[ELL_KMAX][KI] = gl[d & 1];
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, c.ia[u], gu[u]); ldK_g<KI, false>((gcdbl_p)UF, c.ib[u], gl[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, c.ia[u], cu[u]); ldK_g<KI, false>((gcdbl_p)UF, c.ib[u], cl[u]); }
             }
-            double cu[ELL_KMAX][KI], cl[ELL_KMAX][KI];
-#pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++)
-#pragma unroll
-                for (int k = 0; k < KI; k++) { cu[u][k] = gu[u][k]; cl[u][k] = gl[u][k]; }
             have = !c.last;
-            if (have) {
+            { // UNCONDITIONAL (when the next slice opens a new level its operands are not final yet: they are fetched again
+              // after the barrier, `have` = false): with the same number of loads in flight on every path the compiler can
+              // wait for this slice's operands with s_waitcnt vmcnt(8) instead of draining the queue at every slice
                 const FSlot &nx = q[(d + 1) % FAC_DEPTH];
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, nx.ia[u], gu[u]); ldK_g<KI, false>((gcdbl_p)UF, nx.ib[u], gl[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, nx.ia[u], gu[(d + 1) & 1][u]); ldK_g<KI, false>((gcdbl_p)UF, nx.ib[u], gl[(d + 1) & 1][u]); }
             }
             double acc[KI];
 #pragma unroll
@@ -908,23 +915,47 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                 } else stK<KI>(U, c.dst, val);
             }
             if (c.last) {
+                FTICK(9);
                 __syncthreads();
-                // phase B over the level's targets, four per thread in flight (index loads, then the two gathers)
-                struct PB { int dst, dstF; double u[KI], d[KI]; };
-                for_t_pre<T, 4>(lvl_t1 - lvl_t0, [&](int k) {
-                    const int t = lvl_t0 + k, dst = P.fac_dst[t];
-                    PB r; r.dst = dst; r.dstF = P.fac_dstF[t];
-                    ldK<KI>(U, (dst >= 0 && dst < IMG_BASE) ? dst : 0, r.u); ldK<KI>(invD, P.fac_col[t], r.d);
-                    return r;
-                }, [&](int k, const PB &r) {
-                    if (r.dst >= 0 && r.dstF >= 0) {
-                        double o[KI];
+                FTICK(10);
+                // phase B over the level's targets, four per thread in flight.  Two-stage pipeline: the (static) destination
+                // indices of the next four targets are loaded behind this round's gathers, so a round exposes ONE memory
+                // round trip (the gathers of the just-written U and 1/D), not two
+                {
+                    constexpr int UBN = 4;
+                    const int cnt = lvl_t1 - lvl_t0;
+                    int xd[UBN], xf[UBN], xc[UBN];
+                    auto lidx = [&](int i0) {
 #pragma unroll
-                        for (int kk = 0; kk < KI; kk++) o[kk] = r.u[kk] * r.d[kk];
-                        stK<KI>(UF, r.dstF, o);
+                        for (int u = 0; u < UBN; u++) {
+                            const int t = lvl_t0 + min(i0 + u * T, cnt - 1);
+                            xd[u] = ld_u32(P.fac_dst, t); xf[u] = ld_u32(P.fac_dstF, t); xc[u] = ld_u32(P.fac_col, t);
+                        }
+                    };
+                    lidx(tid);
+                    for (int i0 = tid; i0 < cnt; i0 += UBN * T) {
+                        int cd[UBN], cf[UBN]; double pu[UBN][KI], pd[UBN][KI];
+#pragma unroll
+                        for (int u = 0; u < UBN; u++) {
+                            cd[u] = xd[u]; cf[u] = xf[u];
+                            ldK<KI>(U, (cd[u] >= 0 && cd[u] < IMG_BASE) ? cd[u] : 0, pu[u]); ldK<KI>(invD, xc[u], pd[u]);
+                        }
+                        lidx(i0 + UBN * T);
+#pragma unroll
+                        for (int u = 0; u < UBN; u++) {
+                            double o[KI];
+#pragma unroll
+                            for (int kk = 0; kk < KI; kk++) {
+                                asm volatile("" : "+v"(pu[u][kk]), "+v"(pd[u][kk])); // (pins the gathers above the branch: a load whose only use sits under a branch is sunk into it)
+                                o[kk] = pu[u][kk] * pd[u][kk];
+                            }
+                            if (i0 + u * T < cnt && cd[u] >= 0 && cf[u] >= 0) stK<KI>(UF, cf[u], o);
+                        }
                     }
-                });
+                }
+                FTICK(11);
                 __syncthreads();
+                FTICK(10);
             }
         }
     }
@@ -2434,6 +2465,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
 #endif // !EICOS_LDSRES
 
 // ---- launchers (called from api.cpp) ----
+#ifndef EICOS_ISA_PROBE // (tools/dev/isa_probe.sh compiles single stage functions without the kernel instantiations)
 #if EICOS_LDSRES
 template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
     auto byT = [&](auto tc) {
@@ -2531,6 +2563,7 @@ hipError_t upload_pattern(int ps, const DevPat &P) {
     if (ps < 0 || ps >= MAX_PATTERNS) return hipErrorInvalidValue;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_pat), &P, sizeof(DevPat), (size_t)ps * sizeof(DevPat), hipMemcpyHostToDevice);
 }
+#endif // EICOS_ISA_PROBE
 #if EICOS_LDSRES
 } // namespace ldsres
 #else

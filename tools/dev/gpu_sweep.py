@@ -26,4 +26,5 @@ print(f"{name} B={B} {tag}: ms={min(ms):.2f} (all {['%.1f'%m for m in ms]}) iter
 if B <= dm['resident_blocks']:
     tr = g.debug_trace(0)[-1]
     print("   phase us (inst 0): factor %.0f ldl(excl fwd) %.0f fwd %.0f kkt-resid %.0f kkt-post %.0f resid-stage %.0f total %.0f" % (tr[0], tr[1], tr[5], tr[2], tr[3], tr[4], tr[6]), " per iter:", ["%.0f" % (v / max(1, ia['iter'][0])) for v in (tr[0], tr[1], tr[5], tr[2], tr[3], tr[4], tr[6])], "nsolve", ia['n_ldlsolve'][0], "nfactor", ia['n_factor'][0])
-    print("   factor us per call: hybrid tile part %.1f (of %.1f)" % (tr[7] / max(1, ia['n_factor'][0]), tr[0] / max(1, ia['n_factor'][0])))
+    nf = max(1, ia['n_factor'][0])
+    print("   factor us per call: [8] level 0 / hybrid tile part %.1f  [9] phase A %.1f  [10] barriers %.1f  [11] phase B %.1f  (of %.1f)" % (tr[7] / nf, tr[8] / nf, tr[9] / nf, tr[10] / nf, tr[0] / nf))

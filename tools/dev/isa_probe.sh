@@ -1,0 +1,12 @@
+#!/bin/bash
+# ISA of ONE stage function of kernels.hip in seconds (the full file takes two minutes):
+#   tools/dev/isa_probe.sh 'stage_factor<256, 1, true, 1>(ps, (gdbl_p)w)' > /tmp/x.s      (ps: int, w: double *, i: double *)
+set -e
+d=$(mktemp -d)
+cat > $d/p.hip <<EOT
+#define EICOS_ISA_PROBE 1
+#include "$(cd "$(dirname "$0")/../.." && pwd)/eicos_amd/csrc/kernels.hip"
+namespace eicos { __global__ __launch_bounds__(${T:-256}, ${WPE:-3}) void probe(int ps, double *w, double *i, int a, int b) { $1; } }
+EOT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off --cuda-device-only -S -o - $d/p.hip 2>&1
+rm -rf $d
