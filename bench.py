@@ -179,7 +179,7 @@ class Job:
                          "kernel": "k_solve", "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": abytes},
         }
 
-    def cpu_baseline(self, ia):
+    def cpu_baseline(self, ia, target_s=30.0):
         """CPU oracle (a port, NOT the EiCOS binary: Eigen is absent) on a bounded sample of the same workload."""
         from oracle import oracle as orc
         data, pat, B = self.data, self.pat, self.B
@@ -192,7 +192,7 @@ class Job:
         npil = int(min(B, cores))
         r0 = run(0, npil)
         per_inst_cpu = (r0["seconds"] + r0["update_seconds"]) * min(cores, npil) / npil
-        want = int(max(npil, min(4 * B, 30.0 / max(per_inst_cpu, 1e-9))))
+        want = int(max(npil, min(4 * B, target_s / max(per_inst_cpu, 1e-9))))
         reps, ns = (1, want) if want <= B else (min(4, -(-want // B)), B)
         tot_iters, wall, match, maxdiff = 0, 0.0, True, 0
         for _ in range(reps):
@@ -213,6 +213,56 @@ class Job:
                 "per_core": float(tot_iters / wall / cores)}
 
 
+def refinement_profile(job, n=16):
+    """Per-solve refinement counts of the first n instances, GPU vs oracle (Information.nitref1..3 of the LAST pass and the
+    totals n_ldlsolve / n_factor of the whole solve): explains the LDL solves per pass of a workload -- every solveKKT costs
+    1 + k_ref solves, k_ref decided by the reference's stopping rules (src/eicos.cpp:1579-1593) on the refinement residual."""
+    from oracle.oracle import OracleSolver
+    from eicos_amd.problem_io import Values
+    d, ia = job.data, job.ia_first
+    n = min(n, job.B)
+    rows, same = [], 0
+    for i in range(n):
+        o = OracleSolver(job.pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
+        o.solve(); oi = o.info(); o.close()
+        g = (int(ia["n_ldlsolve"][i]), int(ia["iter"][i]), int(ia["nitref1"][i]), int(ia["nitref2"][i]), int(ia["nitref3"][i]))
+        c = (int(oi["n_ldlsolve"]), int(oi["iter"]), int(oi["nitref1"]), int(oi["nitref2"]), int(oi["nitref3"]))
+        same += g == c
+        rows.append({"gpu": g, "oracle": c})
+    nf_g = ia["n_factor"][:n].astype(np.int64)
+    calls = int((2 + 3 * (nf_g - 1)).sum())  # solveKKT calls: two initialisation solves + three per pass that factorised
+    tot_g = sum(r["gpu"][0] for r in rows); tot_o = sum(r["oracle"][0] for r in rows)
+    passes = int(nf_g.sum())
+    return {"instances": n, "identical_(n_ldlsolve,iter,nitref1,nitref2,nitref3)": same,
+            "ldl_solves_gpu": tot_g, "ldl_solves_oracle": tot_o, "solveKKT_calls": calls,
+            "mean_refinement_steps_per_solveKKT": tot_g / max(1, calls) - 1.0,
+            "ldl_solves_per_factorisation": tot_g / max(1, passes), "first": rows[:2]}
+
+def run_config(args, name, pattern, batch, local_rank, perturb=False, soc=False, steps=3, warmup=1, cpu_s=6.0):
+    """One additional BASELINE.json config on this GPU, timed like the headline (updateData + solve per step): its own
+    value, roofline and CPU baseline (a smaller sample than the headline's, so that the default run stays within minutes)."""
+    import copy
+    import eicos_amd
+    a = copy.copy(args)
+    a.perturb, a.resolve, a.warm = perturb, 0.0, 0.0
+    if pattern == "dense-front":
+        from eicos_amd.generate import dense_front_pattern
+        pat, base = dense_front_pattern(2000, 32, 64)
+        sets = [base]
+    else:
+        pat, sets = eicos_amd.read_problem(os.path.join(ROOT, "tests", "golden", pattern + ".epb"))
+    job = Job(a, pat, sets, 0, batch, local_rank, soc=soc)
+    res = job.run(None, steps, warmup)
+    rep = job.report(res, steps, f"{pattern}{'-SOC' if soc else ''} batch={batch}")
+    rep["workload"] = f"{pattern}{'-SOC' if soc else ''}, batch {batch}, {'perturbed (c,h)' if perturb else 'strictly feasible generated (c,h,b)'}"
+    rep["exit_codes"] = {str(k): int(v) for k, v in zip(*np.unique(res["ia"]["exitcode"], return_counts=True))}
+    if not args.no_cpu_baseline:
+        rep["cpu_baseline"] = job.cpu_baseline(job.ia_first, cpu_s)
+        rep["gpu_over_cpu"] = rep["value"] / rep["cpu_baseline"]["value"]
+    job.solver.close()
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +278,8 @@ def main():
     ap.add_argument("--perturb", action="store_true", help="LPnetlib-style batch: perturb c,h of the fixture "
                     "(SURVEY.md 8d config 4) instead of generating strictly feasible (c,h,b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the additional BASELINE.json configs of the default N = 1 line "
+                    "(dense-front batch 512, LPnetlib batch 256, MPC02 batch 512)")
     ap.add_argument("--resolve", type=float, default=0.0, metavar="EPS", help="MPC-style re-solves: steps alternate between "
                     "the batch and a copy with c, h perturbed by EPS (relative), so every solve follows an updateData with "
                     "nearby data (not the headline workload)")
@@ -321,6 +373,7 @@ def main():
                                    f"(l={sjob.pat.l}), same A/G values, generated strictly feasible (c,h,b), same instances and step")
             if world == 1 and not args.no_cpu_baseline:
                 soc_rep["cpu_baseline"] = sjob.cpu_baseline(sjob.ia_first)
+                soc_rep["refinement_vs_oracle"] = refinement_profile(sjob)
         sjob.solver.close()
     else:
         main_rep = job.report(res, args.steps, f"{args.pattern}{'-SOC' if args.soc else ''} batch={B}") if rank == 0 else None
@@ -346,6 +399,15 @@ def main():
             out["cpu_baseline"] = cpu
         if soc_rep is not None:
             out["soc"] = soc_rep
+        if default_workload and world == 1 and not args.no_configs and not args.soc and args.batch is None and args.total is None:
+            # every other BASELINE.json config, driver-run: configs[4] dense-front (MFMA path), configs[3] LPnetlib (three of the
+            # ten patterns: the smallest, a mid-size hybrid one, the deepest), and the per-GPU share of configs[2]
+            cfg = {}
+            cfg["dense_front_b512"] = run_config(args, "dense_front", "dense-front", 512, local_rank, steps=2, warmup=1, cpu_s=8.0)
+            for nm in ("lp_afiro", "lp_bandm", "lp_25fv47"):
+                cfg[f"lpnetlib_{nm}_b256"] = run_config(args, nm, nm, 256, local_rank, perturb=True, steps=5, warmup=1, cpu_s=4.0)
+            cfg["mpc_b512"] = run_config(args, "mpc_b512", "MPC02", 512, local_rank, steps=5, warmup=1, cpu_s=6.0)
+            out["configs"] = cfg
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

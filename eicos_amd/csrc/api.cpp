@@ -154,6 +154,12 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     h->batch = batch; h->device = device; h->npairs = S.npairs;
     if (S.npairs >= (int64_t)1 << 31) { delete h; return fail(EICOS_E_UNSUPPORTED, "factor program exceeds 2^31 pairs"); }
     DevPat &D = h->dp;
+    if (S.tile) { // the tile image, the tile arrays of L and their workspace offsets are indexed with 32-bit ints
+        const long long img = ((long long)h->tiles.nb + h->tiles.nt) * 256;
+        if (img >= IMG_BASE || (long long)S.N + img >= DIAG_POS / 2 || 3 * img * (long long)sizeof(double) > (8LL << 30)) {
+            delete h; return fail(EICOS_E_UNSUPPORTED, "dense-front pattern too large: the tile image of L exceeds the per-workgroup workspace budget");
+        }
+    }
     const bool tile = S.tile != 0;  // some part of L lives in 16 x 16 tiles: all of it (S.tile == 1) or the top block (hybrid, == 2)
     const bool tile1 = S.tile == 1; // pure tile mode: no scalar programs at all
     const TilePlan &TP = h->tiles;
@@ -184,7 +190,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
                          : throughput_bound ? (dimK < 400 ? 128 : 256)
                                             : (dimK < 250 ? 128 : (dimK < 700 ? 256 : 512));
         const int t = env_int("EICOS_THREADS", dflt, 128, 512);
-        h->threads = (t == 128 || t == 256 || t == 512) ? t : dflt;
+        if (t != 128 && t != 256 && t != 512) { delete h; return fail(EICOS_E_INVALID, "EICOS_THREADS must be 128, 256 or 512"); }
+        h->threads = t;
         if (h->threads < 256) h->ki = 1;
     }
     // ---- slab layouts ----
@@ -323,6 +330,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (!tile1) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
     else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); }
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
+    if ((long long)planB.slots + 1 >= IMG_BASE || (long long)S.N >= DIAG_POS / 2) { delete h; return fail(EICOS_E_UNSUPPORTED, "pattern too large for the factor program's destination codes"); }
     {   // level 0 of the factor program: the leaves of the elimination tree have no pairs; the kernel streams over their targets
         // (diagonals first: the per-level task order is stable for equal pair counts) instead of walking their slices
         D.fac_s1 = 0; D.fac_nd0 = 0; D.fac_nt0 = 0;
@@ -477,10 +485,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     put(D.tl_blev, TP.blev_ptr); put(D.tl_tgt_lev, TP.tgt_lev_ptr); put(D.tl_tgt, TP.tgt); put(D.tl_tp, TP.tp_ptr);
     put(D.tl_pa, TP.pa); put(D.tl_pb, TP.pb); put(D.tl_pk, TP.pk); put(D.tl_fin_lev, TP.fin_lev_ptr); put(D.tl_fin, TP.fin);
     TileSweeps TSW;
-    if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_PF);
+    if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_STRIP);
     put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
     TileFactorOps TFO;
-    if (tile) TFO = build_tile_factor_ops(TP, h->threads / 64, TILE_FPF);
+    if (tile) TFO = build_tile_factor_ops(TP, h->threads / 64, TILE_FTRIP);
     put(D.tl_facops, TFO.ops); put(D.tl_facptr, TFO.ptr);
     put(D.tl_ident, TP.ident);
     put(D.tl_trow, TP.t_row); put(D.tl_tcol, TP.t_col); put(D.tl_tc_ptr, TP.tc_ptr); put(D.tl_tr_ptr, TP.tr_ptr); put(D.tl_tr_tile, TP.tr_tile);
@@ -581,6 +589,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds, &bpc));
     }
     bpc = std::max(1, std::min(bpc, 8));
+    HIP_TRY_H(update_set_max_lds()); // (per handle = per device, after hipSetDevice: the entry-parallel updateData kernels use up to 160 KB of dynamic LDS)
     {
         // Workgroups per CU for this batch.  A workgroup slows down by about half of its stand-alone time per
         // co-resident workgroup (measured, MPC02: 13 / 19.8 / 25.8 ms per instance at 1 / 2 / 3 per CU), and a last,

@@ -39,8 +39,9 @@ constexpr int DEVINFO_DOUBLES = 32;
 // over the same rows: `more` = another sub-slice of these rows follows, `cont` = this one continues the previous.
 struct SliceMeta { int row0, cnt, lg, K, off, newlev, more, cont; }; // host form (plan building, host emulation)
 constexpr int ELL_KMAX = 4;  // entries per lane that are software-prefetched
-constexpr int DIAG_POS = 1 << 30;
-constexpr int IMG_BASE = 1 << 28; // factor program, hybrid: dst >= IMG_BASE = entry (dst - IMG_BASE) of the top block's tile image // factor program, diagonal targets: dst = -(j + 1) - (pivot sign is + ? DIAG_POS : 0)
+// Destination codes of the factor program (DevPat::fac_dst), checked against each other in eicos_batch_create:
+constexpr int DIAG_POS = 1 << 30; // diagonal targets: dst = -(j + 1) - (quasi-definite sign of pivot j is + ? DIAG_POS : 0)
+constexpr int IMG_BASE = 1 << 28; // hybrid: dst >= IMG_BASE = entry (dst - IMG_BASE) of the top block's tile image; UB slots stay below IMG_BASE
 
 // Device form of a slice: 16 bytes = one ds_read_b128 / s_load_dwordx4.  off16 = index of the slice's first lane
 // in the plan's packed 16-bit gather-index array (one 8-byte entry = ELL_KMAX indices per lane), see api.cpp.
@@ -174,6 +175,15 @@ constexpr int TILE_PF = 6;          // tile loads in flight per wavefront in the
 #define EICOS_TILE_FPF 3
 #endif
 constexpr int TILE_FPF = EICOS_TILE_FPF;         // operations (two tiles + a D block each) in flight per wavefront in the tile factorisation
+#ifndef EICOS_TILE_FTRIP
+#define EICOS_TILE_FTRIP EICOS_TILE_FPF
+#endif
+#ifndef EICOS_TILE_STRIP
+#define EICOS_TILE_STRIP 6
+#endif
+constexpr int TILE_FTRIP = EICOS_TILE_FTRIP;     // operations per trip of the unrolled loops (factor / sweeps): see ELL_TRIP; op lists are padded to a multiple
+constexpr int TILE_STRIP = EICOS_TILE_STRIP;
+static_assert(TILE_FTRIP % TILE_FPF == 0 && TILE_STRIP % TILE_PF == 0, "the register queues rotate inside a trip");
 constexpr int FOP_INIT = 1, FOP_END = 2, FOP_PAD = 4, FOP_SHIFT = 4; // tile factor op flags: start a target from its K tile / finish it / padding; target id above
 constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)

@@ -1025,12 +1025,13 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
             for (int u = 0; u < TILE_FPF; u++) load(o0 + u, qa[u], qb[u], qd[u]);
         }
         d4_t acc = {0., 0., 0., 0.};
-        for (int o = o0; o < o1; o += TILE_FPF) {
+        for (int o = o0; o < o1; o += TILE_FTRIP) {
 #pragma unroll
-          for (int u = 0; u < TILE_FPF; u++) {
-            const i4_t op = c_fops[o + u];
+          for (int uu = 0; uu < TILE_FTRIP; uu++) {
+            const int u = uu % TILE_FPF;
+            const i4_t op = c_fops[o + uu];
             const d4_t a = qa[u], b = qb[u], dd = qd[u];
-            load(o + u + TILE_FPF, qa[u], qb[u], qd[u]);
+            load(o + uu + TILE_FPF, qa[u], qb[u], qd[u]);
             const int fl = op.w, tg = fl >> FOP_SHIFT;
             if (fl & FOP_INIT) acc = a;
             else if (!(fl & FOP_PAD)) {
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
         cint4_p ops = (cint4_p)(unsigned long long)ops_i;
         cint_p ptr = as_const(ptr_g);
         for (int v = 0; v < P.nblev; v++) {
-            const int o0 = ptr[v * NW + wave], o1 = ptr[v * NW + wave + 1]; // (o1 - o0) is a multiple of TILE_PF
+            const int o0 = ptr[v * NW + wave], o1 = ptr[v * NW + wave + 1]; // (o1 - o0) is a multiple of TILE_STRIP
             d4_t qv[TILE_PF];
             // unconditional: a conditional load would force s_waitcnt vmcnt(0) at every join and serialise the queue
             auto load = [&](int o, d4_t &x) {
@@ -1170,12 +1171,13 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
 #pragma unroll
                 for (int u = 0; u < TILE_PF; u++) load(o0 + u, qv[u]);
             }
-            for (int o = o0; o < o1; o += TILE_PF) {
+            for (int o = o0; o < o1; o += TILE_STRIP) {
 #pragma unroll
-                for (int u = 0; u < TILE_PF; u++) {
-                    const i4_t op = ops[o + u];
+                for (int uu = 0; uu < TILE_STRIP; uu++) {
+                    const int u = uu % TILE_PF;
+                    const i4_t op = ops[o + uu];
                     const d4_t cv = qv[u];
-                    load(o + u + TILE_PF, qv[u]);
+                    load(o + uu + TILE_PF, qv[u]);
                     const int fl = op.w, vb = op.y;
                     if (!(fl & TOP_DIAG)) {
 #pragma unroll
@@ -2473,7 +2475,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
         if (idx16) return nlds >= 2 ? f((const void *)k_solve<T, 2, true, 1>) : f((const void *)k_solve<T, 1, true, 1>);
         return nlds >= 2 ? f((const void *)k_solve<T, 2, false, 1>) : f((const void *)k_solve<T, 1, false, 1>);
     };
-    return byT(std::integral_constant<int, 128>{}); // (small patterns run 128 threads; 64 measured no faster)
+    return byT(std::integral_constant<int, 128>{}); // (small patterns run 128 threads)
 }
 #else
 template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
@@ -2517,15 +2519,17 @@ hipError_t launch_update(int ps, double *inst, int first, int count, const doubl
                          const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, int vals_in_lds, hipStream_t st) {
     if (count <= 0) return hipSuccess;
     if (lds_bytes > 0 && !vals_in_lds) { // entry-parallel, maxima in LDS, values streamed in place in the slab (several workgroups per CU)
-        static bool attr_set2 = false;
-        if (!attr_set2) { (void)hipFuncSetAttribute((const void *)k_update_lds<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr_set2 = true; }
         hipLaunchKernelGGL((k_update_lds<512, false>), dim3(grid), dim3(512), lds_bytes, st, ps, inst, first, count, Gpr, Apr, c, h, b);
     } else if (lds_bytes > 0) { // values + maxima fit LDS: the entry-parallel kernel, 512 threads, one workgroup per CU at a time
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_update_lds<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr_set = true; }
         hipLaunchKernelGGL((k_update_lds<512, true>), dim3(grid), dim3(512), lds_bytes, st, ps, inst, first, count, Gpr, Apr, c, h, b);
     } else hipLaunchKernelGGL(k_update<256>, dim3(grid), dim3(256), 0, st, ps, inst, first, count, Gpr, Apr, c, h, b, scratch);
     return hipGetLastError();
+}
+// the dynamic-LDS ceiling of the two entry-parallel updateData kernels, set once per handle on the handle's device
+hipError_t update_set_max_lds() {
+    hipError_t e = hipFuncSetAttribute((const void *)k_update_lds<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_update_lds<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 }
 hipError_t launch_debug_factor(int ps, double *inst, double *work, int i, int threads, size_t dyn_lds, hipStream_t st) {
     auto big = [&](const void *fn) { if (dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds); };
