@@ -39,12 +39,10 @@ struct eicos_batch {
     Symbolic sym;
     DevPat dp{};
     int batch = 0, device = 0, threads = 256, grid = 0, upd_grid = 0;
-    int ki = 1;               // instances per workgroup solved in lock-step (DevPat::w_split)
     int order_min = 0;        // batches up to this size (one instance per CU) are solved in identity order, larger ones longest-first
-    bool last_ordered = false; int last_kis = 1; // how the most recent solve was launched (eicos_debug_trace)
+    bool last_ordered = false; // how the most recent solve was launched (eicos_debug_trace)
     size_t upd_lds = 0;       // > 0: updateData runs the entry-parallel kernel with this much dynamic LDS (values + maxima)
     int upd_vals_lds = 1;     // 1: its working copy of the values is in LDS too; 0: streamed in place in the instance slab
-    size_t dyn_lds1 = 0; int nlds1 = 0; // launch shape of the single-instance kernel on the same workspace (warm start)
     int *d_pattern = nullptr;
     int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
     size_t dyn_lds = 0;
@@ -179,20 +177,13 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device < 0 ? 0 : device) == hipSuccess) n_cu = pr.multiProcessorCount; }
         // (sparse factors only: with ~50 entries per row of L -- the dense-front config -- 512 threads stay ahead)
         const bool throughput_bound = batch > n_cu && (long long)S.nnzL < 16LL * S.N;
-        // lock-step pairs (see the LDS sizing below): wanted when there are more instances than CUs and two sweep vectors
-        // (+ ~24 KB of tables) fit the 160 KB of LDS; they run as ONE 512-thread workgroup per CU
-        int ki_want = 1; // measured: pairs do not pay on the MPC pattern -> opt-in through EICOS_KI=2
-        h->ki = ki_want;
         // one workgroup per CU (batch <= CUs): latency-bound, more wavefronts per instance pay earlier (measured at batch 256 with
         // the 256-VGPR build of the 512-thread kernels: lp_blend / lp_adlittle, dim_K ~ 300: 256 threads +5..8 % over 128;
         // lp_beaconfd / lp_bandm / lp_agg, dim_K 763..1718: 512 threads +7..12 % over 256)
-        const int dflt = h->ki == 2 ? 512
-                         : throughput_bound ? (dimK < 400 ? 128 : 256)
-                                            : (dimK < 250 ? 128 : (dimK < 700 ? 256 : 512));
+        const int dflt = throughput_bound ? (dimK < 400 ? 128 : 256) : (dimK < 250 ? 128 : (dimK < 700 ? 256 : 512));
         const int t = env_int("EICOS_THREADS", dflt, 128, 512);
         if (t != 128 && t != 256 && t != 512) { delete h; return fail(EICOS_E_INVALID, "EICOS_THREADS must be 128, 256 or 512"); }
         h->threads = t;
-        if (h->threads < 256) h->ki = 1;
     }
     // ---- slab layouts ----
     SlabLayout L;
@@ -286,8 +277,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (GT.on) { // G tile products: partial column sums per tile, G'z per column, G x per row; two right-hand sides
         D.w_gpart = Wl.add((size_t)GT.nt * 16 * 2); D.w_gx = Wl.add((size_t)S.n * 2); D.w_gz = Wl.add((size_t)S.m * 2);
     } else D.w_gpart = D.w_gx = D.w_gz = 0;
-    // ---- from here on: arrays shared KI-interleaved by the instances of a lock-step workgroup (DevPat::w_split) ----
-    D.w_split = (int)Wl.size;
+    // ---- the arrays of the factorisation / KKT solve ----
     D.w_xk = Wl.add((size_t)NV + 16); D.w_ek = Wl.add((size_t)NV + 16); D.w_dxr = Wl.add(NV);
     D.w_D = Wl.add(NV); D.w_invD = Wl.add(NV); // w_UF / w_UB are added once the slice plans are known
 
@@ -520,7 +510,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
         const size_t scratch = tile ? (size_t)(h->threads / 64) * TILE_SCR * sizeof(double) : 0;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
-        const int wgs_by_regs = h->ki == 2 ? 1 : (h->threads == 256 ? 3 : (h->threads == 512 ? 2 : 4)) * 4 / (h->threads / 64); // waves_per_eu<T, KI>() of kernels.hip
+        const int wgs_by_regs = (h->threads == 256 ? 3 : (h->threads == 512 ? 2 : 4)) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
             return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + scratch + lds_static)));
         };
@@ -538,28 +528,18 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         int want = fit;
         if (batch > prop.multiProcessorCount && fit == 2 && 2 * (vec + meta + 4096) <= 160 * 1024) want = 1;
         h->nlds = std::max(0, std::min(fit, env_int("EICOS_NLDS", want, 0, 2)));
-        // Lock-step pairs: with more instances than CUs, one 512-thread workgroup per CU solves TWO
-        // instances at once -- slice decoding, index loads, barriers and the dependent chain of the sparse sweeps are shared,
-        // values / gathers are 16-byte accesses over interleaved arrays.  Needs both sweep vectors in LDS.
-        int ki = h->ki; // wanted (decided with the workgroup size, above); needs both vectors + the tables in LDS
-        if (ki != 2 || tile || fit < 2 || h->threads < 256 || batch < 2) ki = 1; // (tile / hybrid factor paths are single-instance)
-        h->ki = ki;
         // Dual right-hand-side solves (the two independent systems of the initialisation and of every pass share one
         // sweep over the factor): needs two vectors in LDS.  Pure tile mode (bandwidth-bound on streaming L and G): always.
         // Scalar / hybrid programs: when the batch fits one workgroup per CU -- the sweeps are then a dependent chain of level
         // steps, and a step for two right-hand sides costs far less than two steps
-        int dual = (fit == 2 && ki == 1 && (tile1 || batch <= prop.multiProcessorCount)) ? 1 : 0;
+        int dual = (fit == 2 && (tile1 || batch <= prop.multiProcessorCount)) ? 1 : 0;
         dual = env_int("EICOS_DUAL", dual, 0, 1);
-        if (fit < 2 || ki != 1) dual = 0;
+        if (fit < 2) dual = 0;
         if (dual) h->nlds = 1;
         D.dual = dual;
-        if (ki == 2) h->nlds = 1;
-        const int nvec = (ki == 2 || dual) ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS
-        // (the single-instance kernel on a pair handle -- warm start -- runs with the same LDS layout)
-        h->nlds1 = h->nlds;
+        const int nvec = dual ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
         h->dyn_lds = h->nlds >= 1 ? (size_t)nvec * vec + meta : scratch;
-        h->dyn_lds1 = h->dyn_lds;
         D.lds_tab = h->nlds >= 1 ? nvec * D.Npad : 0;
         D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
         // LDS-resident variant (small patterns, kernels_ldsres.hip): when the instance slab and the workspace slab fit LDS
@@ -568,25 +548,23 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // DESIGN.md 5.1).  Only for batches that fit the grid in one round -- beyond that the eight small workgroups per CU
         // of the HBM-slab kernel hide more latency than the <= 3 that LDS holds here (measured, lp_afiro batch 2048).
         h->ldsres = 0; D.lr_inst = D.lr_work = 0;
-        if (!tile && ki == 1 && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1, 0, 1)) {
+        if (!tile && h->nlds >= 1 && h->threads == 128 && env_int("EICOS_LDSRES", 1, 0, 1)) {
             const size_t base = (h->dyn_lds + 15) & ~(size_t)15, islab = (D.inst_stride + 1) & ~(size_t)1, wslab = (D.work_stride + 1) & ~(size_t)1;
             const size_t total = base + (islab + wslab) * sizeof(double);
             const size_t per_cu = (160 * 1024) / (total + lds_static); // workgroups per CU that LDS allows
             if (per_cu >= 1 && (size_t)batch <= per_cu * (size_t)prop.multiProcessorCount) {
                 h->ldsres = 1; D.lr_inst = (int)(base / sizeof(double)); D.lr_work = D.lr_inst + (int)islab;
-                h->dyn_lds = h->dyn_lds1 = total;
+                h->dyn_lds = total;
             }
         }
     }
-    D.group_stride = (size_t)h->ki * D.work_stride;
     int bpc = 1;
     if (h->ldsres) {
-        HIP_TRY_H(ldsres::solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, 1, h->dyn_lds));
-        HIP_TRY_H(ldsres::solve_occupancy(h->threads, h->nlds, h->dp.idx16, 1, h->dyn_lds, &bpc));
+        HIP_TRY_H(ldsres::solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
+        HIP_TRY_H(ldsres::solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
     } else {
-        HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds));
-        if (h->ki > 1) HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds1, h->dp.idx16, 1, h->dyn_lds1));
-        HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->ki, h->dyn_lds, &bpc));
+        HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
+        HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
     }
     bpc = std::max(1, std::min(bpc, 8));
     HIP_TRY_H(update_set_max_lds()); // (per handle = per device, after hipSetDevice: the entry-parallel updateData kernels use up to 160 KB of dynamic LDS)
@@ -596,7 +574,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // partly filled round still costs more than half a round; pick the cheapest estimate (e.g. batch 1024 on
         // 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3 per CU, batch >= 1536 takes 3 per CU).
         double best = 1e300; int best_r = 1;
-        const double groups = std::ceil((double)batch / h->ki);
+        const double groups = (double)batch;
         for (int r = 1; r <= bpc; r++) {
             const double rounds = groups / ((double)prop.multiProcessorCount * r);
             const double full = std::floor(rounds), f = rounds - full;
@@ -608,7 +586,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
     const int resident = prop.multiProcessorCount * bpc;
-    h->grid = std::min((batch + h->ki - 1) / h->ki, resident);
+    h->grid = std::min(batch, resident);
     h->order_min = prop.multiProcessorCount;
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
     {   // entry-parallel updateData: needs the A / G values and the row / column maxima in LDS and <= 8 vector entries per thread
@@ -640,8 +618,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (h->ldsres) HIP_TRY_H(ldsres::upload_pattern(h->pslot, h->dp));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
-    HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.group_stride * sizeof(double)));
-    HIP_TRY_H(hipMemset(h->d_work, 0, (size_t)h->grid * D.group_stride * sizeof(double)));
+    HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
+    HIP_TRY_H(hipMemset(h->d_work, 0, (size_t)h->grid * D.work_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_queue, (16 + (size_t)batch) * sizeof(int))); // [0] queue head, [16..] longest-first order
     HIP_TRY_H(hipMalloc(&h->d_scratch, (size_t)h->upd_grid * (size_t)(S.n + S.p + S.m + 8) * sizeof(double)));
     HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -778,18 +756,15 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    // warm start decides per instance whether the initialisation solves are skipped: members of a lock-step group could
-    // then be in different stages, so warm-started handles run the single-instance kernel (same workspace slabs)
-    const bool single = h->ki == 1 || h->warm_shift > 0.;
     if (h->ldsres)
-        HIP_TRY(ldsres::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16, 1,
+        HIP_TRY(ldsres::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
                                      h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
     else
-    HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, single ? h->nlds1 : h->nlds,
-                         h->dp.idx16, single ? 1 : h->ki, h->order_min * (single ? 1 : h->ki), h->warm_shift, h->dyn_delta, h->dyn_eps, single ? h->dyn_lds1 : h->dyn_lds, h->stream));
+        HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
+                             h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
-    h->last_kis = single ? 1 : h->ki; h->last_ordered = h->batch > h->order_min * h->last_kis;
+    h->last_ordered = h->batch > h->order_min;
     return EICOS_OK;
 }
 
@@ -872,7 +847,7 @@ int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     o->factor_pairs = S.npairs;
     o->inst_bytes = h->dp.inst_stride * sizeof(double); o->work_bytes = h->dp.work_stride * sizeof(double);
     o->pattern_bytes = h->pattern_ints * sizeof(int);
-    o->threads_per_block = h->threads; o->resident_blocks = h->grid * h->ki; o->lds_bytes = (int)h->dyn_lds; o->instances_per_block = h->ki;
+    o->threads_per_block = h->threads; o->resident_blocks = h->grid; o->lds_bytes = (int)h->dyn_lds; o->instances_per_block = 1;
     o->lds_resident = h->ldsres; o->factor_path = h->sym.tile;
     return EICOS_OK;
 }
@@ -980,8 +955,7 @@ int eicos_debug_scalings(eicos_batch *h, int inst, const double *s, const double
 
 int eicos_debug_trace(eicos_batch *h, int inst, double *out) {
     if (!h || !out || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");
-    const int kis = h->last_kis; // instances per workgroup of the kernel that ran
-    if (h->batch > h->grid * kis) return fail(EICOS_E_INVALID, "trace is per workspace slot: needs batch <= resident instances");
+    if (h->batch > h->grid) return fail(EICOS_E_INVALID, "trace is per workspace slot: needs batch <= resident instances");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     int slot = inst;
@@ -991,7 +965,7 @@ int eicos_debug_trace(eicos_batch *h, int inst, double *out) {
         slot = (int)(std::find(ord.begin(), ord.end(), inst) - ord.begin());
         if (slot >= h->batch) return fail(EICOS_E_INVALID, "instance not found in the launch order");
     }
-    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)(slot / kis) * h->dp.group_stride + (size_t)(slot % kis) * h->dp.w_split + h->dp.w_trace,
+    HIP_TRY(hipMemcpy(out, h->d_work + (size_t)slot * h->dp.work_stride + h->dp.w_trace,
                       (size_t)TRACE_ROWS * TRACE_COLS * sizeof(double), hipMemcpyDeviceToHost));
     return EICOS_OK;
 }

@@ -145,12 +145,8 @@ struct DevPat {
     int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2, w_rhs1k, w_rhs2k;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
     int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_UF, w_UB, w_D, w_invD, w_trace;
-    // Workspace of a workgroup that solves KI instances in lock-step (KI = 1: one instance): the arrays at offsets below
-    // w_split are per instance (instance k at k * w_split + offset), the arrays at or above it -- the factor, its value
-    // stream Kt and the KKT-space vectors -- are shared KI-interleaved (element i of instance k at KI * offset + i * KI + k).
-    int w_split;
     int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)
-    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves (tile mode): flag + the two interleaved vectors in the workspace
+    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves: flag + the two 2-interleaved vectors in the workspace
     int lr_inst, lr_work;            // LDS-resident variant: offsets (doubles) of the instance slab and the workspace slab in the dynamic LDS
     // G in dense 16 x 16 tiles (api.cpp): gt_nrb row blocks of 16 rows, tiles [gt_rbptr[rb], gt_rbptr[rb+1]) of row block rb,
     // 16 columns per tile (gt_col: variable index or -1, gt_colk: elimination-order slot), gt_zslot: slot of z_i per row,
@@ -158,7 +154,6 @@ struct DevPat {
     int gt_on, gt_nrb, gt_nt, gt_W, i_Gt, w_gpart, w_gx, w_gz;
     gint_p gt_rbptr, gt_col, gt_colk, gt_zslot, gt_cidx, gt_src;
     size_t inst_stride, work_stride; // in doubles
-    size_t group_stride;             // workspace of one resident workgroup = (instances per workgroup of the handle) * work_stride
 };
 
 // Tile-internal element order (tile mode): a 16 x 16 tile is stored so that lane l of a wavefront owns the four

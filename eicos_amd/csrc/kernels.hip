@@ -72,11 +72,10 @@ constexpr int EX_NOT_CONVERGED = -87;
 // of two tiles in flight per wavefront and spills at 128), 256 threads -> 3 (168 VGPRs, three workgroups per CU: three
 // 48 KB solve vectors are what the 160 KB of LDS hold), 128 threads -> 4 (small patterns, up to eight workgroups per CU).  The AMDGPU
 // attributor propagates the kernel's budget to the non-inlined stage functions.
-// Lock-step pairs (KI = 2) run as ONE workgroup per CU (both sweep vectors in LDS): 512 threads = 2 waves per SIMD -> 256 VGPRs.
 #if EICOS_LDSRES
-template <int T, int KI = 1> constexpr int waves_per_eu() { return 2; } // LDS allows at most three small workgroups per CU
+template <int T> constexpr int waves_per_eu() { return 2; } // LDS allows at most three small workgroups per CU
 #else
-template <int T, int KI = 1> constexpr int waves_per_eu() { return KI == 2 ? T / 256 : (T == 256 ? 3 : (T == 512 ? 2 : 4)); }
+template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : (T == 512 ? 2 : 4); }
 #endif
 
 // Multiply-accumulate of the sparse inner loops (products, sweeps, factor program).  The file is compiled with
@@ -106,14 +105,12 @@ enum { ACT_CONTINUE = 0, ACT_BREAK = 1 };
 constexpr int MAX_PATTERNS = 64;
 __constant__ DevPat c_pat[MAX_PATTERNS];
 
-// Per-instance scalar state.  g_S is the state of the instance the per-instance stages are working on.  A workgroup that
-// solves KI > 1 instances in lock-step keeps every instance's state in g_Sk[k] and swaps it in and out of g_S around the
-// per-instance stages; the lock-step stages (factorisation, KKT solves) address g_Sk[k] directly (inst_state).
+// Per-instance scalar state of the instance the workgroup is solving (LDS, advanced by thread 0 between barriers).
 struct ShI {
     DevInfo wi, bi;
     double sv[SV_COUNT];
     int fl[FL_COUNT];
-    int kref, kref2, done; // refinement steps of the last KKT solve (kref2: of the second right-hand side of a dual solve); 1 = this instance has finished (lock-step groups)
+    int kref, kref2, done; // refinement steps of the last KKT solve (kref2: of the second right-hand side of a dual solve); 1 = this instance has finished
     unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
 };
 struct Sh : ShI {
@@ -121,21 +118,12 @@ struct Sh : ShI {
     double dyn_delta, dyn_eps; // dynamic regularisation of the pivots (extension; 0 = off), set by k_solve
     int next; // next instance of this workgroup (k_solve's queue)
 };
-constexpr int KI_MAX = 2; // instances per workgroup in lock-step
+constexpr int KI_MAX = 2; // right-hand sides of a dual solve (kkt_solve<..., 2, true>)
 enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT, TK_FA = 8, TK_FW1, TK_FB, TK_FW2 }; // 8..11: inside the factor
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
-static_assert(sizeof(Sh) + KI_MAX * sizeof(ShI) <= 4096, "api.cpp budgets 4 KB of static LDS per workgroup");
+static_assert(sizeof(Sh) <= 4096, "api.cpp budgets 4 KB of static LDS per workgroup");
 __shared__ Sh g_S;
-__shared__ ShI g_Sk[KI_MAX];
-template <int KI> __device__ __forceinline__ ShI &inst_state(int k) { if constexpr (KI == 1) return g_S; else return g_Sk[k]; }
-// swap the per-instance state of instance k into / out of g_S (all threads call; ends with a barrier)
-template <int KI> __device__ __forceinline__ void state_in(int k) {
-    if constexpr (KI > 1) { __syncthreads(); if (threadIdx.x == 0) static_cast<ShI &>(g_S) = g_Sk[k]; __syncthreads(); }
-}
-template <int KI> __device__ __forceinline__ void state_out(int k) {
-    if constexpr (KI > 1) { __syncthreads(); if (threadIdx.x == 0) g_Sk[k] = static_cast<ShI &>(g_S); __syncthreads(); }
-}
 extern __shared__ double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | slice tables of both sweeps
 
 // Arguments of non-inlined device functions arrive in VGPRs; the values below are workgroup-uniform,
@@ -167,7 +155,7 @@ __device__ __forceinline__ d2_t ld_u32(const d2_t EICOS_DATA *base, int i) { ret
 __device__ __forceinline__ d2_t ld_u32_nt(const d2_t EICOS_DATA *base, int i) { return base[i]; }
 #endif
 
-// ---- KI-interleaved arrays: element (i, k) of an array shared by the KI instances of a workgroup sits at i * KI + k, so the
+// ---- KI-interleaved arrays (the two right-hand sides of a dual solve): element (i, k) sits at i * KI + k, so the
 // KI values of one slot are ONE load / store of 8 KI bytes (KI = 2: 16 bytes per lane, the width the memory system likes best).
 template <class P> struct vec2_of;
 template <> struct vec2_of<double *> { typedef d2_t *type; };
@@ -386,9 +374,9 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
     }
 }
 
-// Lock-step form of ell_dots for KI instances of one workgroup: the slice descriptors and gather indices are shared, the
-// matrix values come from the KI instance slabs (eval[k]), the gathered vector x is KI-interleaved; `pre(k, row)` /
-// `epi(k, row, sum, pre)` get the instance number.
+// ell_dots for KI right-hand sides at once: the slice descriptors, gather indices and (SHARED: the dual solve of ONE instance)
+// the matrix values are loaded once, the gathered vector x is KI-interleaved; `pre(k, row)` / `epi(k, row, sum, pre)` get the
+// number of the right-hand side.
 template <int T, bool I16, int KI, bool SHARED, class SM, class X, class Pre, class Epi>
 __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, const gcdbl_p (&eval)[KI], X x, int dummy_slot,
                                            Pre &&pre, Epi &&epi) {
@@ -478,8 +466,8 @@ __device__ __forceinline__ void lds_barrier() {
 template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
-    // KI > 1: the workgroup sweeps KI instances in lock-step -- slice descriptors and gather indices are shared, the value
-    // arrays (eval, invD) and the sweep vector ws are KI-interleaved, so every value load / gather / store is one 8 KI-byte access
+    // KI = 2 (with VSH): the two right-hand sides of a dual solve -- one factor, the sweep vector ws 2-interleaved, so every
+    // gather / store of the pair is one 16-byte LDS access
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
@@ -747,16 +735,15 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
     (void)n; (void)p; (void)m; (void)l; (void)N; (void)np; (void)lane; (void)wave; (void)phase; (void)wi;
 
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
-// KI > 1: KI instances in lock-step.  Wg = the group's workspace; the factor arrays (UF, UB, D, invD, Kt) are
-// KI-interleaved at KI * offset (device_types.hpp: DevPat::w_split), the pair / destination indices are shared.
-template <int T, int NLDS, bool I16, int KI>
+// Wg = the workgroup's workspace slab.  Left-looking sliced-ELL program over the level schedule (host: plans.cpp, api.cpp).
+template <int T, int NLDS, bool I16>
 __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     ps = uni(ps); Wg = uni_ptr(Wg);
     const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x;
-    gdbl_p UF = Wg + (size_t)KI * P.w_UF, U = Wg + (size_t)KI * P.w_UB, D = Wg + (size_t)KI * P.w_D, invD = Wg + (size_t)KI * P.w_invD; // pa/pb index UB slots
-    gcdbl_p Kt = Wg + (size_t)KI * P.w_Kt; // KKT entries in target order (solve prologue + updateKKTScalings)
-    gdbl_p Kimg = Wg + P.w_Kimg;           // hybrid (single-instance): targets of the top block go to its tile image
+    gdbl_p UF = Wg + P.w_UF, U = Wg + P.w_UB, D = Wg + P.w_D, invD = Wg + P.w_invD; // pa/pb index UB slots
+    gcdbl_p Kt = Wg + P.w_Kt;    // KKT entries in target order (solve prologue + updateKKTScalings)
+    gdbl_p Kimg = Wg + P.w_Kimg; // hybrid: targets of the top block go to its tile image
     __syncthreads();
     unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
     const int ns = P.fac_ns;
@@ -767,10 +754,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     // Everything that does not depend on factor values (pair indices, the K entry, destinations) is loaded
     // FAC_DEPTH slices ahead, across the level barriers, so a level costs one dependent gather round trip
     // per phase instead of an index load + gather + source-index load + value load chain.
-    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv[KI]; int dst; } q[FAC_DEPTH];
-    double carry[KI]; // partial sum of targets cut into sub-slices
-#pragma unroll
-    for (int k = 0; k < KI; k++) carry[k] = 0.;
+    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
+    double carry = 0.; // partial sum of targets cut into sub-slices
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
     // the loads that need them, so that their round trip is not on the path either
@@ -793,45 +778,39 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             }
         }
         const int t = act ? o.row0 + (tid >> o.lg) : 0;
-        ldK_g<KI, false>(Kt, t, o.kv);
+        o.kv = ld_u32(Kt, t);
         o.dst = ld_u32(P.fac_dst, t);
+    };
+    // a diagonal target: pivot (with the optional dynamic regularisation, extension N4) -> D, 1/D; zero pivot -> fatal
+    auto pivot = [&](int dst, double val) {
+        const int e = -dst - 1, j = e & (DIAG_POS - 1); // -(j+1), plus DIAG_POS when the quasi-definite sign of pivot j is +
+        if (g_S.dyn_delta > 0.) { // ECOS-style dynamic regularisation, off by default
+            const double sg = (e & DIAG_POS) ? 1. : -1.;
+#ifdef EICOS_TRACE_DYNREG
+            if (sg * val <= g_S.dyn_eps) printf("[dynreg scalar] blk %d j %d val %.6e sg %.0f\n", (int)blockIdx.x, j, val, sg);
+#endif
+            if (sg * val <= g_S.dyn_eps) val = sg * g_S.dyn_delta;
+        }
+        if (val == 0.) g_S.fl[FL_FATAL] = 1; // (Eigen: NumericalIssue)
+        D[j] = val; invD[j] = 1. / val;
     };
     // ---- level 0 (the leaves of the elimination tree: two thirds of the nodes of an MPC pattern) has no pairs at all:
     // D_j = K_jj, U_ij = K_ij, L_ij = K_ij / D_j.  Two streaming passes over its targets (diagonals first, host: api.cpp)
     // instead of a slice step per 256 targets: coalesced reads of the K stream, eight targets per thread in flight ----
     const int sbeg = P.fac_s1;
     if (P.fac_nt0 > 0) {
-        struct F0 { int dst; double kv[KI]; };
-        for_t_pre<T, 8>(P.fac_nd0, [&](int t) { F0 r; r.dst = ld_u32(P.fac_dst, t); ldK_g<KI, false>(Kt, t, r.kv); return r; }, [&](int t, const F0 &r) {
-            double val[KI], iv[KI];
-#pragma unroll
-            for (int k = 0; k < KI; k++) val[k] = r.kv[k];
-            if (r.dst >= IMG_BASE) { if constexpr (KI == 1) Kimg[r.dst - IMG_BASE] = val[0]; return; }
-            const int e = -r.dst - 1, j = e & (DIAG_POS - 1);
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                if (g_S.dyn_delta > 0.) { const double sg = (e & DIAG_POS) ? 1. : -1.; if (sg * val[k] <= g_S.dyn_eps) val[k] = sg * g_S.dyn_delta; }
-                iv[k] = 1. / val[k];
-                if (val[k] == 0.) inst_state<KI>(k).fl[FL_FATAL] = 1;
-            }
-            stK<KI>(D, j, val); stK<KI>(invD, j, iv);
+        for_t_pre<T, 8>(P.fac_nd0, [&](int t) { return IV1{ld_u32(P.fac_dst, t), ld_u32(Kt, t)}; }, [&](int t, const IV1 &r) {
+            if (r.i >= IMG_BASE) Kimg[r.i - IMG_BASE] = r.a; else pivot(r.i, r.a);
         });
         __syncthreads();
-        struct F1 { int dst, dstF; double kv[KI], d[KI]; };
-        for_t_pre<T, 8>(P.fac_nt0 - P.fac_nd0, [&](int q) {
-            const int t = P.fac_nd0 + q;
-            F1 r; r.dst = ld_u32(P.fac_dst, t); r.dstF = ld_u32(P.fac_dstF, t);
-            ldK_g<KI, false>(Kt, t, r.kv); ldK<KI>(invD, ld_u32(P.fac_col, t), r.d);
-            return r;
-        }, [&](int q, const F1 &r) {
-            if (r.dst >= IMG_BASE) { if constexpr (KI == 1) Kimg[r.dst - IMG_BASE] = r.kv[0]; return; }
-            stK<KI>(U, r.dst, r.kv);
-            if (r.dstF >= 0) {
-                double o[KI];
-#pragma unroll
-                for (int k = 0; k < KI; k++) o[k] = r.kv[k] * r.d[k];
-                stK<KI>(UF, r.dstF, o);
-            }
+        struct F1 { int dst, dstF; double kv, d; };
+        for_t_pre<T, 8>(P.fac_nt0 - P.fac_nd0, [&](int q_) {
+            const int t = P.fac_nd0 + q_;
+            return F1{ld_u32(P.fac_dst, t), ld_u32(P.fac_dstF, t), ld_u32(Kt, t), invD[ld_u32(P.fac_col, t)]};
+        }, [&](int, const F1 &r) {
+            if (r.dst >= IMG_BASE) { Kimg[r.dst - IMG_BASE] = r.kv; return; }
+            U[r.dst] = r.kv;
+            if (r.dstF >= 0) UF[r.dstF] = r.kv * r.d;
         });
         __syncthreads();
     }
@@ -847,7 +826,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(sbeg + d, ns - 1)), q[d]);
     Sl pm = fmeta(min(sbeg + FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
-    double gu[2][ELL_KMAX][KI], gl[2][ELL_KMAX][KI];
+    double gu[2][ELL_KMAX], gl[2][ELL_KMAX];
     static_assert(FAC_DEPTH % 2 == 0, "operand register sets alternate with the queue slot");
     bool have = false;
     for (int s0 = sbeg; s0 < ns; s0 += FAC_DEPTH) {
@@ -861,13 +840,13 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             if (c.newlev) lvl_t0 = c.row0;
             const int lvl_t1 = c.row0 + c.cnt; // targets of a level are one contiguous range
             const bool act = tid < c.lanes;
-            // gathered factor values: slices of one level are independent, so the next slice's gathers are
-            // issued before this slice's arithmetic waits on its own (one L2 round trip per level, not per slice)
-            // (two operand register sets, by the parity of the slice's queue slot: no copies between a slice's gathers and its use)
-            double (&cu)[ELL_KMAX][KI] = gu[d & 1], (&cl)[ELL_KMAX][KI] = gl[d & 1];
+            // gathered factor values: slices of one level are independent, so the next slice's gathers are issued before this
+            // slice's arithmetic waits on its own (one L2 round trip per level, not per slice).  Two operand register sets, by
+            // the parity of the slice's queue slot: no copies between a slice's gathers and their use
+            double (&cu)[ELL_KMAX] = gu[d & 1], (&cl)[ELL_KMAX] = gl[d & 1];
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, c.ia[u], cu[u]); ldK_g<KI, false>((gcdbl_p)UF, c.ib[u], cl[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { cu[u] = ld_u32((gcdbl_p)U, c.ia[u]); cl[u] = ld_u32((gcdbl_p)UF, c.ib[u]); }
             }
             have = !c.last;
             { // UNCONDITIONAL (when the next slice opens a new level its operands are not final yet: they are fetched again
@@ -875,44 +854,19 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
               // wait for this slice's operands with s_waitcnt vmcnt(8) instead of draining the queue at every slice
                 const FSlot &nx = q[(d + 1) % FAC_DEPTH];
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { ldK_g<KI, false>((gcdbl_p)U, nx.ia[u], gu[(d + 1) & 1][u]); ldK_g<KI, false>((gcdbl_p)UF, nx.ib[u], gl[(d + 1) & 1][u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { gu[(d + 1) & 1][u] = ld_u32((gcdbl_p)U, nx.ia[u]); gl[(d + 1) & 1][u] = ld_u32((gcdbl_p)UF, nx.ib[u]); }
             }
-            double acc[KI];
+            double acc = 0.;
 #pragma unroll
-            for (int k = 0; k < KI; k++) {
-                double a = 0.;
-#pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) a = madd(a, cu[u][k], cl[u][k]);
-                a = grp_reduce_to_lane0(a, c.lg);
-                if (c.cont) a += carry[k];
-                acc[k] = a;
-            }
-            if (c.more) {
-#pragma unroll
-                for (int k = 0; k < KI; k++) carry[k] = acc[k];
-            } else if (act && (tid & ((1 << c.lg) - 1)) == 0) {
-                double val[KI];
-#pragma unroll
-                for (int k = 0; k < KI; k++) val[k] = c.kv[k] - acc[k];
-                if (c.dst >= IMG_BASE) { // hybrid: K - (updates from the columns below the top block) -> input of the tile factorisation
-                    if constexpr (KI == 1) Kimg[c.dst - IMG_BASE] = val[0];
-                } else if (c.dst < 0) { // diagonal target: -(j+1), plus DIAG_POS when the quasi-definite sign of pivot j is +
-                    const int e = -c.dst - 1, j = e & (DIAG_POS - 1);
-                    double iv[KI];
-#pragma unroll
-                    for (int k = 0; k < KI; k++) {
-                        if (g_S.dyn_delta > 0.) { // extension (N4): ECOS-style dynamic regularisation, off by default
-                            const double sg = (e & DIAG_POS) ? 1. : -1.;
-#ifdef EICOS_TRACE_DYNREG
-                            if (sg * val[k] <= g_S.dyn_eps) printf("[dynreg scalar] blk %d j %d val %.6e sg %.0f\n", (int)blockIdx.x, j, val[k], sg);
-#endif
-                            if (sg * val[k] <= g_S.dyn_eps) val[k] = sg * g_S.dyn_delta;
-                        }
-                        iv[k] = 1. / val[k];
-                        if (val[k] == 0.) inst_state<KI>(k).fl[FL_FATAL] = 1; // zero pivot -> fatal (Eigen NumericalIssue)
-                    }
-                    stK<KI>(D, j, val); stK<KI>(invD, j, iv);
-                } else stK<KI>(U, c.dst, val);
+            for (int u = 0; u < ELL_KMAX; u++) acc = madd(acc, cu[u], cl[u]);
+            acc = grp_reduce_to_lane0(acc, c.lg);
+            if (c.cont) acc += carry;
+            if (c.more) carry = acc;
+            else if (act && (tid & ((1 << c.lg) - 1)) == 0) {
+                const double val = c.kv - acc;
+                if (c.dst >= IMG_BASE) Kimg[c.dst - IMG_BASE] = val; // hybrid: K - (updates from the columns below the top block) -> input of the tile factorisation
+                else if (c.dst < 0) pivot(c.dst, val);
+                else U[c.dst] = val;
             }
             if (c.last) {
                 FTICK(9);
@@ -934,22 +888,18 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                     };
                     lidx(tid);
                     for (int i0 = tid; i0 < cnt; i0 += UBN * T) {
-                        int cd[UBN], cf[UBN]; double pu[UBN][KI], pd[UBN][KI];
+                        int cd[UBN], cf[UBN]; double pu[UBN], pd[UBN];
 #pragma unroll
                         for (int u = 0; u < UBN; u++) {
                             cd[u] = xd[u]; cf[u] = xf[u];
-                            ldK<KI>(U, (cd[u] >= 0 && cd[u] < IMG_BASE) ? cd[u] : 0, pu[u]); ldK<KI>(invD, xc[u], pd[u]);
+                            pu[u] = U[(cd[u] >= 0 && cd[u] < IMG_BASE) ? cd[u] : 0]; pd[u] = invD[xc[u]];
                         }
                         lidx(i0 + UBN * T);
 #pragma unroll
                         for (int u = 0; u < UBN; u++) {
-                            double o[KI];
-#pragma unroll
-                            for (int kk = 0; kk < KI; kk++) {
-                                asm volatile("" : "+v"(pu[u][kk]), "+v"(pd[u][kk])); // (pins the gathers above the branch: a load whose only use sits under a branch is sunk into it)
-                                o[kk] = pu[u][kk] * pd[u][kk];
-                            }
-                            if (i0 + u * T < cnt && cd[u] >= 0 && cf[u] >= 0) stK<KI>(UF, cf[u], o);
+                            asm volatile("" : "+v"(pu[u]), "+v"(pd[u])); // (pins the gathers above the branch: a load whose only use sits under a branch is sunk into it)
+                            const double o = pu[u] * pd[u];
+                            if (i0 + u * T < cnt && cd[u] >= 0 && cf[u] >= 0) UF[cf[u]] = o;
                         }
                     }
                 }
@@ -961,10 +911,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     }
     }
     }
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < KI; k++) { ShI &st = inst_state<KI>(k); st.wi.n_factor++; st.tick[TK_FACTOR] += wall_clock64() - tk0_; }
-    }
+    if (tid == 0) { g_S.wi.n_factor++; g_S.tick[TK_FACTOR] += wall_clock64() - tk0_; }
     __syncthreads();
 }
 
@@ -1314,11 +1261,8 @@ __device__ __forceinline__ void g_tile_products(const DevPat &P, gcdbl_p Gt, gin
 }
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
-// One instance (state in g_S; slab I, workspace W = Wg + ki * w_split); the factor's K stream Kt is KI-interleaved.
-template <int T, int NLDS, bool I16, int KI>
-__device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int iter) {
-    Wg = uni_ptr(Wg); ki = uni(ki);
-    gdbl_p W = Wg + (size_t)ki * c_pat[uni(ps)].w_split;
+template <int T, int NLDS, bool I16>
+__device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
     gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
@@ -1452,10 +1396,10 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int
     }
     // ---- updateScalings (ref :411-479) + updateKKTScalings (ref :1691-1732) ----
     // the scaling block goes to the instance slab (Vv) and to the factor's target-ordered value stream (Kt)
-    gdbl_p Kt = Wg + (size_t)KI * P.w_Kt + ki; // element t of this instance at Kt[t * KI]
+    gdbl_p Kt = W + P.w_Kt;
     for_t_pre<T, 4>(l, [&](int i) { return IV2{P.v2t[i], wsl[i], wz[i]}; }, [&](int i, const IV2 &r) {
         const double v = r.a / r.b;
-        lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; Kt[(size_t)r.i * KI] = -v - DELTASTAT;
+        lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; Kt[r.i] = -v - DELTASTAT;
     });
     double firstfail = 1e300;
     if (P.nc > 0) {
@@ -1524,13 +1468,13 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int
             // KKT scaling block, slot order of ref cacheIndices :1955-1986: D[d], vdiag, v[d-1], udiag, u[d]
             for (int k = ln; k < d; k += g) {
                 const double qk = (k >= 1) ? (0.5 / gam) * (wsl[o + k] / snorm - wz[o + k] / znorm) : 0.;
-                if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[(size_t)vt[d + k] * KI] = e; }
+                if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[vt[d + k]] = e; }
                 const double e0 = (k == 0) ? -eta2 * d1 - DELTASTAT : -eta2 - DELTASTAT;
                 const double e2 = (k == 0) ? -eta2 * u0 : -eta2 * u1 * qk;
-                v[k] = e0; Kt[(size_t)vt[k] * KI] = e0;
-                v[2 * d + 1 + k] = e2; Kt[(size_t)vt[2 * d + 1 + k] * KI] = e2;
+                v[k] = e0; Kt[vt[k]] = e0;
+                v[2 * d + 1 + k] = e2; Kt[vt[2 * d + 1 + k]] = e2;
             }
-            if (ln == 0) { v[d] = -eta2; Kt[(size_t)vt[d] * KI] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[(size_t)vt[2 * d] * KI] = eta2 + DELTASTAT; }
+            if (ln == 0) { v[d] = -eta2; Kt[vt[d]] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[vt[2 * d]] = eta2 + DELTASTAT; }
         });
     }
     __syncthreads();
@@ -1539,16 +1483,14 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p Wg, int ki, int
     return ST_FACTOR;
 }
 
-// ---------------- the KKT stages, part 1: solveKKT (ref :1471-1620) for the KI instances of the workgroup in lock-step ----------------
-// Instance k: slab Ik, workspace Wg + k * w_split; the KKT-space vectors (sweep vector SV, iterate X, residual E, parked
-// iterate Xg, last correction dxr) and the factor are KI-interleaved.  Every instance keeps its own refinement state
-// (step count, previous error, done flag): the loop runs until all of them have stopped; an instance that has stopped
-// keeps its iterate while the others take further steps (its lanes still compute, the result is discarded).
-// amask: bit k set = instance k takes part (not finished, slot in use).
-// DUAL (KI = 2, tile mode): not two instances but the TWO INDEPENDENT right-hand sides of one instance -- rhs1 and rhs2 of
+// ---------------- the KKT stages, part 1: solveKKT (ref :1471-1620) ----------------
+// KI = 1: one right-hand side.  KI = 2 with DUAL: the TWO INDEPENDENT right-hand sides of one instance -- rhs1 and rhs2 of
 // the initialisation (ref :933, :966) or of a pass (KKT1 and the affine system, ref :1173-1179: RHSaffine does not depend on
 // the first solution) -- solved together: the sweeps and the refinement residuals stream L, A and G once for both.  The
-// vectors are interleaved like a lock-step pair's, the matrix arrays are the instance's own.
+// KKT-space vectors (sweep vector SV, iterate X, residual E, parked iterate Xg) are then 2-interleaved (element i of
+// right-hand side k at 2 i + k); every right-hand side keeps its own refinement state (step count, previous error, done
+// flag): the loop runs until both have stopped, one that has stopped keeps its iterate while the other takes further
+// steps (its lanes still compute, the result is discarded).  amask: bit k set = right-hand side k takes part.
 template <int T, int NLDS, bool I16, int KI, bool DUAL = false>
 __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, int stage, int amask) {
     ps = uni(ps); I0 = uni_ptr(I0); I1 = uni_ptr(I1); Wg = uni_ptr(Wg); stage = uni(stage); amask = uni(amask);
@@ -1556,7 +1498,8 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
     const int tid = threadIdx.x;
     int phase = 0;
-    static_assert(KI == 1 || NLDS == 1, "lock-step groups keep one KKT-space vector per instance in LDS");
+    static_assert(DUAL == (KI == 2), "KI = 2 is the dual right-hand-side solve");
+    static_assert(KI == 1 || NLDS == 1, "a dual solve keeps its two sweep vectors in LDS");
     gdbl_p Ik[KI_MAX] = {I0, I1};
     const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
     const bool first = (stage == ST_KKT_INIT1 || stage == ST_KKT1);
@@ -1564,7 +1507,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     gdbl_p dx[KI], dy[KI], dz[KI];
 #pragma unroll
     for (int k = 0; k < KI; k++) {
-        gdbl_p I = Ik[k], W = Wg + (DUAL ? 0 : (size_t)k * P.w_split);
+        gdbl_p I = Ik[k], W = Wg;
         const bool fk = DUAL ? (k == 0) : first; // dual: right-hand side 0 is rhs1 -> (dx1, dy1, dz1), 1 is rhs2 -> (dx2, dy2, dz2)
         cagv[k] = I + P.i_cag; rAv[k] = I + P.i_rA; rGv[k] = I + P.i_rG;
         rhsp[k] = W + (fk ? P.w_rhs1 : P.w_rhs2);                      // elimination order (what the triangular sweeps consume)
@@ -1573,7 +1516,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         lpv[k] = W + P.w_lpv; csc[k] = W + P.w_csc; qv[k] = W + P.w_qv;
         dx[k] = W + (fk ? P.w_dx1 : P.w_dx2); dy[k] = W + (fk ? P.w_dy1 : P.w_dy2); dz[k] = W + (fk ? P.w_dz1 : P.w_dz2);
     }
-    auto state = [&](int k) -> ShI & { if constexpr (DUAL) return g_S; else return inst_state<KI>(k); };
+    auto state = [&](int) -> ShI & { return g_S; };
     // KKT-space vectors, in elimination order: X = current solution, E = rhs / residual / solve vector.
     // Both in LDS (NLDS = 2) or both in the workspace slab (NLDS = 0, patterns too large for LDS).
     // Roles: SV = vector the triangular sweeps run on; X = solution the residual gathers from; E = where the
@@ -1581,26 +1524,20 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     // per CU): the LDS vector alternates between the sweep vector and X -- the ~25k gathers of a residual hit
     // LDS, its ~N scattered stores go to E in the workspace slab, and X is parked in the slab (Xg) only while a
     // further refinement step borrows the LDS vector.  NLDS = 0: everything in the workspace slab.
-    auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return Wg + (size_t)KI * P.w_ek; }();
-    auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return Wg + (size_t)KI * P.w_xk; }();
-    auto E = [&] { if constexpr (DUAL) return Wg + P.w_dual_ek; else if constexpr (NLDS == 1) return Wg + (size_t)KI * P.w_ek; else return SV; }();
-    gdbl_p Xg = DUAL ? Wg + P.w_dual_xk : Wg + (size_t)KI * P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
+    auto SV = [&] { if constexpr (NLDS >= 1) return g_dyn; else return Wg + P.w_ek; }();
+    auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return Wg + P.w_xk; }();
+    auto E = [&] { if constexpr (DUAL) return Wg + P.w_dual_ek; else if constexpr (NLDS == 1) return Wg + P.w_ek; else return SV; }();
+    gdbl_p Xg = DUAL ? Wg + P.w_dual_xk : Wg + P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
     const PackedSlice *tabs = reinterpret_cast<const PackedSlice *>(g_dyn + P.lds_tab);
     auto tab_cag = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_cag; else return P.cag_sl; }();
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rA; else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rG; else return P.rG_sl; }();
-    gdbl_p dxr = Wg + (size_t)KI * P.w_dxr;
-    constexpr int KF = DUAL ? 1 : KI; // instances whose factors are interleaved (dual: one factor, two right-hand sides)
-    gdbl_p UF = Wg + (size_t)KF * P.w_UF, UB = Wg + (size_t)KF * P.w_UB, invD = Wg + (size_t)KF * P.w_invD;
+    gdbl_p dxr = Wg + P.w_dxr;
+    gdbl_p UF = Wg + P.w_UF, UB = Wg + P.w_UB, invD = Wg + P.w_invD; // (one factor, also for two right-hand sides)
     __syncthreads();
     unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
-    auto tick = [&](int slot) { // the lock-step time is booked on every participating instance
-        if (tid == 0) {
-            const unsigned long long t1_ = wall_clock64();
-#pragma unroll
-            for (int k = 0; k < (DUAL ? 1 : KI); k++) if ((amask >> k) & 1) state(k).tick[slot] += t1_ - tk0_;
-            tk0_ = t1_;
-        }
+    auto tick = [&](int slot) {
+        if (tid == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; }
     };
     // per-instance refinement state (workgroup-uniform: every thread sees the same reduction results)
     int kcnt[KI]; double nerr_prev[KI], thr[KI]; bool rdone[KI];
@@ -1630,11 +1567,11 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         // forward: workgroup-wide levels, then the narrow top of the tree on wavefront 0; backward: the top first
         const bool wave0 = uni(tid >> 6) == 0;
         if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
-            if constexpr (KI == 1 || DUAL) { if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV); }
+            if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV);
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
             tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
             if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down
-                if constexpr (KI == 1 || DUAL) {
+                {
                     if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
                     tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
@@ -1650,7 +1587,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         } else {
             tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
             if (P.tile == 2) {
-                if constexpr (KI == 1 || DUAL) {
+                {
                     if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
                     tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
@@ -1949,11 +1886,10 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
 }
 
 // ---------------- per-instance prologue of a solve (its state ends up in g_S); returns 1 if it was warm-started ----------------
-template <int T, int KI>
-__device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p Wg, int ki, double warm) {
-    ps = uni(ps); I = uni_ptr(I); Wg = uni_ptr(Wg); ki = uni(ki);
+template <int T>
+__device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double warm) {
+    ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W);
     const DevPat &P = c_pat[ps];
-    gdbl_p W = Wg + (size_t)ki * P.w_split;
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
     const int tid = threadIdx.x;
     DevInfo *ginfo = (DevInfo *)(I + P.i_info); // (C-style cast: in the LDS-resident build the slab pointer is an LDS pointer)
@@ -1986,17 +1922,17 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p Wg, int ki, 
         FOR_T(i, np + m) { rhs1k[i] = 0.; rhs2k[i] = 0.; }
         __syncthreads();
         { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
-            gdbl_p Kt = Wg + (size_t)KI * P.w_Kt + ki; // KI-interleaved: element t of this instance at Kt[t * KI]
+            gdbl_p Kt = W + P.w_Kt;
             if (P.tile) { // dense tile image of K: zero, then scatter the structural entries (+ 1 on the padding diagonals);
                           // hybrid: only the padding -- the scalar factor program writes the structural entries every pass
-                gdbl_p Kimg = Wg + P.w_Kimg;
+                gdbl_p Kimg = W + P.w_Kimg;
                 const int nimg = (P.nb + P.nt) * 256;
                 FOR_T(t, nimg) Kimg[t] = 0.;
                 __syncthreads();
                 for_t_pre<T, 8>(P.tl_nimg, [&](int e) { return IV1{P.tl_img_dst[e], I[P.tl_img_src[e]]}; }, [&](int e, const IV1 &r) { Kimg[r.i] = r.a; });
             }
             if (P.tile != 1)
-            for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[(size_t)t * KI] = r.a; });
+            for_t_pre<T, 8>(P.fac_nt, [&](int t) { return V1{I[P.fac_src[t]]}; }, [&](int t, const V1 &r) { Kt[t] = r.a; });
         }
         {
             double nr3[3] = {0., 0., 0.};
@@ -2062,64 +1998,39 @@ __device__ __forceinline__ void instance_end(const DevPat &P, gdbl_p I, gdbl_p W
     }
 }
 
-// ---------------- one group of KI instances, whole solve (reference Solver::solve, src/eicos.cpp:848-1262) ----------------
-// The KI instances run the same stage at the same time.  Factorisation and KKT solves are lock-step code over
-// KI-interleaved arrays; everything else runs per instance with that instance's scalar state swapped into g_S.
-// An instance that finishes early (exit test, fatal pivot) is written back at once and then only rides along.
-template <int T, int NLDS, bool I16, int KI>
-__device__ __forceinline__ void solve_group(int ps, gdbl_p (&Ik)[KI_MAX], int nvalid, gdbl_p Wg, double warm) {
+// ---------------- one instance, whole solve (reference Solver::solve, src/eicos.cpp:848-1262): the stage machine ----------------
+template <int T, int NLDS, bool I16>
+__device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, double warm) {
     const DevPat &P = c_pat[ps];
     int stage = ST_FACTOR, iter = -1; // iter = -1 while initialising
-    int amask = 0; // bit k: instance k is still being solved
-    for (int k = 0; k < KI; k++) {
-        if (k >= nvalid) { if constexpr (KI > 1) { if (threadIdx.x == 0) g_Sk[k].done = 1; } continue; }
-        const int w = instance_begin<T, KI>(ps, Ik[k], Wg, k, warm);
-        if (w) { stage = ST_RESID; iter = 0; } // (warm start: single-instance groups only)
-        state_out<KI>(k);
-        amask |= 1 << k;
-    }
+    if (instance_begin<T>(ps, I, W, warm)) { stage = ST_RESID; iter = 0; } // warm start: no initialisation solves
     __syncthreads();
-    while (amask) {
+    while (stage != ST_DONE) {
         if (stage == ST_FACTOR) {
-            if (P.tile != 1) stage_factor<T, NLDS, I16, KI>(ps, Wg); // scalar program (hybrid: everything below the top block + its image)
-            if (P.tile) { if constexpr (KI == 1) stage_factor_tiles<T, NLDS>(ps, Ik[0], Wg, iter); }
-            for (int k = 0; k < KI; k++) { // zero pivot -> fatal, no backscale (ref :901-905,1166-1170)
-                if (!((amask >> k) & 1) || !inst_state<KI>(k).fl[FL_FATAL]) continue;
-                state_in<KI>(k); instance_end(P, Ik[k], Wg + (size_t)k * P.w_split); state_out<KI>(k);
-                amask &= ~(1 << k);
-            }
-            stage = (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
+            if (P.tile != 1) stage_factor<T, NLDS, I16>(ps, W); // scalar program (hybrid: everything below the top block + its image)
+            if (P.tile) stage_factor_tiles<T, NLDS>(ps, I, W, iter);
+            if (g_S.fl[FL_FATAL]) { instance_end(P, I, W); stage = ST_DONE; } // zero pivot -> fatal, no backscale (ref :901-905,1166-1170)
+            else stage = (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
         } else if (stage == ST_RESID) {
-            for (int k = 0; k < KI; k++) {
-                if (!((amask >> k) & 1)) continue;
-                state_in<KI>(k);
-                if (stage_resid<T, NLDS, I16, KI>(ps, Ik[k], Wg, k, iter) == ST_DONE) { __syncthreads(); instance_end(P, Ik[k], Wg + (size_t)k * P.w_split); amask &= ~(1 << k); }
-                state_out<KI>(k);
-            }
-            stage = ST_FACTOR;
-        } else if (KI == 1 && NLDS == 1 && P.dual && (stage == ST_KKT_INIT1 || stage == ST_KKT1)) {
+            if (stage_resid<T, NLDS, I16>(ps, I, W, iter) == ST_DONE) { __syncthreads(); instance_end(P, I, W); stage = ST_DONE; }
+            else stage = ST_FACTOR;
+        } else if (NLDS == 1 && P.dual && (stage == ST_KKT_INIT1 || stage == ST_KKT1)) {
             // the two right-hand sides of this point of the algorithm do not depend on each other: one dual solve
-            if constexpr (KI == 1 && NLDS == 1) {
-                if (stage == ST_KKT1) kkt_post<T>(ps, Ik[0], Wg, ST_KKT1); // RHSaffine (ref :1176) needs the residuals only
-                kkt_solve<T, 1, I16, 2, true>(ps, Ik[0], Ik[0], Wg, stage, 3);
+            if constexpr (NLDS == 1) {
+                if (stage == ST_KKT1) kkt_post<T>(ps, I, W, ST_KKT1); // RHSaffine (ref :1176) needs the residuals only
+                kkt_solve<T, 1, I16, 2, true>(ps, I, I, W, stage, 3);
                 const int second = (stage == ST_KKT1) ? ST_KKT_AFF : ST_KKT_INIT2;
-                if (stage == ST_KKT_INIT1) kkt_post<T>(ps, Ik[0], Wg, ST_KKT_INIT1);
+                if (stage == ST_KKT_INIT1) kkt_post<T>(ps, I, W, ST_KKT_INIT1);
                 __syncthreads();
                 if (threadIdx.x == 0) g_S.kref = g_S.kref2;
                 __syncthreads();
-                const int next = kkt_post<T>(ps, Ik[0], Wg, second);
+                const int next = kkt_post<T>(ps, I, W, second);
                 if (next == ST_RESID) iter = 0; // (after the initialisation pair)
                 stage = next;
             }
         } else {
-            kkt_solve<T, NLDS, I16, KI>(ps, Ik[0], Ik[KI - 1], Wg, stage, amask);
-            int next = stage;
-            for (int k = 0; k < KI; k++) {
-                if (!((amask >> k) & 1)) continue;
-                state_in<KI>(k);
-                next = kkt_post<T>(ps, Ik[k], Wg + (size_t)k * P.w_split, stage);
-                state_out<KI>(k);
-            }
+            kkt_solve<T, NLDS, I16, 1>(ps, I, I, W, stage, 1);
+            const int next = kkt_post<T>(ps, I, W, stage);
             if (next == ST_RESID) iter = (stage == ST_KKT_INIT2) ? 0 : iter + 1; // a pass of the main loop completed
             stage = next;
         }
@@ -2127,17 +2038,17 @@ __device__ __forceinline__ void solve_group(int ps, gdbl_p (&Ik)[KI_MAX], int nv
     __syncthreads();
 }
 
-template <int T, int NLDS, bool I16, int KI>
-__global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
+template <int T, int NLDS, bool I16>
+__global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
     int ps, double *inst, double *work, int B, int *queue, const int *order, double warm, double dyn_delta, double dyn_eps) {
     const DevPat &P = c_pat[ps];
 #if EICOS_LDSRES
-    static_assert(KI == 1 && NLDS >= 1, "LDS-resident variant: single instances, sweep vector + tables in LDS");
-    gdbl_p Wg = (gdbl_p)(g_dyn + P.lr_work), Il = (gdbl_p)(g_dyn + P.lr_inst); // the slabs of the instance being solved
-    double *Wglob = work + (size_t)blockIdx.x * P.group_stride;
-    for (int q = threadIdx.x; q < (int)P.work_stride; q += T) Wg[q] = Wglob[q]; // (zero padding slots, cone state kept between solves)
+    static_assert(NLDS >= 1, "LDS-resident variant: sweep vector + tables in LDS");
+    gdbl_p W = (gdbl_p)(g_dyn + P.lr_work), Il = (gdbl_p)(g_dyn + P.lr_inst); // the slabs of the instance being solved
+    double *Wglob = work + (size_t)blockIdx.x * P.work_stride;
+    for (int q = threadIdx.x; q < (int)P.work_stride; q += T) W[q] = Wglob[q]; // (zero padding slots, cone state kept between solves)
 #else
-    gdbl_p Wg = (gdbl_p)work + (size_t)blockIdx.x * P.group_stride;
+    gdbl_p W = (gdbl_p)work + (size_t)blockIdx.x * P.work_stride;
 #endif
     if constexpr (NLDS >= 1) { // every slice table -> LDS, once per workgroup (same plans for every instance)
         int *dst = reinterpret_cast<int *>(g_dyn + P.lds_tab); // (doubles from the start of the dynamic LDS: behind the vectors)
@@ -2151,37 +2062,30 @@ __global__ __launch_bounds__(T, (waves_per_eu<T, KI>())) void k_solve(
         __syncthreads();
     }
     if (threadIdx.x == 0) { g_S.dyn_delta = dyn_delta; g_S.dyn_eps = dyn_eps; }
-    // Instances differ in iteration count (12..18 on the headline batch): after its first group (= its own index, so
-    // that workspace slot g holds the history of instances g KI .. g KI + KI - 1 when the batch fits the grid) a
-    // workgroup pulls the next unsolved group from a queue instead of striding through the batch.
-    // `order` (batches larger than the grid): instances sorted by the work their previous solve took, longest first --
-    // consecutive entries, i.e. the members of a group, then have about the same number of passes ahead of them.
-    for (int g = blockIdx.x; g * KI < B;) {
-        gdbl_p Ik[KI_MAX];
-        int nvalid = 0;
-        for (int k = 0; k < KI_MAX; k++) {
-            const int i = min(g * KI + (k < KI ? k : 0), B - 1);
-            const int id = order ? order[i] : i;
+    // Instances differ in iteration count (12..18 on the headline batch): after its first instance (= its own index, so
+    // that workspace slot g holds the history of instance g when the batch fits the grid) a workgroup pulls the next
+    // unsolved instance from a queue instead of striding through the batch.
+    // `order` (batches larger than one instance per CU): instances sorted by the work their previous solve took, longest first.
+    for (int g = blockIdx.x; g < B;) {
+        const int id = order ? order[g] : g;
 #if EICOS_LDSRES
-            Ik[k] = Il;
-            if (k == 0) {
-                const double *Ig = inst + (size_t)id * P.inst_stride;
-                __syncthreads();
-                for (int q = threadIdx.x; q < (int)P.inst_stride; q += T) Il[q] = Ig[q];
-                __syncthreads();
-            }
-#else
-            Ik[k] = (gdbl_p)inst + (size_t)id * P.inst_stride;
-#endif
-            if (k < KI && g * KI + k < B) nvalid++;
+        gdbl_p I = Il;
+        {
+            const double *Ig = inst + (size_t)id * P.inst_stride;
+            __syncthreads();
+            for (int q = threadIdx.x; q < (int)P.inst_stride; q += T) Il[q] = Ig[q];
+            __syncthreads();
         }
-        solve_group<T, NLDS, I16, KI>(ps, Ik, nvalid, Wg, warm);
+#else
+        gdbl_p I = (gdbl_p)inst + (size_t)id * P.inst_stride;
+#endif
+        solve_instance<T, NLDS, I16>(ps, I, W, warm);
         __syncthreads();
 #if EICOS_LDSRES
         { // results, persistent per-instance state and (for the debug readbacks) the workspace go back to HBM
-            double *Ig = inst + (size_t)(order ? order[g] : g) * P.inst_stride;
+            double *Ig = inst + (size_t)id * P.inst_stride;
             for (int q = threadIdx.x; q < (int)P.inst_stride; q += T) Ig[q] = Il[q];
-            for (int q = threadIdx.x; q < (int)P.work_stride; q += T) Wglob[q] = Wg[q];
+            for (int q = threadIdx.x; q < (int)P.work_stride; q += T) Wglob[q] = W[q];
         }
 #endif
         if (threadIdx.x == 0) g_S.next = (int)gridDim.x + atomicAdd(queue, 1);
@@ -2437,7 +2341,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
     if (P.tile != 1) {
         for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
         __syncthreads();
-        stage_factor<T, 0, false, 1>(ps, (gdbl_p)work);
+        stage_factor<T, 0, false>(ps, (gdbl_p)work);
     }
     if (P.tile) stage_factor_tiles<T, 0>(ps, I, (gdbl_p)work, -1);
 }
@@ -2460,7 +2364,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
     for (int j = threadIdx.x; j < P.n; j += T) I[P.i_x + j] = 0.;
     for (int j = threadIdx.x; j < P.p; j += T) I[P.i_y + j] = 0.;
     __syncthreads();
-    const int st = stage_resid<T, 0, false, 1>(ps, I, (gdbl_p)work, 0, 0);
+    const int st = stage_resid<T, 0, false>(ps, I, (gdbl_p)work, 0);
     if (threadIdx.x == 0) ok[0] = (st == ST_FACTOR) ? 1 : 0;
 }
 
@@ -2469,26 +2373,26 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
 // ---- launchers (called from api.cpp) ----
 #ifndef EICOS_ISA_PROBE // (tools/dev/isa_probe.sh compiles single stage functions without the kernel instantiations)
 #if EICOS_LDSRES
-template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
+template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        if (idx16) return nlds >= 2 ? f((const void *)k_solve<T, 2, true, 1>) : f((const void *)k_solve<T, 1, true, 1>);
-        return nlds >= 2 ? f((const void *)k_solve<T, 2, false, 1>) : f((const void *)k_solve<T, 1, false, 1>);
+        if (idx16) return nlds >= 2 ? f((const void *)k_solve<T, 2, true>) : f((const void *)k_solve<T, 1, true>);
+        return nlds >= 2 ? f((const void *)k_solve<T, 2, false>) : f((const void *)k_solve<T, 1, false>);
     };
     return byT(std::integral_constant<int, 128>{}); // (small patterns run 128 threads)
 }
 #else
-template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, int ki, F &&f) {
+template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, F &&f) {
     auto byT = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
         if (idx16) {
-            if (nlds >= 2) return f((const void *)k_solve<T, 2, true, 1>);
-            if (nlds == 1) return f((const void *)k_solve<T, 1, true, 1>);
-            return f((const void *)k_solve<T, 0, true, 1>);
+            if (nlds >= 2) return f((const void *)k_solve<T, 2, true>);
+            if (nlds == 1) return f((const void *)k_solve<T, 1, true>);
+            return f((const void *)k_solve<T, 0, true>);
         }
-        if (nlds >= 2) return f((const void *)k_solve<T, 2, false, 1>);
-        if (nlds == 1) return f((const void *)k_solve<T, 1, false, 1>);
-        return f((const void *)k_solve<T, 0, false, 1>);
+        if (nlds >= 2) return f((const void *)k_solve<T, 2, false>);
+        if (nlds == 1) return f((const void *)k_solve<T, 1, false>);
+        return f((const void *)k_solve<T, 0, false>);
     };
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
@@ -2496,7 +2400,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
 }
 #endif
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        int idx16, int ki, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
+                        int idx16, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // group queue of this launch
     if (e != hipSuccess) return e;
@@ -2508,7 +2412,7 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
+    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order, (void *)&warm, (void *)&dyn_delta,
                         (void *)&dyn_eps};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
@@ -2551,14 +2455,14 @@ hipError_t launch_debug_scalings(int ps, double *inst, double *work, int i, int 
     return hipGetLastError();
 }
 #endif // !EICOS_LDSRES
-hipError_t solve_occupancy(int threads, int nlds, int idx16, int ki, size_t dyn_lds, int *blocks_per_cu) {
-    return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu) {
+    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, threads, dyn_lds);
     });
 }
-hipError_t solve_set_max_lds(int threads, int nlds, int idx16, int ki, size_t dyn_lds) {
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds) {
     if (dyn_lds == 0) return hipSuccess;
-    return dispatch_solve(threads, nlds, idx16, ki, [&](const void *fn) {
+    return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
     });
 }

@@ -60,9 +60,9 @@ typedef struct eicos_dims {
     long long factor_pairs;      /* multiply-subtract pairs of one numeric factorisation */
     size_t inst_bytes, work_bytes, pattern_bytes;
     int threads_per_block;
-    int resident_blocks; /* instances resident on the GPU at a time = resident workgroups x instances_per_block */
+    int resident_blocks; /* instances resident on the GPU at a time = resident workgroups */
     int lds_bytes; /* dynamic LDS per workgroup (solve vector staged in LDS), 0 if in HBM */
-    int instances_per_block; /* instances a workgroup solves in lock-step (1 or 2) */
+    int instances_per_block; /* always 1 (field kept for ABI stability: the lock-step pairs of round 2 were measured slower and removed) */
     int lds_resident; /* 1: small pattern, the solve works on LDS copies of the instance's slabs (lds_bytes includes them) */
     int factor_path;  /* 0 scalar level-scheduled program, 1 dense 16x16 tiles (MFMA), 2 hybrid: tiles for the top of the tree */
 } eicos_dims;
