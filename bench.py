@@ -153,12 +153,16 @@ class Job:
         dev = self.devs[0]["c"].device
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         cnt = torch.tensor([int(ia["iter"].sum()), int((ia["exitcode"] == 0).sum()), self.B], dtype=torch.float64, device=dev)
+        km = float(np.mean(kernel_ms))
+        kmin = torch.tensor([km], dtype=torch.float64, device=dev); kmax = kmin.clone()
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            dist.all_reduce(kmin, op=dist.ReduceOp.MIN)  # launch skew between the ranks (timing only: no data-path collective)
+            dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         tot_iters, tot_ok, tot_B = (int(v) for v in cnt.tolist())
-        return dict(dt=float(t.item()), iters=tot_iters, ok=tot_ok, instances=tot_B, ia=ia,
-                    kernel_ms=float(np.mean(kernel_ms)), update_ms=float(np.mean(update_ms)))
+        return dict(dt=float(t.item()), iters=tot_iters, ok=tot_ok, instances=tot_B, ia=ia, kernel_ms=km, update_ms=float(np.mean(update_ms)),
+                    kernel_ms_min_over_ranks=float(kmin.item()), kernel_ms_max_over_ranks=float(kmax.item()))
 
     def report(self, r, steps, tag):
         dims, ia = self.dims, r["ia"]
@@ -174,6 +178,7 @@ class Job:
             "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
             "factor_path": ("scalar", "tile", "hybrid")[dims.get("factor_path", 0)], "lds_resident": bool(dims.get("lds_resident", 0)),
             "update_kernel_ms": r["update_ms"],
+            "kernel_ms_min_over_ranks": r["kernel_ms_min_over_ranks"], "kernel_ms_max_over_ranks": r["kernel_ms_max_over_ranks"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                          "kernel": "k_solve", "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": abytes},
