@@ -67,10 +67,10 @@ constexpr int TRI_DEPTH = EICOS_TRI_DEPTH; // ... this many slices ahead of thei
 #ifndef EICOS_TRI_TRIP
 #define EICOS_TRI_TRIP 6
 #endif
-constexpr int TRI_TRIP = EICOS_TRI_TRIP;   // slices per trip of the (unrolled) sweep loops, see ELL_TRIP; plans are padded to a multiple
+constexpr int TRI_TRIP = EICOS_TRI_TRIP;   // slices per trip of the (unrolled) sweep loops, see ELL_TRIP
 static_assert(TRI_TRIP % TRI_DEPTH == 0, "the register queue rotates inside a trip");
 constexpr int ELL_DEPTH = EICOS_ELL_DEPTH; // same for the matrix-vector products
-// Slices per trip of the (unrolled) product loops; plans are padded to a multiple.  The compiler's s_waitcnt insertion is
+// Slices per trip of the (unrolled) product loops (the remainder of a plan runs in trips of ELL_DEPTH).  The compiler's s_waitcnt insertion is
 // exact inside a trip but drains the whole load queue at the loop head (s_waitcnt vmcnt(0)), so a trip of ELL_DEPTH slices
 // exposes a full memory round trip every ELL_DEPTH slices.
 #ifndef EICOS_ELL_TRIP

@@ -347,30 +347,39 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
     };
 #pragma unroll
     for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
-    for (int s0 = 0; s0 < ns; s0 += ELL_TRIP) {
+    // one slice step; `d` = the slice's slot of the register queue.  A trip of ELL_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
+    // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of ELL_DEPTH, so
+    // plans are padded to a multiple of ELL_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
+    auto step = [&](const int d, const int s) __attribute__((always_inline)) {
+        const Sl m = meta(s);
+        int ci[ELL_KMAX]; double cv[ELL_KMAX];
+        const R cr = qr[d];
 #pragma unroll
-        for (int u = 0; u < ELL_TRIP; u++) {
-            const int d = u % ELL_DEPTH, s = s0 + u;
-            const Sl m = meta(s);
-            int ci[ELL_KMAX]; double cv[ELL_KMAX];
-            const R cr = qr[d];
+        for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
+        load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
+        const int lanes = m.cnt << m.lg;
+        const bool act = t < lanes;
+        double xg[ELL_KMAX];
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
-            load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
-            const int lanes = m.cnt << m.lg;
-            const bool act = t < lanes;
-            double xg[ELL_KMAX];
+        for (int kk = 0; kk < ELL_KMAX; kk++) xg[kk] = x[ci[kk]];
+        __builtin_amdgcn_sched_barrier(0);
+        double acc = 0.;
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) xg[kk] = x[ci[kk]];
-            __builtin_amdgcn_sched_barrier(0);
-            double acc = 0.;
+        for (int kk = 0; kk < ELL_KMAX; kk++) acc = madd(acc, cv[kk], xg[kk]);
+        acc = grp_reduce_to_lane0(acc, m.lg);
+        if (m.cont) acc += carry;
+        if (m.more) carry = acc;
+        else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc, cr);
+    
+    };
+    int s0 = 0;
+    for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) acc = madd(acc, cv[kk], xg[kk]);
-            acc = grp_reduce_to_lane0(acc, m.lg);
-            if (m.cont) acc += carry;
-            if (m.more) carry = acc;
-            else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc, cr);
-        }
+        for (int u = 0; u < ELL_TRIP; u++) step(u % ELL_DEPTH, s0 + u);
+    }
+    for (; s0 < ns; s0 += ELL_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < ELL_DEPTH; u++) step(u, s0 + u);
     }
 }
 
@@ -407,38 +416,47 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
     };
 #pragma unroll
     for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
-    for (int s0 = 0; s0 < ns; s0 += ELL_TRIP) {
+    // one slice step; `d` = the slice's slot of the register queue.  A trip of ELL_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
+    // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of ELL_DEPTH, so
+    // plans are padded to a multiple of ELL_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
+    auto step = [&](const int d, const int s) __attribute__((always_inline)) {
+        const Sl m = meta(s);
+        int ci[ELL_KMAX]; double cv[ELL_KMAX][KI]; R cr[KI];
 #pragma unroll
-        for (int u = 0; u < ELL_TRIP; u++) {
-            const int d = u % ELL_DEPTH, s = s0 + u;
-            const Sl m = meta(s);
-            int ci[ELL_KMAX]; double cv[ELL_KMAX][KI]; R cr[KI];
+        for (int k = 0; k < KI; k++) cr[k] = qr[d][k];
 #pragma unroll
-            for (int k = 0; k < KI; k++) cr[k] = qr[d][k];
+        for (int kk = 0; kk < ELL_KMAX; kk++) {
+            ci[kk] = qi[d][kk];
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) {
-                ci[kk] = qi[d][kk];
-#pragma unroll
-                for (int k = 0; k < KI; k++) cv[kk][k] = qv[d][kk][k];
-            }
-            load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
-            const int lanes = m.cnt << m.lg;
-            const bool act = t < lanes;
-            double xg[ELL_KMAX][KI];
-#pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(x, ci[kk], xg[kk]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                double acc = 0.;
-#pragma unroll
-                for (int kk = 0; kk < ELL_KMAX; kk++) acc = madd(acc, cv[kk][k], xg[kk][k]);
-                acc = grp_reduce_to_lane0(acc, m.lg);
-                if (m.cont) acc += carry[k];
-                if (m.more) carry[k] = acc;
-                else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(k, m.row0 + (t >> m.lg), acc, cr[k]);
-            }
+            for (int k = 0; k < KI; k++) cv[kk][k] = qv[d][kk][k];
         }
+        load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
+        const int lanes = m.cnt << m.lg;
+        const bool act = t < lanes;
+        double xg[ELL_KMAX][KI];
+#pragma unroll
+        for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(x, ci[kk], xg[kk]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            double acc = 0.;
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) acc = madd(acc, cv[kk][k], xg[kk][k]);
+            acc = grp_reduce_to_lane0(acc, m.lg);
+            if (m.cont) acc += carry[k];
+            if (m.more) carry[k] = acc;
+            else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(k, m.row0 + (t >> m.lg), acc, cr[k]);
+        }
+    
+    };
+    int s0 = 0;
+    for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
+#pragma unroll
+        for (int u = 0; u < ELL_TRIP; u++) step(u % ELL_DEPTH, s0 + u);
+    }
+    for (; s0 < ns; s0 += ELL_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < ELL_DEPTH; u++) step(u, s0 + u);
     }
 }
 
@@ -505,48 +523,57 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
         } else ldK_g<KI, false>(invD, r, o.d);
         ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
-    // ns is a multiple of TRI_TRIP (the host pads plans with empty slices) and refills past the end
+    // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
 #pragma unroll
     for (int d = 0; d < TRI_DEPTH; d++) load(d < ns ? d : 0, q[d]);
-    for (int s0 = 0; s0 < ns; s0 += TRI_TRIP) {
+    // one slice step; `d` = the slice's slot of the register queue.  A trip of TRI_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
+    // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of TRI_DEPTH, so
+    // plans are padded to a multiple of TRI_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
+    auto step = [&](const int d, const int s) __attribute__((always_inline)) {
+        const Slot c = q[d];
+        load(min(s + TRI_DEPTH, ns - 1), q[d]);
+        if (c.newlev) {
+            if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
+            else if (LDSBAR) lds_barrier();
+            else __syncthreads();
+        }
+        double xg[ELL_KMAX][KI]; // all gathers in flight before the first multiply (the scheduler would serialise them)
 #pragma unroll
-        for (int u = 0; u < TRI_TRIP; u++) {
-            const int d = u % TRI_DEPTH, s = s0 + u;
-            const Slot c = q[d];
-            load(min(s + TRI_DEPTH, ns - 1), q[d]);
-            if (c.newlev) {
-                if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
-                else if (LDSBAR) lds_barrier();
-                else __syncthreads();
-            }
-            double xg[ELL_KMAX][KI]; // all gathers in flight before the first multiply (the scheduler would serialise them)
+        for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, c.idx[kk], xg[kk]);
+        __builtin_amdgcn_sched_barrier(0);
+        double acc[KI];
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, c.idx[kk], xg[kk]);
-            __builtin_amdgcn_sched_barrier(0);
-            double acc[KI];
+        for (int k = 0; k < KI; k++) {
+            double a = 0.;
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) a = madd(a, c.val[kk][k], xg[kk][k]);
+            acc[k] = grp_reduce_to_lane0(a, c.lg);
+        }
+        if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
+            const int r = c.row0 + (t >> c.lg);
+            // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
+            // (same lane, program order), and only the last one applies the pivot
+            double cur[KI], out[KI];
+            if (c.cont) ldK<KI>(ws, r, cur);
 #pragma unroll
             for (int k = 0; k < KI; k++) {
-                double a = 0.;
-#pragma unroll
-                for (int kk = 0; kk < ELL_KMAX; kk++) a = madd(a, c.val[kk][k], xg[kk][k]);
-                acc[k] = grp_reduce_to_lane0(a, c.lg);
+                const double v = (c.cont ? cur[k] : c.own[k]) - acc[k];
+                out[k] = (FORWARD || c.more) ? v         // y_i = b_i - sum_k L[i,k] y_k
+                                             : v * c.d[k]; // x_j = (y_j - sum_i U[i,j] x_i) / D_j
             }
-            if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
-                const int r = c.row0 + (t >> c.lg);
-                // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
-                // (same lane, program order), and only the last one applies the pivot
-                double cur[KI], out[KI];
-                if (c.cont) ldK<KI>(ws, r, cur);
-#pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    const double v = (c.cont ? cur[k] : c.own[k]) - acc[k];
-                    out[k] = (FORWARD || c.more) ? v         // y_i = b_i - sum_k L[i,k] y_k
-                                                 : v * c.d[k]; // x_j = (y_j - sum_i U[i,j] x_i) / D_j
-                }
-                stK<KI>(ws, r, out);
-            }
+            stK<KI>(ws, r, out);
         }
+    
+    };
+    int s0 = 0;
+    for (; s0 + TRI_TRIP <= ns; s0 += TRI_TRIP) {
+#pragma unroll
+        for (int u = 0; u < TRI_TRIP; u++) step(u % TRI_DEPTH, s0 + u);
+    }
+    for (; s0 < ns; s0 += TRI_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < TRI_DEPTH; u++) step(u, s0 + u);
     }
     if (!SOLO) __syncthreads();
 }

@@ -76,8 +76,8 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
             first = false;
         }
     };
-    auto pad = [&]() { // empty slices: no loop tail in the kernel's software pipeline (TRI_TRIP slices per trip)
-        while (pl.sl.size() % TRI_TRIP) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0});
+    auto pad = [&]() { // empty slices: no loop tail in the kernel's software pipeline (trips of TRI_TRIP slices, remainder in trips of TRI_DEPTH)
+        while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0});
     };
     // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
     const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
@@ -170,7 +170,7 @@ EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T) {
         r += cnt;
     }
     pl.src.push_back(-1); // dummy slot (index `slots`)
-    while (pl.sl.size() % ELL_TRIP) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // no loop tail
+    while (pl.sl.size() % ELL_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); // no loop tail
     return pl;
 }
 
