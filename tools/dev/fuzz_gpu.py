@@ -1,6 +1,7 @@
 """Dev script (GPU): randomized differential campaign GPU vs oracle over random sparse SOCP patterns and kernel
 variants.  usage: python tools/dev/fuzz_gpu.py [n_cases] [seed0]"""
 import os, sys, time
+os.environ["EICOS_EXPERIMENT"] = "1"  # the kernel-variant knobs are honoured only under this opt-in (csrc/envknob.hpp)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -24,7 +25,7 @@ for case in range(ncase):
     if l + sum(q) == 0:
         l = 3
     dens = float(rng.choice([0.05, 0.15, 0.3, 0.6])) / scale
-    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL"):
+    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL", "EICOS_FAC_L0", "EICOS_CONE_ORDER"):
         os.environ.pop(k, None)
     var = {}
     if rng.random() < 0.7:
@@ -42,6 +43,11 @@ for case in range(ncase):
         var["EICOS_LDSRES"] = "0"
     if rng.random() < 0.3:
         var["EICOS_DUAL"] = "0"
+    # round 3: the streamed level 0 of the factor program off, the cone-aware elimination order forced / forbidden
+    if rng.random() < 0.2:
+        var["EICOS_FAC_L0"] = "0"
+    if rng.random() < 0.4:
+        var["EICOS_CONE_ORDER"] = str(rng.choice([0, 1]))
     os.environ.update(var)
     try:
         pat, base = random_socp_pattern(n, p, l, q, density=dens, seed=seed0 + case)

@@ -1,5 +1,6 @@
 """Dev script (GPU): one fuzz case in detail.  usage: python tools/dev/r2_case.py <seed> <scale> <dyn 0|1> KEY=VAL ..."""
 import os, sys
+os.environ["EICOS_EXPERIMENT"] = "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -21,7 +22,7 @@ import scipy.sparse as sp
 G = [sp.csc_matrix((d["Gpr"][i], pat.Gir, pat.Gjc), shape=(pat.m, pat.n)) for i in range(3)]
 A = [sp.csc_matrix((d["Apr"][i], pat.Air, pat.Ajc), shape=(pat.p, pat.n)) for i in range(3)]
 xs = {}
-KEYS = ("EICOS_LDSRES", "EICOS_TILES", "EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_DUAL")
+KEYS = ("EICOS_LDSRES", "EICOS_TILES", "EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_DUAL", "EICOS_FAC_L0", "EICOS_CONE_ORDER")
 for env in (envv, {}, {"EICOS_TILES": "0", "EICOS_LDSRES": "0"}):
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)

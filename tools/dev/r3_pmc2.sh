@@ -3,7 +3,8 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
 rm -rf gpurun_out/pmc_$tag
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+# (a TCC_EA0_* group made rocprofv3 abort and hang until its timeout on this pool: not collected)
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   t=$(echo $c | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/$t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-soc --no-configs "$@" > gpurun_out/pmc_${tag}_$t.log 2>&1
   echo "$t rc=$?"
