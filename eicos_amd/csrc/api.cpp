@@ -279,7 +279,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     } else D.w_gpart = D.w_gx = D.w_gz = 0;
     // ---- the arrays of the factorisation / KKT solve ----
     D.w_xk = Wl.add((size_t)NV + 16); D.w_ek = Wl.add((size_t)NV + 16); D.w_dxr = Wl.add(NV);
-    D.w_D = Wl.add(NV); D.w_invD = Wl.add(NV); // w_UF / w_UB are added once the slice plans are known
+    D.w_D = Wl.add(NV); D.w_invD = Wl.add((size_t)NV + 8); // (+ the always-zero slot fac_kpad of the deferred-L factorisation) // w_UF / w_UB are added once the slice plans are known
 
     // ---- pattern arrays ----
     IntPool pool;
@@ -318,7 +318,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
     FactorPlan planX;
     if (!tile1) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
-    else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); }
+    else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); planX.pbU.assign(1, 0); planX.pk.assign(1, 0); }
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
     if ((long long)planB.slots + 1 >= IMG_BASE || (long long)S.N >= DIAG_POS / 2) { delete h; return fail(EICOS_E_UNSUPPORTED, "pattern too large for the factor program's destination codes"); }
     {   // level 0 of the factor program: the leaves of the elimination tree have no pairs; the kernel streams over their targets
@@ -393,12 +393,15 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     const std::vector<int> rG_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx, 0), rG_k_w16 = pack16(prG.sl, rG_o16, D.rG_d16, rG_idx_k, NV);
     // factor program: the (pa, pb) slot pairs of a lane, 16 bytes per lane and slice (pa words then pb words)
     const std::vector<int> x_o16 = lane_offsets(planX.sl, D.fac_d16);
-    std::vector<int> fac_w16;
+    std::vector<int> fac_w16, fac_w16d, fac_k16;
     {
         const std::vector<int> wa = pack16(planX.sl, x_o16, D.fac_d16, planX.pa, planB.slots), wb = pack16(planX.sl, x_o16, D.fac_d16, planX.pb, planF.slots);
-        fac_w16.resize(wa.size() * 2);
+        const std::vector<int> wu = pack16(planX.sl, x_o16, D.fac_d16, planX.pbU, planB.slots); // deferred-L form: both operands are UB slots
+        fac_k16 = pack16(planX.sl, x_o16, D.fac_d16, planX.pk, S.N);                             // ... and the pivot column of every pair
+        fac_w16.resize(wa.size() * 2); fac_w16d.resize(wa.size() * 2);
         for (size_t e = 0; e * 2 < wa.size(); e++) {
             fac_w16[4 * e] = wa[2 * e]; fac_w16[4 * e + 1] = wa[2 * e + 1]; fac_w16[4 * e + 2] = wb[2 * e]; fac_w16[4 * e + 3] = wb[2 * e + 1];
+            fac_w16d[4 * e] = wa[2 * e]; fac_w16d[4 * e + 1] = wa[2 * e + 1]; fac_w16d[4 * e + 2] = wu[2 * e]; fac_w16d[4 * e + 3] = wu[2 * e + 1];
         }
     }
     D.idx16 = (idx16_ok && env_int("EICOS_IDX16", 1, 0, 1)) ? 1 : 0;
@@ -485,7 +488,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     put(D.v2t, v2t);
     const int *fac_sl_p = nullptr;
     put(fac_sl_p, fac_sl_i);
-    put(D.fac_pa, planX.pa); put(D.fac_pb, planX.pb); put(D.fac_p16, fac_w16);
+    const int *fac_pb_f = nullptr, *fac_pb_u = nullptr, *fac_p16_f = nullptr, *fac_p16_u = nullptr; // (stored-L / deferred-L forms: chosen with NLDS below)
+    put(D.fac_pa, planX.pa); put(fac_pb_f, planX.pb); put(fac_pb_u, planX.pbU); put(fac_p16_f, fac_w16); put(fac_p16_u, fac_w16d);
+    put(D.fac_pk, planX.pk); put(D.fac_k16, fac_k16);
     put(D.fac_src, fac_src); put(D.fac_dst, fac_dst); put(D.fac_dstF, fac_dstF); put(D.fac_col, fac_col);
 
     // ---- device resources ----
@@ -539,6 +544,12 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         D.dual = dual;
         const int nvec = dual ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
+        // deferred-L factorisation (device_types.hpp: fac_defer): needs the idle LDS solve vector for the mirror of 1/D
+        // It trades one LDS read per pair for a write + read of every L entry and one barrier per level: measured +1.5..3.3 % on MPC02 and
+        // nine Netlib patterns (pairs/nnzL 1.7..7.5), -1 % on lp_25fv47 (10.1) -- profiles/r03_log_defer.log; the rule below is that fit.
+        const int defer_auto = (double)S.npairs <= 8.0 * (double)S.nnzL ? 1 : 0;
+        D.fac_defer = (!tile1 && h->nlds >= 1 && env_int("EICOS_FAC_DEFER", defer_auto, 0, 1)) ? 1 : 0;
+        D.fac_kpad = S.N;
         h->dyn_lds = h->nlds >= 1 ? (size_t)nvec * vec + meta : scratch;
         D.lds_tab = h->nlds >= 1 ? nvec * D.Npad : 0;
         D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
@@ -605,6 +616,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     HIP_TRY_H(hipMalloc(&h->d_pattern, pool.data.size() * sizeof(int)));
     HIP_TRY_H(hipMemcpy(h->d_pattern, pool.data.data(), pool.data.size() * sizeof(int), hipMemcpyHostToDevice));
     for (auto &s : slots) *s.dst = h->d_pattern + s.off;
+    D.fac_pb = D.fac_defer ? fac_pb_u : fac_pb_f; D.fac_p16 = D.fac_defer ? fac_p16_u : fac_p16_f;
     D.fsl = reinterpret_cast<const PackedSlice *>(fsl_p); D.bsl = reinterpret_cast<const PackedSlice *>(bsl_p);
     D.cag_sl = reinterpret_cast<const PackedSlice *>(cag_sl_p); D.rA_sl = reinterpret_cast<const PackedSlice *>(rA_sl_p);
     D.rG_sl = reinterpret_cast<const PackedSlice *>(rG_sl_p);

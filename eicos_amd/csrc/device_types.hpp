@@ -126,6 +126,10 @@ struct DevPat {
     gint_p v2t;                    // [nV] scaling-block entry -> its target
     gint_p fac_pa, fac_pb, fac_src, fac_dst, fac_dstF, fac_col;
     gint_p fac_p16; int fac_d16; // idx16: per lane and slice the four (pa, pb) pairs as eight 16-bit slot numbers (16 bytes)
+    // fac_defer = 1 (needs an LDS vector: NLDS >= 1): pb names U[j,k] (a UB slot) and fac_pk / fac_k16 the pivot column k; the
+    // factorisation keeps a mirror of 1/D in the (then idle) LDS solve vector and forms L[j,k] = U[j,k] * (1/D[k]) on the fly --
+    // bit-identical to the stored L -- so no level needs a second phase; L goes to its forward slots in one pass at the end
+    int fac_defer, fac_kpad; gint_p fac_pk, fac_k16; // fac_kpad: the pivot-column index of padding pairs (its mirror slot holds 0)
     // ---- tile mode (dense fronts, tiles.hpp): L = block-sparse matrix of dense 16 x 16 tiles; D.N is then 16 * nb ----
     int tile, nb, nt, nblev;       // 1 = tile path, 2 = hybrid (top block of the tree on tiles); blocks, off-diagonal tiles, block levels
     int tl_base;                   // slot of block 0 in the KKT-space vectors (hybrid: the scalar part comes first)

@@ -781,7 +781,15 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     // Everything that does not depend on factor values (pair indices, the K entry, destinations) is loaded
     // FAC_DEPTH slices ahead, across the level barriers, so a level costs one dependent gather round trip
     // per phase instead of an index load + gather + source-index load + value load chain.
-    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
+    struct FSlot { int row0, cnt, lg, K, off, lanes, newlev, last, more, cont; int ia[ELL_KMAX], ib[ELL_KMAX], ik[ELL_KMAX]; double kv; int dst; } q[FAC_DEPTH];
+    // Deferred L (DevPat::fac_defer; needs the LDS solve vector, idle during the factorisation, as a mirror of 1/D): a pair is
+    // U[i,k] * (U[j,k] * (1/D[k])) with 1/D[k] gathered from LDS -- the product in brackets is exactly the stored L[j,k] -- so the
+    // forward-order copy of L is not needed before the sweeps: no phase B, ONE barrier per level, L written in one pass at the end
+    const bool defer = P.fac_defer != 0;
+    // 1/D[k] of a pair's pivot column: from the LDS mirror ([0, N] at the start of the dynamic LDS, slot fac_kpad = 0 for padding
+    // pairs), or -- kernels without an LDS vector: only the debug entry, api.cpp sets fac_defer with NLDS >= 1 -- from the array itself
+    auto inv_of = [&](int k) -> double { if constexpr (NLDS >= 1) return g_dyn[k]; else return invD[k]; };
+    gcdbl_p Lsrc = defer ? (gcdbl_p)U : (gcdbl_p)UF;
     double carry = 0.; // partial sum of targets cut into sub-slices
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
@@ -793,15 +801,17 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
         o.more = nm.more; o.cont = nm.cont;
         o.lanes = o.cnt << o.lg;
         const bool act = tid < o.lanes;
-        if constexpr (I16) { // the lane's four (pa, pb) pairs packed as eight 16-bit slot numbers: one 16-byte load
+        if constexpr (I16) { // the lane's four (pa, pb) pairs packed as eight 16-bit slot numbers: one 16-byte load (+ 8 bytes: the pivot columns)
             const uint4 w = ld_u32(reinterpret_cast<const uint4 EICOS_GLOBAL *>(P.fac_p16), act ? nm.off16 + tid : P.fac_d16);
+            const uint2 wk = ld_u32(reinterpret_cast<const uint2 EICOS_GLOBAL *>(P.fac_k16), act ? nm.off16 + tid : P.fac_d16);
             o.ia[0] = w.x & 0xffffu; o.ia[1] = w.x >> 16; o.ia[2] = w.y & 0xffffu; o.ia[3] = w.y >> 16;
             o.ib[0] = w.z & 0xffffu; o.ib[1] = w.z >> 16; o.ib[2] = w.w & 0xffffu; o.ib[3] = w.w >> 16;
+            o.ik[0] = wk.x & 0xffffu; o.ik[1] = wk.x >> 16; o.ik[2] = wk.y & 0xffffu; o.ik[3] = wk.y >> 16;
         } else {
 #pragma unroll
             for (int u = 0; u < ELL_KMAX; u++) {
                 const int slot = (act && u < o.K) ? o.off + u * o.lanes + tid : P.fac_slots; // dummy pair: 0 * 0
-                o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot];
+                o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot]; o.ik[u] = P.fac_pk[slot];
             }
         }
         const int t = act ? o.row0 + (tid >> o.lg) : 0;
@@ -819,12 +829,15 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             if (sg * val <= g_S.dyn_eps) val = sg * g_S.dyn_delta;
         }
         if (val == 0.) g_S.fl[FL_FATAL] = 1; // (Eigen: NumericalIssue)
-        D[j] = val; invD[j] = 1. / val;
+        const double iv = 1. / val;
+        D[j] = val; invD[j] = iv;
+        if constexpr (NLDS >= 1) { if (defer) g_dyn[j] = iv; }
     };
     // ---- level 0 (the leaves of the elimination tree: two thirds of the nodes of an MPC pattern) has no pairs at all:
     // D_j = K_jj, U_ij = K_ij, L_ij = K_ij / D_j.  Two streaming passes over its targets (diagonals first, host: api.cpp)
     // instead of a slice step per 256 targets: coalesced reads of the K stream, eight targets per thread in flight ----
     const int sbeg = P.fac_s1;
+    if constexpr (NLDS >= 1) { if (defer) { if (tid == 0) g_dyn[P.fac_kpad] = 0.; __syncthreads(); } } // (what padding pairs read; the global array keeps a 0 there)
     if (P.fac_nt0 > 0) {
         for_t_pre<T, 8>(P.fac_nd0, [&](int t) { return IV1{ld_u32(P.fac_dst, t), ld_u32(Kt, t)}; }, [&](int t, const IV1 &r) {
             if (r.i >= IMG_BASE) Kimg[r.i - IMG_BASE] = r.a; else pivot(r.i, r.a);
@@ -833,7 +846,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
         struct F1 { int dst, dstF; double kv, d; };
         for_t_pre<T, 8>(P.fac_nt0 - P.fac_nd0, [&](int q_) {
             const int t = P.fac_nd0 + q_;
-            return F1{ld_u32(P.fac_dst, t), ld_u32(P.fac_dstF, t), ld_u32(Kt, t), invD[ld_u32(P.fac_col, t)]};
+            const int col = ld_u32(P.fac_col, t);
+            return F1{ld_u32(P.fac_dst, t), ld_u32(P.fac_dstF, t), ld_u32(Kt, t), defer ? inv_of(col) : invD[col]};
         }, [&](int, const F1 &r) {
             if (r.dst >= IMG_BASE) { Kimg[r.dst - IMG_BASE] = r.kv; return; }
             U[r.dst] = r.kv;
@@ -853,7 +867,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     for (int d = 0; d < FAC_DEPTH; d++) fload(fmeta(min(sbeg + d, ns - 1)), q[d]);
     Sl pm = fmeta(min(sbeg + FAC_DEPTH, ns - 1)); // descriptor of the next slice to be loaded
     int lvl_t0 = 0;
-    double gu[2][ELL_KMAX], gl[2][ELL_KMAX];
+    double gu[2][ELL_KMAX], gl[2][ELL_KMAX], gk[2][ELL_KMAX];
     static_assert(FAC_DEPTH % 2 == 0, "operand register sets alternate with the queue slot");
     bool have = false;
     for (int s0 = sbeg; s0 < ns; s0 += FAC_DEPTH) {
@@ -870,10 +884,10 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             // gathered factor values: slices of one level are independent, so the next slice's gathers are issued before this
             // slice's arithmetic waits on its own (one L2 round trip per level, not per slice).  Two operand register sets, by
             // the parity of the slice's queue slot: no copies between a slice's gathers and their use
-            double (&cu)[ELL_KMAX] = gu[d & 1], (&cl)[ELL_KMAX] = gl[d & 1];
+            double (&cu)[ELL_KMAX] = gu[d & 1], (&cl)[ELL_KMAX] = gl[d & 1], (&ck)[ELL_KMAX] = gk[d & 1];
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { cu[u] = ld_u32((gcdbl_p)U, c.ia[u]); cl[u] = ld_u32((gcdbl_p)UF, c.ib[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) { cu[u] = ld_u32((gcdbl_p)U, c.ia[u]); cl[u] = ld_u32(Lsrc, c.ib[u]); ck[u] = defer ? inv_of(c.ik[u]) : 1.; }
             }
             have = !c.last;
             { // UNCONDITIONAL (when the next slice opens a new level its operands are not final yet: they are fetched again
@@ -881,11 +895,14 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
               // wait for this slice's operands with s_waitcnt vmcnt(8) instead of draining the queue at every slice
                 const FSlot &nx = q[(d + 1) % FAC_DEPTH];
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { gu[(d + 1) & 1][u] = ld_u32((gcdbl_p)U, nx.ia[u]); gl[(d + 1) & 1][u] = ld_u32((gcdbl_p)UF, nx.ib[u]); }
+                for (int u = 0; u < ELL_KMAX; u++) {
+                    gu[(d + 1) & 1][u] = ld_u32((gcdbl_p)U, nx.ia[u]); gl[(d + 1) & 1][u] = ld_u32(Lsrc, nx.ib[u]);
+                    gk[(d + 1) & 1][u] = defer ? inv_of(nx.ik[u]) : 1.;
+                }
             }
             double acc = 0.;
 #pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) acc = madd(acc, cu[u], cl[u]);
+            for (int u = 0; u < ELL_KMAX; u++) acc = madd(acc, cu[u], cl[u] * ck[u]); // (deferred: cl * ck IS the stored L[j,k]; else ck = 1)
             acc = grp_reduce_to_lane0(acc, c.lg);
             if (c.cont) acc += carry;
             if (c.more) carry = acc;
@@ -895,7 +912,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
                 else if (c.dst < 0) pivot(c.dst, val);
                 else U[c.dst] = val;
             }
-            if (c.last) {
+            if (c.last && defer) { FTICK(9); __syncthreads(); FTICK(10); } // the level's U, D and the pivot mirror are final
+            else if (c.last) {
                 FTICK(9);
                 __syncthreads();
                 FTICK(10);
@@ -936,6 +954,16 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             }
         }
     }
+    }
+    if (defer) { // L = U / D into the forward slots for every entry target beyond level 0 (level 0 wrote its own above): one pass
+        struct F2 { int dst, dstF; double u, d; };
+        for_t_pre<T, 8>(P.fac_nt - P.fac_nt0, [&](int q_) {
+            const int t = P.fac_nt0 + q_, dst = ld_u32(P.fac_dst, t);
+            return F2{dst, ld_u32(P.fac_dstF, t), U[(dst >= 0 && dst < IMG_BASE) ? dst : 0], inv_of(ld_u32(P.fac_col, t))};
+        }, [&](int, const F2 &r) {
+            if (r.dst >= 0 && r.dst < IMG_BASE && r.dstF >= 0) UF[r.dstF] = r.u * r.d;
+        });
+        FTICK(11);
     }
     }
     if (tid == 0) { g_S.wi.n_factor++; g_S.tick[TK_FACTOR] += wall_clock64() - tk0_; }

@@ -119,6 +119,8 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
             push_subslices(pl.sl, SliceMeta{(int)pl.target.size(), cnt, lg, K, pl.slots, first ? 1 : 0, 0, 0});
             pl.pa.resize((size_t)pl.slots + (size_t)K * lanes, dummyB);
             pl.pb.resize(pl.pa.size(), dummyF);
+            pl.pbU.resize(pl.pa.size(), dummyB);
+            pl.pk.resize(pl.pa.size(), S.N); // (slot N of the pivot mirror holds 0: a padding pair is 0 * (0 * 0))
             for (int i = r; i < r + cnt; i++) {
                 const int tgt = S.ftask[i];
                 pl.target.push_back(tgt);
@@ -126,6 +128,7 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
                     const int j = (int)(e - S.tp[tgt]), q = j % g, kk = j / g;
                     const int slot = pl.slots + kk * lanes + (i - r) * g + q;
                     pl.pa[slot] = posB[S.pa[e]]; pl.pb[slot] = posF[S.pb[e]]; // term = U[i,k] * L[j,k]
+                    pl.pbU[slot] = posB[S.pb[e]]; pl.pk[slot] = S.pk[e];       // ... = U[i,k] * (U[j,k] * (1 / D[k]))
                 }
             }
             pl.slots += K * lanes;
@@ -133,7 +136,7 @@ FactorPlan build_factor_plan(const Symbolic &S, int T, const std::vector<int> &p
             first = false;
         }
     }
-    pl.pa.push_back(dummyB); pl.pb.push_back(dummyF); // dummy slot `slots`
+    pl.pa.push_back(dummyB); pl.pb.push_back(dummyF); pl.pbU.push_back(dummyB); pl.pk.push_back(S.N); // dummy slot `slots`
     // newlev bit 1: last slice of its level (the kernel runs the level's second phase after it)
     for (size_t i = 0; i < pl.sl.size(); i++)
         if (i + 1 == pl.sl.size() || (pl.sl[i + 1].newlev & 1)) pl.sl[i].newlev |= 2;

@@ -40,6 +40,7 @@ EllPlan build_ell_plan(const std::vector<int> &ptr, int nrows, int T);
 struct FactorPlan {
     std::vector<SliceMeta> sl;       // row0 = index of the slice's first target in the per-target arrays
     std::vector<int> pa, pb;         // per slot: U[i,k] in the backward (column) slot order, L[j,k] in the forward (row) slot order
+    std::vector<int> pbU, pk;        // the same pair as U[j,k] (backward slot) and its pivot column k: term = U[i,k] * (U[j,k] / D[k])
     std::vector<int> target;         // per target: Symbolic target id (j < N: diagonal, N + e: entry e)
     int slots = 0;
 };

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import ALL_FIXTURES, load_fixture
 import eicos_amd
-from eicos_amd.generate import feasible_batch, mpc_soc_variant, perturbed_batch
+from eicos_amd.generate import SEED, feasible_batch, mpc_soc_variant, perturbed_batch
 from eicos_amd.problem_io import Values
 from oracle.oracle import OracleSolver
 from test_oracle_golden import in_cone, kkt_residuals
@@ -160,6 +160,8 @@ def test_dense_front_socp():
                                  {"EICOS_TILES": "1"}, {"EICOS_TILES": "1", "EICOS_NLDS": "0"}, {"EICOS_TILES": "1", "EICOS_THREADS": "128", "EICOS_NLDS": "2"},
                                  {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"},
                                  {"EICOS_FAC_L0": "0"}, {"EICOS_FAC_L0": "0", "EICOS_TILES": "0", "EICOS_THREADS": "256"},
+                                 {"EICOS_FAC_DEFER": "0"}, {"EICOS_FAC_DEFER": "1", "EICOS_TILES": "2"}, {"EICOS_FAC_DEFER": "1", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
+                                 {"EICOS_FAC_DEFER": "1", "EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_NLDS": "1"}, {"EICOS_FAC_DEFER": "1", "EICOS_FAC_L0": "0"},
                                  {"EICOS_LDSRES": "0"}, {"EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_TILES": "0"},
                                  {"EICOS_TILES": "1", "EICOS_GTILES": "2"}, {"EICOS_TILES": "1", "EICOS_GTILES": "2", "EICOS_DUAL": "0", "EICOS_THREADS": "256"},
                                  {"EICOS_TILES": "1", "EICOS_GTILES": "0"},
@@ -182,6 +184,25 @@ def test_every_kernel_variant_matches_oracle(env, monkeypatch):
             if oc == 0:
                 assert abs(gi[i]["pcost"] - oi["pcost"]) <= PCOST_RTOL * max(1.0, abs(oi["pcost"]))
         g.close(); o.close()
+
+
+@pytest.mark.parametrize("name", ["lp_bandm", "MPC02", "issue98", "lp_25fv47"])
+def test_deferred_l_factorisation_is_bit_identical_to_the_stored_l_one(name, monkeypatch):
+    # deferred L: a pair's L[j,k] is formed on the fly as U[j,k] * (1/D[k]) -- the same product, rounded the same way, as the
+    # stored entry of the other form -- so the two forms may not differ in a single bit of the iterates
+    pat, sets = load_fixture(name)
+    B = 3
+    d = perturbed_batch(pat, sets[0], 0, B, SEED)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("EICOS_FAC_DEFER", flag)
+        g = eicos_amd.BatchSolver(pat, B)
+        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"]); codes = g.solve().copy(); ia = g.info_arrays()
+        y, z, s_ = g.duals()
+        out.append((codes, ia["iter"].copy(), g.solution().copy(), z.copy()))
+        g.close()
+    for a_, b_ in zip(out[0], out[1]):
+        assert np.array_equal(a_, b_)
 
 
 def test_g_tile_products_match_the_ell_products_on_dense_fronts(monkeypatch):
