@@ -596,6 +596,21 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         bpc = forced > 0 ? std::min(forced, bpc) : best_r;
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
+    // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
+    // scattered stores and the read-back stay on chip.  Verified against the runtime's occupancy for the enlarged allocation.
+    D.e_lds = 0; D.e_off = 0;
+    if (!h->ldsres && h->nlds == 1 && !D.dual && S.tile != 1 && env_int("EICOS_E_LDS", 1, 0, 1)) {
+        const size_t base = (h->dyn_lds + 15) & ~(size_t)15, room = (160 * 1024) / (size_t)bpc;
+        size_t xs = room > base + 4096 + 1024 ? std::min<size_t>((size_t)NV, (room - base - 4096 - 1024) / sizeof(double)) & ~(size_t)15 : 0;
+        while (xs > 0) {
+            int got = 0;
+            HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, base + xs * sizeof(double)));
+            HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, base + xs * sizeof(double), &got));
+            if (got >= bpc) break;
+            xs = (xs * 3 / 4) & ~(size_t)15;
+        }
+        if (xs > 0) { D.e_lds = (int)xs; D.e_off = (int)(base / sizeof(double)); h->dyn_lds = base + xs * sizeof(double); }
+    }
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min(batch, resident);
     h->order_min = prop.multiProcessorCount;

@@ -129,6 +129,9 @@ struct DevPat {
     // fac_defer = 1 (needs an LDS vector: NLDS >= 1): pb names U[j,k] (a UB slot) and fac_pk / fac_k16 the pivot column k; the
     // factorisation keeps a mirror of 1/D in the (then idle) LDS solve vector and forms L[j,k] = U[j,k] * (1/D[k]) on the fly --
     // bit-identical to the stored L -- so no level needs a second phase; L goes to its forward slots in one pass at the end
+    // NLDS = 1 without dual right-hand sides: elimination positions [0, e_lds) of the refinement residual E are kept in LDS at g_dyn + e_off
+    // (doubles) -- the part of the CU's LDS that the chosen number of resident workgroups leaves unused
+    int e_lds, e_off;
     int fac_defer, fac_kpad; gint_p fac_pk, fac_k16; // fac_kpad: the pivot-column index of padding pairs (its mirror slot holds 0)
     // ---- tile mode (dense fronts, tiles.hpp): L = block-sparse matrix of dense 16 x 16 tiles; D.N is then 16 * nb ----
     int tile, nb, nt, nblev;       // 1 = tile path, 2 = hybrid (top block of the tree on tiles); blocks, off-diagonal tiles, block levels

@@ -1583,6 +1583,13 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return Wg + P.w_xk; }();
     auto E = [&] { if constexpr (DUAL) return Wg + P.w_dual_ek; else if constexpr (NLDS == 1) return Wg + P.w_ek; else return SV; }();
     gdbl_p Xg = DUAL ? Wg + P.w_dual_xk : Wg + P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
+    // NLDS = 1, one right-hand side: the first e_lds elimination positions of E live in the LDS the launch shape leaves free
+    // behind the tables (api.cpp) -- E is written by scattered 8-byte stores (partial lines in HBM) and read back once
+    constexpr bool ESPLIT = (NLDS == 1 && !DUAL);
+    const int e_lds = ESPLIT ? P.e_lds : 0;
+    double *EL = g_dyn + P.e_off;
+    auto stE = [&](int o, int k, double v) { if constexpr (ESPLIT) { if (o < e_lds) EL[o] = v; else E[o] = v; } else E[o * KI + k] = v; };
+    auto ldE = [&](int o, int k) -> double { if constexpr (ESPLIT) return o < e_lds ? EL[o] : (double)E[o]; else return E[o * KI + k]; };
     const PackedSlice *tabs = reinterpret_cast<const PackedSlice *>(g_dyn + P.lds_tab);
     auto tab_cag = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_cag; else return P.cag_sl; }();
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rA; else return P.rA_sl; }();
@@ -1691,14 +1698,14 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
                     [&](int k, int j, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - (s + pr.g) - DELTASTAT * X[o * KI + k]; // ex = bx - G'dz - A'dy - delta dx
-            E[o * KI + k] = e; nex[k] = fmax(nex[k], fabs(e));
+            stE(o, k, e); nex[k] = fmax(nex[k], fabs(e));
         });
         ell_dots_k<T, I16, KI, DUAL>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
                     [&](int k, int r) { return PreK{ld_u32(by[k], r), 0., ld_u32(P.ipy, r), 0, 0.}; },
                     [&](int k, int r, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - s + DELTASTAT * X[o * KI + k]; // ey = by - A dx + delta dy
-            E[o * KI + k] = e; ney[k] = fmax(ney[k], fabs(e));
+            stE(o, k, e); ney[k] = fmax(ney[k], fabs(e));
         });
         ell_dots_k<T, I16, KI, DUAL>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
                     [&](int k, int i) { return PreK{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i), gt ? gzv[i * KI + k] : 0.}; },
@@ -1707,7 +1714,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
             const double xo = X[o * KI + k];
             double v = pr.b - (s + pr.g) + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
             if (i < l) { v += init ? xo : pr.w * xo; nez[k] = fmax(nez[k], fabs(v)); } // ... + V dz (LP part)
-            E[o * KI + k] = v;
+            stE(o, k, v);
         });
         if (P.nc > 0) {
             __syncthreads();
@@ -1718,28 +1725,29 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
                     constexpr int g = decltype(G)::value;
                     const int d = P.cq[c], o = P.cone_off[c];
                     const int p1 = P.ipz[o] * KI + k, p3 = P.ipv[c] * KI + k, p4 = P.ipu[c] * KI + k;
+                    const int e1 = P.ipz[o], e3 = P.ipv[c], e4 = P.ipu[c];
                     double mx = 0.;
                     if (init) {
-                        for (int q = ln; q < d; q += g) { const int pq = P.ipz[o + q] * KI + k; const double v = E[pq] + X[pq]; E[pq] = v; mx = fmax(mx, fabs(v)); }
-                        if (ln == 0) { const double x3 = X[p3], x4 = X[p4]; E[p3] = x3; E[p4] = x4; mx = fmax(mx, fmax(fabs(x3), fabs(x4))); }
+                        for (int q = ln; q < d; q += g) { const int eq = P.ipz[o + q], pq = eq * KI + k; const double v = ldE(eq, k) + X[pq]; stE(eq, k, v); mx = fmax(mx, fabs(v)); }
+                        if (ln == 0) { const double x3 = X[p3], x4 = X[p4]; stE(e3, k, x3); stE(e4, k, x4); mx = fmax(mx, fmax(fabs(x3), fabs(x4))); }
                     } else {
                         gcdbl_p cs = csc[k] + c * CSC_STRIDE;
                         const double eta2 = cs[CS_ETA2], x1 = X[p1], x3 = X[p3], x4 = X[p4];
                         const double tt = cs[CS_V1] * x3 + cs[CS_U1] * x4;
                         double qtx = 0.;
                         for (int q = 1 + ln; q < d; q += g) {
-                            const int pq = P.ipz[o + q] * KI + k;
+                            const int eq = P.ipz[o + q], pq = eq * KI + k;
                             const double qq = qv[k][o + q], xq = X[pq];
-                            const double v = E[pq] + eta2 * (xq + tt * qq);
-                            E[pq] = v; mx = fmax(mx, fabs(v));
+                            const double v = ldE(eq, k) + eta2 * (xq + tt * qq);
+                            stE(eq, k, v); mx = fmax(mx, fabs(v));
                             qtx += qq * xq;
                         }
                         qtx = grp_sum<g>(qtx);
                         if (ln == 0) {
-                            const double v1 = E[p1] + eta2 * (cs[CS_D1] * x1 + cs[CS_U0] * x4);
+                            const double v1 = ldE(e1, k) + eta2 * (cs[CS_D1] * x1 + cs[CS_U0] * x4);
                             const double v3 = eta2 * (cs[CS_V1] * qtx + x3);
                             const double v4 = eta2 * (cs[CS_U0] * x1 + cs[CS_U1] * qtx - x4);
-                            E[p1] = v1; E[p3] = v3; E[p4] = v4;
+                            stE(e1, k, v1); stE(e3, k, v3); stE(e4, k, v4);
                             mx = fmax(mx, fmax(fabs(v1), fmax(fabs(v3), fabs(v4))));
                         }
                     }
@@ -1771,7 +1779,11 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         if (all_done) break;
         if constexpr (NLDS == 1) { // another step: park the iterate in the slab, residual -> sweep vector (unit stride)
             __syncthreads();
-            for_t_pre<T, 6>(N, [&](int i) { VKI<KI> r; ldK<KI>(E, i, r.v); return r; }, [&](int i, const VKI<KI> &r) {
+            for_t_pre<T, 6>(N, [&](int i) {
+                VKI<KI> r;
+                if constexpr (ESPLIT) r.v[0] = ldE(i, 0); else ldK<KI>(E, i, r.v);
+                return r;
+            }, [&](int i, const VKI<KI> &r) {
                 double c[KI];
                 ldK<KI>(X, i, c); stK<KI>(Xg, i, c); stK<KI>(SV, i, r.v);
             });
