@@ -579,12 +579,13 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 }
 
 // ---------------- lambda = W z (ref scale :485-507); ends with a barrier ----------------
-template <int T>
+// CONES_ONLY: the LP rows were done by the caller inside a fused pass (same product, out[i] = lpw[i] * zz[i])
+template <int T, bool CONES_ONLY = false>
 __device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out) {
     ps = uni(ps); W = uni_ptr(W); zz = uni_ptr(zz); out = uni_ptr(out);
     const DevPat &P = c_pat[ps];
     gcdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
-    for_t_pre<T, 8>(P.l, [&](int i) { return V2{lpw[i], zz[i]}; }, [&](int i, const V2 &r) { out[i] = r.a * r.b; });
+    if constexpr (!CONES_ONLY) for_t_pre<T, 8>(P.l, [&](int i) { return V2{lpw[i], zz[i]}; }, [&](int i, const V2 &r) { out[i] = r.a * r.b; });
     for_cones<T>(ps, [&](int c, auto G, int lane) {
         constexpr int g = decltype(G)::value;
         const int o = P.cone_off[c], d = P.cq[c];
@@ -627,17 +628,18 @@ __device__ __noinline__ void dev_bring_to_cone(int ps, gcdbl_p r, double sgn, gd
 }
 
 // ---------------- lineSearch (ref :1380-1469); result to every thread ----------------
-template <int T>
+// LP_DONE: the caller has formed the LP rows' min(ds / lam), min(dz / lam) per thread inside a fused pass (rmin0, smin0)
+template <int T, bool LP_DONE = false>
 __device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, double dtau,
-                                               double kap, double dkap) {
+                                               double kap, double dkap, double rmin0 = DBL_MAX, double smin0 = DBL_MAX) {
     ps = uni(ps); W = uni_ptr(W);
     const DevPat &P = c_pat[ps];
     gcdbl_p lam = W + P.w_lam, ds = W + P.w_dsw, dz = W + P.w_wdz;
     const int l = P.l;
     int phase = 0;
     __syncthreads();
-    double rmin = DBL_MAX, smin = DBL_MAX, cstep = 0., bad = 0.;
-    for_t_pre<T, 4>(l, [&](int i) { return V3{lam[i], ds[i], dz[i]}; },
+    double rmin = rmin0, smin = smin0, cstep = 0., bad = 0.;
+    if constexpr (!LP_DONE) for_t_pre<T, 4>(l, [&](int i) { return V3{lam[i], ds[i], dz[i]}; },
                     [&](int i, const V3 &r) { rmin = fmin(rmin, r.b / r.a); smin = fmin(smin, r.c / r.a); });
     auto cone_step = [&](int o, int d, auto G, int lane, bool &skipped) -> double {
         constexpr int g = decltype(G)::value;
@@ -1452,9 +1454,12 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     // ---- updateScalings (ref :411-479) + updateKKTScalings (ref :1691-1732) ----
     // the scaling block goes to the instance slab (Vv) and to the factor's target-ordered value stream (Kt)
     gdbl_p Kt = W + P.w_Kt;
+    const bool lp_only = P.nc == 0;
     for_t_pre<T, 4>(l, [&](int i) { return IV2{P.v2t[i], wsl[i], wz[i]}; }, [&](int i, const IV2 &r) {
         const double v = r.a / r.b;
-        lpv[i] = v; lpw[i] = sqrt(v); Vv[i] = -v - DELTASTAT; Kt[r.i] = -v - DELTASTAT;
+        const double w = sqrt(v);
+        lpv[i] = v; lpw[i] = w; Vv[i] = -v - DELTASTAT; Kt[r.i] = -v - DELTASTAT;
+        if (lp_only) lam[i] = w * r.b; // lambda = W z (ref :476) in the same pass when there is no cone that could fail
     });
     double firstfail = 1e300;
     if (P.nc > 0) {
@@ -1533,7 +1538,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
         });
     }
     __syncthreads();
-    if (firstfail >= 1e299) dev_scale<T>(ps, W, wz, lam); // lambda = W z only when every cone succeeded (ref :476)
+    if (!lp_only && firstfail >= 1e299) dev_scale<T>(ps, W, wz, lam); // lambda = W z only when every cone succeeded (ref :476)
     TICK_END(TK_RESID);
     return ST_FACTOR;
 }
@@ -1855,12 +1860,22 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         const double dtau_denom = kap / tau - d6[0] - d6[1] - d6[2];
         const double dtauaff = (g_S.sv[SV_RT] - kap + d6[3] + d6[4] + d6[5]) / dtau_denom;
         const double dkapaff = -kap - kap / tau * dtauaff;
-        for_t_pre<T, 8>(m, [&](int i) { return V2{dz2[i], dz1[i]}; }, [&](int i, const V2 &r) { dz2[i] = r.a + dtauaff * r.b; });
+        // LP rows, one pass: dz2 += dtauaff dz1 (kept in registers: nothing reads the affine dz2 of an LP row again), wdz = W dz2,
+        // dsw = -wdz - lam and the line search's ratios -- the element-wise operations of the four separate passes, unchanged
+        double rmin = DBL_MAX, smin = DBL_MAX;
+        for_t_pre<T, 4>(l, [&](int i) { return V4{dz2[i], dz1[i], lpw[i], lam[i]}; }, [&](int i, const V4 &r) {
+            const double z2 = r.a + dtauaff * r.b, w = r.c * z2, d = -w - r.d;
+            wdz[i] = w; dsw[i] = d;
+            rmin = fmin(rmin, d / r.d); smin = fmin(smin, w / r.d);
+        });
+        for_t_pre<T, 8>(m - l, [&](int i) { return V2{dz2[l + i], dz1[l + i]}; }, [&](int i, const V2 &r) { dz2[l + i] = r.a + dtauaff * r.b; });
         __syncthreads();
         if (tid == 0) { g_S.sv[SV_DTAUDEN] = dtau_denom; g_S.sv[SV_DTAUAFF] = dtauaff; g_S.sv[SV_DKAPAFF] = dkapaff; }
-        dev_scale<T>(ps, W, dz2, wdz);
-        for_t_pre<T, 8>(m, [&](int i) { return V2{wdz[i], lam[i]}; }, [&](int i, const V2 &r) { dsw[i] = -r.a - r.b; });
-        const double step_aff = dev_line_search<T>(ps, W, tau, dtauaff, kap, dkapaff);
+        if (P.nc > 0) {
+            dev_scale<T, true>(ps, W, dz2, wdz);
+            for_t_pre<T, 8>(m - l, [&](int i) { return V2{wdz[l + i], lam[l + i]}; }, [&](int i, const V2 &r) { dsw[l + i] = -r.a - r.b; });
+        }
+        const double step_aff = dev_line_search<T, true>(ps, W, tau, dtauaff, kap, dkapaff, rmin, smin);
         const double oms_ = 1. - step_aff;
         const double sigma = fmin(fmax(oms_ * oms_ * oms_, SIGMAMIN), SIGMAMAX);
         const double mu = wi.mu;
@@ -1868,12 +1883,14 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         if (tid == 0) { wi.step_aff = step_aff; wi.sigma = sigma; }
         // ---- RHScombined (ref :1282-1325) ----
         const double sigmamu = sigma * mu, oms = 1. - sigma;
-        for_t_pre<T, 4>(l, [&](int i) { return V4{lam[i], dsw[i], wdz[i], lpw[i]}; }, [&](int i, const V4 &r) {
-            // LP part: ds1 = lam*lam + dsw*wdz - sigmamu ; dsw = ds1/lam ; t1 = w*dsw
-            const double d1_ = r.a * r.a + r.b * r.c - sigmamu;
-            const double q_ = d1_ / r.a;
+        struct RC { int o; double lam, ds, wz, w, rz; };
+        for_t_pre<T, 4>(l, [&](int i) { return RC{P.ipz[i], lam[i], dsw[i], wdz[i], lpw[i], rz[i]}; }, [&](int i, const RC &r) {
+            // LP part: ds1 = lam*lam + dsw*wdz - sigmamu ; dsw = ds1/lam ; t1 = w*dsw (in registers) ; rhs2 row = -(1 - sigma) rz + t1
+            const double d1_ = r.lam * r.lam + r.ds * r.wz - sigmamu;
+            const double q_ = d1_ / r.lam;
             dsw[i] = q_;
-            t1[i] = r.d * q_;
+            const double v = -oms * r.rz + r.w * q_;
+            rhs2k[np + i] = v; rhs2[r.o] = v;
         });
         if (P.nc > 0) {
             for_cones<T>(ps, [&](int c, auto G, int ln) {
@@ -1915,7 +1932,7 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         __syncthreads();
         for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], rhs2k[j]}; }, [&](int j, const IV1 &r) { const double v = r.a * oms; rhs2k[j] = v; rhs2[r.i] = v; });
         for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], rhs2k[n + j]}; }, [&](int j, const IV1 &r) { const double v = r.a * oms; rhs2k[n + j] = v; rhs2[r.i] = v; });
-        for_t_pre<T, 8>(m, [&](int i) { return IV2{P.ipz[i], rz[i], t1[i]}; }, [&](int i, const IV2 &r) { const double v = -oms * r.a + r.b; rhs2k[np + i] = v; rhs2[r.i] = v; });
+        for_t_pre<T, 8>(m - l, [&](int i) { return IV2{P.ipz[l + i], rz[l + i], t1[l + i]}; }, [&](int i, const IV2 &r) { const double v = -oms * r.a + r.b; rhs2k[np + l + i] = v; rhs2[r.i] = v; });
         __syncthreads();
         stage = ST_KKT_COMB;
     } else { // ST_KKT_COMB, ref :1212-1252
@@ -1931,15 +1948,27 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         const double dkap = -(bkap + kap * dtau) / tau;
         for_t_pre<T, 4>(n, [&](int j) { return V2{dx2[j], dx1[j]}; }, [&](int j, const V2 &r) { dx2[j] = r.a + dtau * r.b; });
         for_t_pre<T, 4>(p, [&](int j) { return V2{dy2[j], dy1[j]}; }, [&](int j, const V2 &r) { dy2[j] = r.a + dtau * r.b; });
-        for_t_pre<T, 8>(m, [&](int i) { return V2{dz2[i], dz1[i]}; }, [&](int i, const V2 &r) { dz2[i] = r.a + dtau * r.b; });
+        // LP rows, one pass: dz2 += dtau dz1, wdz = W dz2 (registers), dsw = -(dsw + wdz) and the line search's ratios
+        double rmin = DBL_MAX, smin = DBL_MAX;
+        struct CB { double z2, z1, w, ds, lam; };
+        for_t_pre<T, 4>(l, [&](int i) { return CB{dz2[i], dz1[i], lpw[i], dsw[i], lam[i]}; }, [&](int i, const CB &r) {
+            const double z2 = r.z2 + dtau * r.z1, w = r.w * z2, d = -(r.ds + w);
+            dz2[i] = z2; dsw[i] = d;
+            rmin = fmin(rmin, d / r.lam); smin = fmin(smin, w / r.lam);
+        });
+        for_t_pre<T, 8>(m - l, [&](int i) { return V2{dz2[l + i], dz1[l + i]}; }, [&](int i, const V2 &r) { dz2[l + i] = r.a + dtau * r.b; });
         __syncthreads();
-        dev_scale<T>(ps, W, dz2, wdz);
-        for_t_pre<T, 8>(m, [&](int i) { return V2{dsw[i], wdz[i]}; }, [&](int i, const V2 &r) { dsw[i] = -(r.a + r.b); });
-        const double st = GAMMA * dev_line_search<T>(ps, W, tau, dtau, kap, dkap);
-        dev_scale<T>(ps, W, dsw, dsa);
+        if (P.nc > 0) {
+            dev_scale<T, true>(ps, W, dz2, wdz);
+            for_t_pre<T, 8>(m - l, [&](int i) { return V2{dsw[l + i], wdz[l + i]}; }, [&](int i, const V2 &r) { dsw[l + i] = -(r.a + r.b); });
+        }
+        const double st = GAMMA * dev_line_search<T, true>(ps, W, tau, dtau, kap, dkap, rmin, smin);
+        if (P.nc > 0) dev_scale<T, true>(ps, W, dsw, dsa);
         for_t_pre<T, 4>(n, [&](int j) { return V2{wx[j], dx2[j]}; }, [&](int j, const V2 &r) { wx[j] = r.a + st * r.b; });
         for_t_pre<T, 4>(p, [&](int j) { return V2{wy[j], dy2[j]}; }, [&](int j, const V2 &r) { wy[j] = r.a + st * r.b; });
-        for_t_pre<T, 4>(m, [&](int i) { return V4{wz[i], dz2[i], wsl[i], dsa[i]}; }, [&](int i, const V4 &r) { wz[i] = r.a + st * r.b; wsl[i] = r.c + st * r.d; });
+        // LP rows: ds = W dsw formed in registers
+        for_t_pre<T, 4>(l, [&](int i) { return CB{wz[i], dz2[i], lpw[i], dsw[i], wsl[i]}; }, [&](int i, const CB &r) { wz[i] = r.z2 + st * r.z1; wsl[i] = r.lam + st * (r.w * r.ds); });
+        for_t_pre<T, 4>(m - l, [&](int i) { return V4{wz[l + i], dz2[l + i], wsl[l + i], dsa[l + i]}; }, [&](int i, const V4 &r) { wz[l + i] = r.a + st * r.b; wsl[l + i] = r.c + st * r.d; });
         if (tid == 0) {
             wi.nitref3 = kref; wi.step = st;
             wi.kap = kap + st * dkap;
