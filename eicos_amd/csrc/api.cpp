@@ -244,7 +244,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.i_cag = L.add((size_t)pcag.slots + 8); D.i_rA = L.add((size_t)prA.slots + 8); D.i_rG = L.add((size_t)prG.slots + 8);
     D.gt_on = GT.on; D.gt_nrb = GT.nrb; D.gt_nt = GT.nt; D.gt_W = GT.W;
     D.i_Gt = GT.on ? (int)L.add((size_t)GT.nt * 256 + 8) : 0;
-    D.i_c = L.add(S.n); D.i_h = L.add(S.m); D.i_b = L.add(S.p);
+    D.i_c = L.add((size_t)S.n + S.p + S.m); D.i_b = D.i_c + S.n; D.i_h = D.i_b + S.p; // [c | b | h]: one array in [x | y | z] order (kkt_solve's epilogue)
     D.i_xe = L.add(S.n); D.i_ae = L.add(S.p); D.i_ge = L.add(S.m);
     D.i_Vv = L.add(S.nV); D.i_cst = L.add(4);
     D.i_x = L.add(S.n); D.i_y = L.add(S.p); D.i_z = L.add(S.m); D.i_s = L.add(S.m);
@@ -268,9 +268,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.inst_stride = L.size;
     SlabLayout Wl;
     D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m); D.w_blam = Wl.add(S.m);
-    D.w_rx = Wl.add(S.n); D.w_ry = Wl.add(S.p); D.w_rz = Wl.add(S.m); D.w_rhs1 = Wl.add((size_t)NV + 16); D.w_rhs2 = Wl.add((size_t)NV + 16); // elimination order
+    D.w_rz = Wl.add(S.m);
     D.w_rhs1k = Wl.add((size_t)S.n + S.p + S.m); D.w_rhs2k = Wl.add((size_t)S.n + S.p + S.m);       // [x | y | z] order
-    D.w_dx1 = Wl.add(S.n); D.w_dy1 = Wl.add(S.p); D.w_dz1 = Wl.add(S.m); D.w_dx2 = Wl.add(S.n); D.w_dy2 = Wl.add(S.p); D.w_dz2 = Wl.add(S.m);
+    D.w_dx1 = Wl.add((size_t)S.n + S.p + S.m); D.w_dy1 = D.w_dx1 + S.n; D.w_dz1 = D.w_dy1 + S.p; // [dx | dy | dz]: one array each
+    D.w_dx2 = Wl.add((size_t)S.n + S.p + S.m); D.w_dy2 = D.w_dx2 + S.n; D.w_dz2 = D.w_dy2 + S.p;
     D.w_dsw = Wl.add(S.m); D.w_wdz = Wl.add(S.m); D.w_dsa = Wl.add(S.m); D.w_t1 = Wl.add(S.m); D.w_t2 = Wl.add(S.m);
     D.w_lpw = Wl.add(S.l); D.w_lpv = Wl.add(S.l); D.w_csc = Wl.add((size_t)S.nc * CSC_STRIDE); D.w_qv = Wl.add(S.m);
     D.w_trace = Wl.add((size_t)TRACE_ROWS * TRACE_COLS);
@@ -436,6 +437,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         put(D.gt_rbptr, GT.rbptr); put(D.gt_col, GT.col); put(D.gt_colk, gt_colk); put(D.gt_zslot, gt_zslot); put(D.gt_cidx, GT.cidx); put(D.gt_src, GT.src);
     }
     put(D.ipx, ipx); put(D.ipy, ipy); put(D.ipz, ipz); put(D.ipv, ipv); put(D.ipu, ipu);
+    std::vector<int> ipk(ipx); ipk.insert(ipk.end(), ipy.begin(), ipy.end()); ipk.insert(ipk.end(), ipz.begin(), ipz.end());
+    put(D.ipk, ipk);
     // quasi-definite sign of pivot `pos` (elimination position): + for the x block and the u expansion of every cone
     // (ref setupKKT :1734-1890), - elsewhere; only used by the dynamic-regularisation extension
     auto pivot_positive = [&](int pos) {

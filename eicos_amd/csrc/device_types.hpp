@@ -99,7 +99,7 @@ struct DevPat {
     gint_p cag_idx_k, cag_idx_yz, cag_src, rA_idx, rA_idx_k, rA_src, rG_idx, rG_idx_k, rG_src;
     // KKT-space vectors live in the (level-ordered) elimination order on the device: position of
     // variable j / equality row r / cone-block row i / the v- and u-expansion slot of cone c
-    gint_p ipx, ipy, ipz, ipv, ipu;
+    gint_p ipx, ipy, ipz, ipv, ipu; gint_p ipk; // [ipx | ipy | ipz] in one array
     // cones
     gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;
@@ -149,7 +149,7 @@ struct DevPat {
     // instance slab offsets
     int i_Av, i_Gv, i_cag, i_rA, i_rG, i_c, i_h, i_b, i_xe, i_ae, i_ge, i_Vv, i_cst, i_x, i_y, i_z, i_s, i_info;
     // workspace slab offsets
-    int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rx, w_ry, w_rz, w_rhs1, w_rhs2, w_rhs1k, w_rhs2k;
+    int w_lam, w_bx, w_by, w_bz, w_bs, w_blam, w_rz, w_rhs1k, w_rhs2k;
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
     int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_UF, w_UB, w_D, w_invD, w_trace;
     int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)

@@ -110,6 +110,7 @@ struct ShI {
     DevInfo wi, bi;
     double sv[SV_COUNT];
     int fl[FL_COUNT];
+    double dots[2][3]; // c'dx, b'dy, h'dz of the last solve with right-hand side 1 / 2 (kkt_solve's epilogue; kkt_post's d tau needs them)
     int kref, kref2, done; // refinement steps of the last KKT solve (kref2: of the second right-hand side of a dual solve); 1 = this instance has finished
     unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
 };
@@ -281,18 +282,50 @@ struct V2 { double a, b; };
 struct V3 { double a, b, c; };
 struct V4 { double a, b, c, d; };
 template <int KI> struct VKI { double v[KI]; };
+template <int KI> struct IVK { int o; double v[KI]; };
 struct IV1 { int i; double a; };
 struct IV2 { int i; double a, b; };
 struct IIV { int i, j; double a; };
 struct IIV3 { int i, j; double a, b, c; };
-template <int T, int U = 4, class L, class F>
+#ifndef EICOS_PRE_MULT
+#define EICOS_PRE_MULT 1
+#endif
+template <int T, int U0 = 4, class L, class F>
 __device__ __forceinline__ void for_t_pre(int cnt, L &&ld, F &&fn) {
+    constexpr int U = U0 * EICOS_PRE_MULT; // elements per thread in flight
     for (int i0 = threadIdx.x; i0 < cnt; i0 += U * T) {
         decltype(ld(0)) r[U];
 #pragma unroll
         for (int u = 0; u < U; u++) { const int i = i0 + u * T; r[u] = ld(i < cnt ? i : i0); } // clamped: unconditional loads
 #pragma unroll
         for (int u = 0; u < U; u++) { const int i = i0 + u * T; if (i < cnt) fn(i, r[u]); }
+    }
+}
+
+// The same over three index ranges (the x, y and z parts of a KKT-space quantity) as ONE software-pipelined loop: a step covers T
+// consecutive elements of one range (the range of a step is workgroup-uniform), U steps are in flight -- the short x and y ranges no
+// longer cost a memory round trip each.  Element i of a range goes to thread i mod T, as in three separate for_t_pre loops (per-thread
+// partial sums are bit-identical).  ld / fn get the range and the index in the CONCATENATED array [range 0 | range 1 | range 2].
+template <int T, int U, class L, class F>
+__device__ __forceinline__ void for_t_pre3(int n0, int n1, int n2, L &&ld, F &&fn) {
+    const int K0 = (n0 + T - 1) / T, K1 = (n1 + T - 1) / T, K2 = (n2 + T - 1) / T, K = K0 + K1 + K2;
+    const int tid = threadIdx.x;
+    // step kk -> range g (workgroup-uniform), index in the concatenated array [range 0 | range 1 | range 2], valid or not; all by
+    // arithmetic on SGPRs (a three-way select of pointers is turned into a table in scratch memory by the compiler)
+    auto locate = [&](int kk, int &g, int &j, bool &ok) {
+        const int a = kk >= K0 ? 1 : 0, b = kk >= K0 + K1 ? 1 : 0;
+        g = a + b;
+        const int i = tid + (kk - a * K0 - b * K1) * T;            // index inside its range
+        const int cnt = n0 + a * (n1 - n0) + b * (n2 - n1);
+        ok = kk < K && i < cnt;
+        j = ok ? i + a * n0 + b * n1 : 0;                           // (clamped: unconditional loads)
+    };
+    for (int kb = 0; kb < K; kb += U) {
+        decltype(ld(0, 0)) r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { int g, j; bool ok; locate(kb + u, g, j, ok); r[u] = ld(g, j); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { int g, j; bool ok; locate(kb + u, g, j, ok); if (ok) fn(g, j, r[u]); }
     }
 }
 
@@ -1325,7 +1358,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
     gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
     gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
-    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
+    gdbl_p lam = W + P.w_lam, rz = W + P.w_rz, rhs2k = W + P.w_rhs2k;
     gdbl_p lpw = W + P.w_lpw, lpv = W + P.w_lpv, csc = W + P.w_csc, qv = W + P.w_qv;
     __syncthreads();
     TICK_BEGIN;
@@ -1345,14 +1378,14 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
                 [&](int j, double s, const Pre2 &pr) { // -G'z - A'y: (y,z) contiguous
         const double hr = -(s + pr.g), c_ = pr.a, xj = pr.b;
         const double r = hr - tau * c_;
-        rx[j] = r;
+        rhs2k[j] = r; // (rx, only ever read as the x part of RHSaffine)
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
     ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx, P.rA_16, P.rA_d16, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r], 0.}; },
                 [&](int r, double s, const Pre2 &pr) {
         const double b_ = pr.a, yr = pr.b;
         const double rr = s - tau * b_;
-        ry[r] = rr;
+        rhs2k[n + r] = -rr; // (-ry: the y part of RHSaffine)
         r8[4] += s * s; r8[5] += rr * rr; r8[6] += b_ * yr; r8[7] += yr * yr;
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
@@ -1361,7 +1394,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
                 [&](int i, double s, const Pre3 &pr) {
         const double si = pr.a, zi = pr.b, h_ = pr.c;
         const double hr = si + (s + pr.g), r = hr - tau * h_;
-        rz[i] = r;
+        rz[i] = r; rhs2k[np + i] = si - r; // (s - rz: the z part of RHSaffine)
         q6[0] += hr * hr; q6[1] += r * r; q6[2] += h_ * zi; q6[3] += zi * zi; q6[4] += si * si; q6[5] += si * zi;
     });
     blk_reduce<OpSum, T, 6>(phase, q6);
@@ -1563,15 +1596,14 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
     gdbl_p Ik[KI_MAX] = {I0, I1};
     const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
     const bool first = (stage == ST_KKT_INIT1 || stage == ST_KKT1);
-    gcdbl_p cagv[KI], rAv[KI], rGv[KI], rhsp[KI], bx[KI], by[KI], bz[KI], lpv[KI], csc[KI], qv[KI];
+    gcdbl_p cagv[KI], rAv[KI], rGv[KI], bx[KI], by[KI], bz[KI], lpv[KI], csc[KI], qv[KI];
     gdbl_p dx[KI], dy[KI], dz[KI];
 #pragma unroll
     for (int k = 0; k < KI; k++) {
         gdbl_p I = Ik[k], W = Wg;
         const bool fk = DUAL ? (k == 0) : first; // dual: right-hand side 0 is rhs1 -> (dx1, dy1, dz1), 1 is rhs2 -> (dx2, dy2, dz2)
         cagv[k] = I + P.i_cag; rAv[k] = I + P.i_rA; rGv[k] = I + P.i_rG;
-        rhsp[k] = W + (fk ? P.w_rhs1 : P.w_rhs2);                      // elimination order (what the triangular sweeps consume)
-        gcdbl_p rhsk = W + (fk ? P.w_rhs1k : P.w_rhs2k);               // same values as [x | y | z] (what the residual reads)
+        gcdbl_p rhsk = W + (fk ? P.w_rhs1k : P.w_rhs2k);               // the right-hand side as [x | y | z]
         bx[k] = rhsk; by[k] = rhsk + n; bz[k] = rhsk + np;
         lpv[k] = W + P.w_lpv; csc[k] = W + P.w_csc; qv[k] = W + P.w_qv;
         dx[k] = W + (fk ? P.w_dx1 : P.w_dx2); dy[k] = W + (fk ? P.w_dy1 : P.w_dy2); dz[k] = W + (fk ? P.w_dz1 : P.w_dz2);
@@ -1612,16 +1644,28 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         double nr[KI];
 #pragma unroll
         for (int k = 0; k < KI; k++) nr[k] = 0.;
-        for_t_pre<T, 6>(P.Npad, [&](int i) {
-            VKI<KI> r;
+        // the sweep vector: the right-hand side [x | y | z] scattered to its elimination positions (one pass: P.ipk = [ipx | ipy | ipz]), zero
+        // in the expansion rows of the cones and in the padding (tile layouts pad inside the blocks: zero everything first)
+        {
+            double z[KI];
 #pragma unroll
-            for (int k = 0; k < KI; k++) r.v[k] = rhsp[k][i < N ? i : max(N - 1, 0)]; // N = 0 (empty problem): slot 0 of the N+16 allocation
+            for (int k = 0; k < KI; k++) z[k] = 0.;
+            if (P.tile != 0) { FOR_T(i, P.Npad) stK<KI>(SV, i, z); __syncthreads(); }
+            else {
+                FOR_T(c, P.nc) { stK<KI>(SV, P.ipv[c], z); stK<KI>(SV, P.ipu[c], z); }
+                FOR_T(i, P.Npad - N) stK<KI>(SV, N + i, z);
+            }
+        }
+        for_t_pre<T, 6>(np + m, [&](int j) {
+            IVK<KI> r;
+            r.o = ld_u32(P.ipk, j);
+#pragma unroll
+            for (int k = 0; k < KI; k++) r.v[k] = ld_u32(bx[k], j); // (bx = the whole [x | y | z] vector)
             return r;
-        }, [&](int i, const VKI<KI> &r) {
-            double v[KI];
+        }, [&](int, const IVK<KI> &r) {
 #pragma unroll
-            for (int k = 0; k < KI; k++) { v[k] = (i < N) ? r.v[k] : 0.; nr[k] = fmax(nr[k], fabs(v[k])); } // load the rhs; slots >= N stay 0
-            stK<KI>(SV, i, v);
+            for (int k = 0; k < KI; k++) nr[k] = fmax(nr[k], fabs(r.v[k]));
+            stK<KI>(SV, r.o, r.v);
         });
         blk_reduce<OpMax, T, KI>(phase, nr);
 #pragma unroll
@@ -1795,13 +1839,32 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         }
     }
     __syncthreads();
+    double d3k[3 * KI]; // ... with c'dx, b'dy, h'dz on the way (every pass of the main loop needs them: ref :1185-1190, :1216-1219)
 #pragma unroll
     for (int k = 0; k < KI; k++) {
-        if (!((amask >> k) & 1)) continue;
-        for_t_pre<T, 4>(n, [&](int j) { return V1{X[P.ipx[j] * KI + k]}; }, [&](int j, const V1 &r) { dx[k][j] = r.a; });
-        for_t_pre<T, 4>(p, [&](int j) { return V1{X[P.ipy[j] * KI + k]}; }, [&](int j, const V1 &r) { dy[k][j] = r.a; });
-        for_t_pre<T, 8>(m, [&](int i) { return V1{X[P.ipz[i] * KI + k]}; }, [&](int i, const V1 &r) { dz[k][i] = r.a; });
+        double d3[3] = {0., 0., 0.};
+        if ((amask >> k) & 1) {
+        gcdbl_p cv = Ik[k] + P.i_c;
+        for_t_pre3<T, 8>(n, p, m, [&](int, int j) { // (j: index in [x | y | z]; c, b, h and dx, dy, dz are laid out in that order)
+            return V2{X[ld_u32(P.ipk, j) * KI + k], init ? 0. : ld_u32(cv, j)};
+        }, [&](int rg, int j, const V2 &r) {
+            dx[k][j] = r.a;
+            const double t = r.b * r.a;
+            d3[0] += rg == 0 ? t : 0.; d3[1] += rg == 1 ? t : 0.; d3[2] += rg == 2 ? t : 0.; // (x + 0 = x: the partial sums are those of three separate loops)
+        });
         if (tid == 0) { if (DUAL && k == 1) g_S.kref2 = kcnt[k]; else state(k).kref = kcnt[k]; }
+        }
+        d3k[3 * k] = d3[0]; d3k[3 * k + 1] = d3[1]; d3k[3 * k + 2] = d3[2];
+    }
+    if (!init) { // (outside the loop over the right-hand sides: a barrier inside keeps the compiler from unrolling it)
+        blk_reduce<OpSum, T, 3 * KI>(phase, d3k);
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < KI; k++) if ((amask >> k) & 1) {
+                const int which = (DUAL ? k == 0 : first) ? 0 : 1;
+                g_S.dots[which][0] = d3k[3 * k]; g_S.dots[which][1] = d3k[3 * k + 1]; g_S.dots[which][2] = d3k[3 * k + 2];
+            }
+        }
     }
     __syncthreads();
     tick(TK_KRES);
@@ -1815,12 +1878,10 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     const int n = P.n, p = P.p, m = P.m, l = P.l, np = P.n + P.p;
     const int tid = threadIdx.x;
     DevInfo &wi = g_S.wi;
-    int phase = 0;
-    gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b;
+    gdbl_p cv = I + P.i_c;
     gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
-    gdbl_p lam = W + P.w_lam, rx = W + P.w_rx, ry = W + P.w_ry, rz = W + P.w_rz;
-    gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2;     // elimination order (what the triangular sweeps consume)
-    gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k; // same values as [x | y | z] (what the residual reads)
+    gdbl_p lam = W + P.w_lam, rz = W + P.w_rz;
+    gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k; // the right-hand sides as [x | y | z] (kkt_solve scatters them into the sweep vector)
     gdbl_p dx1 = W + P.w_dx1, dy1 = W + P.w_dy1, dz1 = W + P.w_dz1, dx2 = W + P.w_dx2, dy2 = W + P.w_dy2, dz2 = W + P.w_dz2;
     gdbl_p dsw = W + P.w_dsw, wdz = W + P.w_wdz, dsa = W + P.w_dsa, t1 = W + P.w_t1, t2 = W + P.w_t2;
     gdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
@@ -1835,7 +1896,7 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     } else if (stage == ST_KKT_INIT2) { // ref :966-992
         for_t_pre<T, 4>(p, [&](int j) { return V1{dy2[j]}; }, [&](int j, const V1 &r) { wy[j] = r.a; });
         dev_bring_to_cone<T>(ps, dz2, 1., wz);
-        for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], cv[j]}; }, [&](int j, const IV1 &r) { const double v = -r.a; rhs1[r.i] = v; rhs1k[j] = v; });
+        for_t_pre<T, 4>(n, [&](int j) { return V1{cv[j]}; }, [&](int j, const V1 &r) { rhs1k[j] = -r.a; });
         if (tid == 0) {
             wi.nitref2 = kref;
             wi.kap = 1.; wi.tau = 1.; wi.step = 0.; wi.step_aff = 0.; wi.pinf = 0; wi.dinf = 0;
@@ -1843,19 +1904,11 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         }
         __syncthreads();
         stage = ST_RESID;
-    } else if (stage == ST_KKT1) { // RHSaffine (ref :1670-1689)
-        for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], rx[j]}; }, [&](int j, const IV1 &r) { rhs2[r.i] = r.a; rhs2k[j] = r.a; });
-        for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], ry[j]}; }, [&](int j, const IV1 &r) { rhs2[r.i] = -r.a; rhs2k[n + j] = -r.a; });
-        for_t_pre<T, 8>(m, [&](int i) { return IV2{P.ipz[i], wsl[i], rz[i]}; },
-                        [&](int i, const IV2 &r) { const double v = r.a - r.b; rhs2[r.i] = v; rhs2k[np + i] = v; }); // expansion slots stay 0
-        __syncthreads();
+    } else if (stage == ST_KKT1) { // RHSaffine (ref :1670-1689) = [rx; -ry; s - rz]: written by stage_resid's epilogues
         stage = ST_KKT_AFF;
     } else if (stage == ST_KKT_AFF) { // ref :1181-1210
-        double d6[6] = {0, 0, 0, 0, 0, 0}; // c.dx1 b.dy1 h.dz1 c.dx2 b.dy2 h.dz2
-        for_t_pre<T, 4>(n, [&](int j) { return V3{cv[j], dx1[j], dx2[j]}; }, [&](int j, const V3 &r) { d6[0] += r.a * r.b; d6[3] += r.a * r.c; });
-        for_t_pre<T, 4>(p, [&](int j) { return V3{bv[j], dy1[j], dy2[j]}; }, [&](int j, const V3 &r) { d6[1] += r.a * r.b; d6[4] += r.a * r.c; });
-        for_t_pre<T, 4>(m, [&](int i) { return V3{hv[i], dz1[i], dz2[i]}; }, [&](int i, const V3 &r) { d6[2] += r.a * r.b; d6[5] += r.a * r.c; });
-        blk_reduce<OpSum, T, 6>(phase, d6);
+        // c.dx1 b.dy1 h.dz1 c.dx2 b.dy2 h.dz2: formed by the epilogues of the two solves
+        const double d6[6] = {g_S.dots[0][0], g_S.dots[0][1], g_S.dots[0][2], g_S.dots[1][0], g_S.dots[1][1], g_S.dots[1][2]};
         const double kap = wi.kap, tau = wi.tau;
         const double dtau_denom = kap / tau - d6[0] - d6[1] - d6[2];
         const double dtauaff = (g_S.sv[SV_RT] - kap + d6[3] + d6[4] + d6[5]) / dtau_denom;
@@ -1883,14 +1936,14 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         if (tid == 0) { wi.step_aff = step_aff; wi.sigma = sigma; }
         // ---- RHScombined (ref :1282-1325) ----
         const double sigmamu = sigma * mu, oms = 1. - sigma;
-        struct RC { int o; double lam, ds, wz, w, rz; };
-        for_t_pre<T, 4>(l, [&](int i) { return RC{P.ipz[i], lam[i], dsw[i], wdz[i], lpw[i], rz[i]}; }, [&](int i, const RC &r) {
+        struct RC { double lam, ds, wz, w, rz; };
+        for_t_pre<T, 4>(l, [&](int i) { return RC{lam[i], dsw[i], wdz[i], lpw[i], rz[i]}; }, [&](int i, const RC &r) {
             // LP part: ds1 = lam*lam + dsw*wdz - sigmamu ; dsw = ds1/lam ; t1 = w*dsw (in registers) ; rhs2 row = -(1 - sigma) rz + t1
             const double d1_ = r.lam * r.lam + r.ds * r.wz - sigmamu;
             const double q_ = d1_ / r.lam;
             dsw[i] = q_;
             const double v = -oms * r.rz + r.w * q_;
-            rhs2k[np + i] = v; rhs2[r.o] = v;
+            rhs2k[np + i] = v;
         });
         if (P.nc > 0) {
             for_cones<T>(ps, [&](int c, auto G, int ln) {
@@ -1930,17 +1983,12 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
             });
         }
         __syncthreads();
-        for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], rhs2k[j]}; }, [&](int j, const IV1 &r) { const double v = r.a * oms; rhs2k[j] = v; rhs2[r.i] = v; });
-        for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], rhs2k[n + j]}; }, [&](int j, const IV1 &r) { const double v = r.a * oms; rhs2k[n + j] = v; rhs2[r.i] = v; });
-        for_t_pre<T, 8>(m - l, [&](int i) { return IV2{P.ipz[l + i], rz[l + i], t1[l + i]}; }, [&](int i, const IV2 &r) { const double v = -oms * r.a + r.b; rhs2k[np + l + i] = v; rhs2[r.i] = v; });
+        for_t_pre<T, 8>(np, [&](int j) { return V1{rhs2k[j]}; }, [&](int j, const V1 &r) { rhs2k[j] = r.a * oms; });
+        for_t_pre<T, 8>(m - l, [&](int i) { return V2{rz[l + i], t1[l + i]}; }, [&](int i, const V2 &r) { rhs2k[np + l + i] = -oms * r.a + r.b; });
         __syncthreads();
         stage = ST_KKT_COMB;
     } else { // ST_KKT_COMB, ref :1212-1252
-        double e3[3] = {0, 0, 0};
-        for_t_pre<T, 4>(n, [&](int j) { return V2{cv[j], dx2[j]}; }, [&](int j, const V2 &r) { e3[0] += r.a * r.b; });
-        for_t_pre<T, 4>(p, [&](int j) { return V2{bv[j], dy2[j]}; }, [&](int j, const V2 &r) { e3[1] += r.a * r.b; });
-        for_t_pre<T, 8>(m, [&](int i) { return V2{hv[i], dz2[i]}; }, [&](int i, const V2 &r) { e3[2] += r.a * r.b; });
-        blk_reduce<OpSum, T, 3>(phase, e3);
+        const double e3[3] = {g_S.dots[1][0], g_S.dots[1][1], g_S.dots[1][2]}; // c.dx2 b.dy2 h.dz2 (epilogue of the combined solve)
         const double kap = wi.kap, tau = wi.tau, sigma = wi.sigma;
         const double dtauaff = g_S.sv[SV_DTAUAFF], dkapaff = g_S.sv[SV_DKAPAFF];
         const double bkap = kap * tau + dkapaff * dtauaff - sigma * wi.mu;
@@ -1986,13 +2034,13 @@ template <int T>
 __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double warm) {
     ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W);
     const DevPat &P = c_pat[ps];
-    const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
+    const int n = P.n, p = P.p, m = P.m, l = P.l, np = P.n + P.p;
     const int tid = threadIdx.x;
     DevInfo *ginfo = (DevInfo *)(I + P.i_info); // (C-style cast: in the LDS-resident build the slab pointer is an LDS pointer)
     DevInfo &wi = g_S.wi;
     {
         gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
-        gdbl_p rhs1 = W + P.w_rhs1, rhs2 = W + P.w_rhs2, rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k;
+        gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k;
         int phase = 0;
         __syncthreads();
         if (tid == 0) { // sticky across solve() calls like the reference's w.i
@@ -2014,7 +2062,6 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double wa
             if (ln == 0) { v[d] = -1.; v[2 * d] = 1.; }
         });
         // rhs1 = [0; b; h expanded], rhs2 = [-c; 0; 0]   (ref :865-886)
-        FOR_T(i, N) { rhs1[i] = 0.; rhs2[i] = 0.; }
         FOR_T(i, np + m) { rhs1k[i] = 0.; rhs2k[i] = 0.; }
         __syncthreads();
         { // KKT entries in the factor's target order (one gather per solve; the scaling part is refreshed per iteration)
@@ -2032,9 +2079,9 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double wa
         }
         {
             double nr3[3] = {0., 0., 0.};
-            for_t_pre<T, 4>(n, [&](int j) { return IV1{P.ipx[j], cv[j]}; }, [&](int j, const IV1 &r) { rhs2[r.i] = -r.a; rhs2k[j] = -r.a; nr3[0] += r.a * r.a; });
-            for_t_pre<T, 4>(p, [&](int j) { return IV1{P.ipy[j], bv[j]}; }, [&](int j, const IV1 &r) { rhs1[r.i] = r.a; rhs1k[n + j] = r.a; nr3[1] += r.a * r.a; });
-            for_t_pre<T, 8>(m, [&](int i) { return IV1{P.ipz[i], hv[i]}; }, [&](int i, const IV1 &r) { rhs1[r.i] = r.a; rhs1k[np + i] = r.a; nr3[2] += r.a * r.a; });
+            for_t_pre<T, 4>(n, [&](int j) { return V1{cv[j]}; }, [&](int j, const V1 &r) { rhs2k[j] = -r.a; nr3[0] += r.a * r.a; });
+            for_t_pre<T, 4>(p, [&](int j) { return V1{bv[j]}; }, [&](int j, const V1 &r) { rhs1k[n + j] = r.a; nr3[1] += r.a * r.a; });
+            for_t_pre<T, 8>(m, [&](int i) { return V1{hv[i]}; }, [&](int i, const V1 &r) { rhs1k[np + i] = r.a; nr3[2] += r.a * r.a; });
             blk_reduce<OpSum, T, 3>(phase, nr3);
             if (tid == 0) {
                 g_S.sv[SV_RESX0] = fmax(1., sqrt(nr3[0])); g_S.sv[SV_RESY0] = fmax(1., sqrt(nr3[1])); g_S.sv[SV_RESZ0] = fmax(1., sqrt(nr3[2]));
@@ -2049,7 +2096,7 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double wa
         // instead of the two initialisation solves (ref :929-972); tau = kap = 1, first pass = iteration 0.
         gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s, cv = I + P.i_c;
         gcdbl_p xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
-        gdbl_p rhs1 = W + P.w_rhs1, rhs1k = W + P.w_rhs1k;
+        gdbl_p rhs1k = W + P.w_rhs1k;
         int phase = 0;
         FOR_T(j, n) wx[j] *= xe[j];
         FOR_T(r, p) wy[r] *= ae[r];
@@ -2067,7 +2114,7 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double wa
             ts = grp_sum<g>(ts); tz = grp_sum<g>(tz);
             if (ln == 0) { wsl[o] = fmax(wsl[o], sqrt(ts) + as); wz[o] = fmax(wz[o], sqrt(tz) + az); }
         });
-        FOR_T(j, n) { const double v = -cv[j]; rhs1[P.ipx[j]] = v; rhs1k[j] = v; } // as after the second init solve (ref :966-972)
+        FOR_T(j, n) rhs1k[j] = -cv[j]; // as after the second init solve (ref :966-972)
         if (tid == 0) {
             wi.nitref1 = 0; wi.nitref2 = 0;
             wi.kap = 1.; wi.tau = 1.; wi.step = 0.; wi.step_aff = 0.; wi.pinf = 0; wi.dinf = 0;
