@@ -63,6 +63,10 @@ static_assert(ELL_KMAX == 4, "the packed index entries hold four 16-bit indices 
 #ifndef EICOS_FAC_DEPTH
 #define EICOS_FAC_DEPTH 2
 #endif
+#ifndef EICOS_TRI_DEPTH_SOLO
+#define EICOS_TRI_DEPTH_SOLO 3
+#endif
+constexpr int TRI_DEPTH_SOLO = EICOS_TRI_DEPTH_SOLO; // queue depth (= slices per trip) of the single-wavefront part of the sweeps
 constexpr int TRI_DEPTH = EICOS_TRI_DEPTH; // ... this many slices ahead of their use (plans are padded to a multiple)
 #ifndef EICOS_TRI_TRIP
 #define EICOS_TRI_TRIP 6

@@ -521,10 +521,12 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     // gather / store of the pair is one 16-byte LDS access
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
+    // the narrow tree top (SOLO, one wavefront) runs short steps: the same lead time needs a deeper queue than the workgroup-wide levels
+    constexpr int DEPTH = SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH, TRIP = SOLO ? TRI_DEPTH_SOLO : TRI_TRIP;
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
         int row0, lg, K, off, lanes, newlev, more, cont;
         int idx[ELL_KMAX]; double val[ELL_KMAX][KI]; double d[KI], own[KI];
-    } q[TRI_DEPTH];
+    } q[DEPTH];
     // every slice issues the same number of global loads per lane (inactive lanes / padding read the plan's dummy
     // slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
     auto load = [&](int s, Slot &o) {
@@ -559,13 +561,13 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
 #pragma unroll
-    for (int d = 0; d < TRI_DEPTH; d++) load(d < ns ? d : 0, q[d]);
+    for (int d = 0; d < DEPTH; d++) load(d < ns ? d : 0, q[d]);
     // one slice step; `d` = the slice's slot of the register queue.  A trip of TRI_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
     // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of TRI_DEPTH, so
     // plans are padded to a multiple of TRI_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
     auto step = [&](const int d, const int s) __attribute__((always_inline)) {
         const Slot c = q[d];
-        load(min(s + TRI_DEPTH, ns - 1), q[d]);
+        load(min(s + DEPTH, ns - 1), q[d]);
         if (c.newlev) {
             if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
             else if (LDSBAR) lds_barrier();
@@ -600,13 +602,18 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     
     };
     int s0 = 0;
-    for (; s0 + TRI_TRIP <= ns; s0 += TRI_TRIP) {
+    for (; s0 + TRIP <= ns; s0 += TRIP) {
 #pragma unroll
-        for (int u = 0; u < TRI_TRIP; u++) step(u % TRI_DEPTH, s0 + u);
+        for (int u = 0; u < TRIP; u++) step(u % DEPTH, s0 + u);
     }
-    for (; s0 < ns; s0 += TRI_DEPTH) {
+    if constexpr (SOLO) { // remainder: guarded steps (no padding slices: an empty slice is a full step of the chain)
 #pragma unroll
-        for (int u = 0; u < TRI_DEPTH; u++) step(u, s0 + u);
+        for (int u = 0; u < DEPTH; u++) if (s0 + u < ns) step(u, s0 + u);
+    } else {
+        for (; s0 < ns; s0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; u++) step(u, s0 + u);
+        }
     }
     if (!SOLO) __syncthreads();
 }
@@ -1690,8 +1697,14 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
                     if (wave0) tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
+#ifdef EICOS_SOLO_TICKS
+                tick(TK_LDL);
+#endif
                 tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                 tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+#ifdef EICOS_SOLO_TICKS
+                tick(TK_FWD); // (dev builds: the narrow tree top of both sweeps, wavefront 0 alone, shows up as "fwd" in the phase timers)
+#endif
             }
             __syncthreads();
             tri_sweep<T, false, true, false, I16, KI, DUAL>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);

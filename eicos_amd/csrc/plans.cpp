@@ -87,11 +87,11 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
         for (int v = v_first; v < vs; v++) emit_level(v, T);
         pad(); pl.n_wide = (int)pl.sl.size();
         for (int v = std::max(vs, v_first); v < nlev; v++) emit_level(v, 64);
-        pad(); pl.n_solo = (int)pl.sl.size() - pl.n_wide;
+        pl.n_solo = (int)pl.sl.size() - pl.n_wide; // (no padding: the single-wavefront loop guards its remainder)
         if (hyb) { emit_level(nlev, T); pad(); pl.n_ext = (int)pl.sl.size() - pl.n_wide - pl.n_solo; }
     } else {
         for (int v = nlev - 1; v >= std::max(vs, v_first); v--) emit_level(v, 64);
-        pad(); pl.n_solo = (int)pl.sl.size();
+        pl.n_solo = (int)pl.sl.size();
         for (int v = vs - 1; v >= v_first; v--) emit_level(v, T);
         pad(); pl.n_wide = (int)pl.sl.size() - pl.n_solo;
     }
