@@ -616,6 +616,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     }
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min(batch, resident);
+    h->grid = std::max(1, std::min(h->grid, env_int("EICOS_GRID", h->grid, 1, 1 << 20))); // experiments: fewer workgroups than the resident maximum
     h->order_min = prop.multiProcessorCount;
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
     {   // entry-parallel updateData: needs the A / G values and the row / column maxima in LDS and <= 8 vector entries per thread
