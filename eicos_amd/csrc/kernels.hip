@@ -522,7 +522,8 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
     // the narrow tree top (SOLO, one wavefront) runs short steps: the same lead time needs a deeper queue than the workgroup-wide levels
-    constexpr int DEPTH = SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH, TRIP = SOLO ? TRI_DEPTH_SOLO : TRI_TRIP;
+    constexpr int DEPTH = SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH;
+    constexpr int TRIP = SOLO ? ((TRI_TRIP + TRI_DEPTH_SOLO - 1) / TRI_DEPTH_SOLO) * TRI_DEPTH_SOLO : TRI_TRIP; // (a multiple of the queue depth)
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
         int row0, lg, K, off, lanes, newlev, more, cont;
         int idx[ELL_KMAX]; double val[ELL_KMAX][KI]; double d[KI], own[KI];
@@ -606,14 +607,9 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 #pragma unroll
         for (int u = 0; u < TRIP; u++) step(u % DEPTH, s0 + u);
     }
-    if constexpr (SOLO) { // remainder: guarded steps (no padding slices: an empty slice is a full step of the chain)
+    for (; s0 < ns; s0 += DEPTH) { // remainder in trips of the queue depth (the host pads every section of a plan to a multiple of it)
 #pragma unroll
-        for (int u = 0; u < DEPTH; u++) if (s0 + u < ns) step(u, s0 + u);
-    } else {
-        for (; s0 < ns; s0 += DEPTH) {
-#pragma unroll
-            for (int u = 0; u < DEPTH; u++) step(u, s0 + u);
-        }
+        for (int u = 0; u < DEPTH; u++) step(u, s0 + u);
     }
     if (!SOLO) __syncthreads();
 }
@@ -805,7 +801,7 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
 
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
 // Wg = the workgroup's workspace slab.  Left-looking sliced-ELL program over the level schedule (host: plans.cpp, api.cpp).
-template <int T, int NLDS, bool I16>
+template <int T, int NLDS, bool I16, bool DEFER>
 __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     ps = uni(ps); Wg = uni_ptr(Wg);
     const DevPat &P = c_pat[ps];
@@ -827,7 +823,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
     // Deferred L (DevPat::fac_defer; needs the LDS solve vector, idle during the factorisation, as a mirror of 1/D): a pair is
     // U[i,k] * (U[j,k] * (1/D[k])) with 1/D[k] gathered from LDS -- the product in brackets is exactly the stored L[j,k] -- so the
     // forward-order copy of L is not needed before the sweeps: no phase B, ONE barrier per level, L written in one pass at the end
-    const bool defer = P.fac_defer != 0;
+    // (DEFER = DevPat::fac_defer, a template parameter: the stored-L form must not pay for the pivot-column indices and the third operand)
+    constexpr bool defer = DEFER;
     // 1/D[k] of a pair's pivot column: from the LDS mirror ([0, N] at the start of the dynamic LDS, slot fac_kpad = 0 for padding
     // pairs), or -- kernels without an LDS vector: only the debug entry, api.cpp sets fac_defer with NLDS >= 1 -- from the array itself
     auto inv_of = [&](int k) -> double { if constexpr (NLDS >= 1) return g_dyn[k]; else return invD[k]; };
@@ -845,7 +842,8 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
         const bool act = tid < o.lanes;
         if constexpr (I16) { // the lane's four (pa, pb) pairs packed as eight 16-bit slot numbers: one 16-byte load (+ 8 bytes: the pivot columns)
             const uint4 w = ld_u32(reinterpret_cast<const uint4 EICOS_GLOBAL *>(P.fac_p16), act ? nm.off16 + tid : P.fac_d16);
-            const uint2 wk = ld_u32(reinterpret_cast<const uint2 EICOS_GLOBAL *>(P.fac_k16), act ? nm.off16 + tid : P.fac_d16);
+            uint2 wk = {0u, 0u};
+            if constexpr (defer) wk = ld_u32(reinterpret_cast<const uint2 EICOS_GLOBAL *>(P.fac_k16), act ? nm.off16 + tid : P.fac_d16);
             o.ia[0] = w.x & 0xffffu; o.ia[1] = w.x >> 16; o.ia[2] = w.y & 0xffffu; o.ia[3] = w.y >> 16;
             o.ib[0] = w.z & 0xffffu; o.ib[1] = w.z >> 16; o.ib[2] = w.w & 0xffffu; o.ib[3] = w.w >> 16;
             o.ik[0] = wk.x & 0xffffu; o.ik[1] = wk.x >> 16; o.ik[2] = wk.y & 0xffffu; o.ik[3] = wk.y >> 16;
@@ -853,7 +851,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
 #pragma unroll
             for (int u = 0; u < ELL_KMAX; u++) {
                 const int slot = (act && u < o.K) ? o.off + u * o.lanes + tid : P.fac_slots; // dummy pair: 0 * 0
-                o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot]; o.ik[u] = P.fac_pk[slot];
+                o.ia[u] = P.fac_pa[slot]; o.ib[u] = P.fac_pb[slot]; o.ik[u] = defer ? P.fac_pk[slot] : 0;
             }
         }
         const int t = act ? o.row0 + (tid >> o.lg) : 0;
@@ -944,7 +942,7 @@ __device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
             }
             double acc = 0.;
 #pragma unroll
-            for (int u = 0; u < ELL_KMAX; u++) acc = madd(acc, cu[u], cl[u] * ck[u]); // (deferred: cl * ck IS the stored L[j,k]; else ck = 1)
+            for (int u = 0; u < ELL_KMAX; u++) acc = madd(acc, cu[u], defer ? cl[u] * ck[u] : cl[u]); // (deferred: cl * ck IS the stored L[j,k])
             acc = grp_reduce_to_lane0(acc, c.lg);
             if (c.cont) acc += carry;
             if (c.more) carry = acc;
@@ -2163,7 +2161,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
     __syncthreads();
     while (stage != ST_DONE) {
         if (stage == ST_FACTOR) {
-            if (P.tile != 1) stage_factor<T, NLDS, I16>(ps, W); // scalar program (hybrid: everything below the top block + its image)
+            if (P.tile != 1) { if (P.fac_defer) stage_factor<T, NLDS, I16, true>(ps, W); else stage_factor<T, NLDS, I16, false>(ps, W); } // scalar program (hybrid: everything below the top block + its image)
             if (P.tile) stage_factor_tiles<T, NLDS>(ps, I, W, iter);
             if (g_S.fl[FL_FATAL]) { instance_end(P, I, W); stage = ST_DONE; } // zero pivot -> fatal, no backscale (ref :901-905,1166-1170)
             else stage = (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
@@ -2497,7 +2495,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_factor(int ps, d
     if (P.tile != 1) {
         for (int t = threadIdx.x; t < P.fac_nt; t += T) Kt[t] = I[P.fac_src[t]];
         __syncthreads();
-        stage_factor<T, 0, false>(ps, (gdbl_p)work);
+        if (c_pat[ps].fac_defer) stage_factor<T, 0, false, true>(ps, (gdbl_p)work); else stage_factor<T, 0, false, false>(ps, (gdbl_p)work);
     }
     if (P.tile) stage_factor_tiles<T, 0>(ps, I, (gdbl_p)work, -1);
 }

@@ -79,6 +79,7 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     auto pad = [&]() { // empty slices: no loop tail in the kernel's software pipeline (trips of TRI_TRIP slices, remainder in trips of TRI_DEPTH)
         while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0});
     };
+    auto pad_solo = [&]() { while (pl.sl.size() % TRI_DEPTH_SOLO) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); };
     // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
     const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
     int vs = nlev;
@@ -87,11 +88,11 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
         for (int v = v_first; v < vs; v++) emit_level(v, T);
         pad(); pl.n_wide = (int)pl.sl.size();
         for (int v = std::max(vs, v_first); v < nlev; v++) emit_level(v, 64);
-        pl.n_solo = (int)pl.sl.size() - pl.n_wide; // (no padding: the single-wavefront loop guards its remainder)
+        pad_solo(); pl.n_solo = (int)pl.sl.size() - pl.n_wide;
         if (hyb) { emit_level(nlev, T); pad(); pl.n_ext = (int)pl.sl.size() - pl.n_wide - pl.n_solo; }
     } else {
         for (int v = nlev - 1; v >= std::max(vs, v_first); v--) emit_level(v, 64);
-        pl.n_solo = (int)pl.sl.size();
+        pad_solo(); pl.n_solo = (int)pl.sl.size();
         for (int v = vs - 1; v >= v_first; v--) emit_level(v, T);
         pad(); pl.n_wide = (int)pl.sl.size() - pl.n_solo;
     }
