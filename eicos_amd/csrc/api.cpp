@@ -439,6 +439,15 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     put(D.ipx, ipx); put(D.ipy, ipy); put(D.ipz, ipz); put(D.ipv, ipv); put(D.ipu, ipu);
     std::vector<int> ipk(ipx); ipk.insert(ipk.end(), ipy.begin(), ipy.end()); ipk.insert(ipk.end(), ipz.begin(), ipz.end());
     put(D.ipk, ipk);
+    const int Npad_v = tile ? NV + 16 : (NV + 1 + 15) & ~15; // (= D.Npad below)
+    std::vector<int> zpos; // sweep-vector slots no x / y / z entry lands in: cone expansions, padding (inside the blocks in tile layouts)
+    {
+        std::vector<char> hit((size_t)Npad_v, 0);
+        for (int o : ipk) hit[o] = 1;
+        for (int i = 0; i < Npad_v; i++) if (!hit[i]) zpos.push_back(i);
+    }
+    D.nzpos = (int)zpos.size();
+    put(D.zpos, zpos);
     // quasi-definite sign of pivot `pos` (elimination position): + for the x block and the u expansion of every cone
     // (ref setupKKT :1734-1890), - elsewhere; only used by the dynamic-regularisation extension
     auto pivot_positive = [&](int pos) {
@@ -509,7 +518,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // launch shape: env overrides are for experiments (bench sweeps); defaults chosen from measurements
     // KKT-space vectors (solve vector, current solution, refinement residual) live in LDS when they fit:
     // 160 KiB per CU minus the static block (reductions + scalar state)
-    D.Npad = tile ? NV + 16 : (NV + 1 + 15) & ~15; // >= N+1: slot N is the always-zero target of ELL padding (tile mode: a whole zero block)
+    D.Npad = Npad_v; // tile ? NV + 16 : (NV + 1 + 15) & ~15 // >= N+1: slot N is the always-zero target of ELL padding (tile mode: a whole zero block)
     {
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo + D.nfs_ext; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
         D.lm_total = D.lm_rG + D.rG_ns;

@@ -104,6 +104,7 @@ struct DevPat {
     // KKT-space vectors live in the (level-ordered) elimination order on the device: position of
     // variable j / equality row r / cone-block row i / the v- and u-expansion slot of cone c
     gint_p ipx, ipy, ipz, ipv, ipu; gint_p ipk; // [ipx | ipy | ipz] in one array
+    gint_p zpos; int nzpos; // the slots of the sweep vector [0, Npad) that are not an x / y / z position (cone expansions, padding): kept zero
     // cones
     gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;

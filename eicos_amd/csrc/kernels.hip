@@ -1650,16 +1650,12 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
 #pragma unroll
         for (int k = 0; k < KI; k++) nr[k] = 0.;
         // the sweep vector: the right-hand side [x | y | z] scattered to its elimination positions (one pass: P.ipk = [ipx | ipy | ipz]), zero
-        // in the expansion rows of the cones and in the padding (tile layouts pad inside the blocks: zero everything first)
+        // in the expansion rows of the cones and in the padding (tile layouts pad inside the blocks)
         {
             double z[KI];
 #pragma unroll
             for (int k = 0; k < KI; k++) z[k] = 0.;
-            if (P.tile != 0) { FOR_T(i, P.Npad) stK<KI>(SV, i, z); __syncthreads(); }
-            else {
-                FOR_T(c, P.nc) { stK<KI>(SV, P.ipv[c], z); stK<KI>(SV, P.ipu[c], z); }
-                FOR_T(i, P.Npad - N) stK<KI>(SV, N + i, z);
-            }
+            FOR_T(q_, P.nzpos) stK<KI>(SV, P.zpos[q_], z); // (host list: every slot of [0, Npad) that no entry of ipk names)
         }
         for_t_pre<T, 6>(np + m, [&](int j) {
             IVK<KI> r;
