@@ -47,6 +47,7 @@ struct eicos_batch {
     int pslot = -1; // slot of this handle's DevPat in the kernels' constant-memory table
     size_t dyn_lds = 0;
     int nlds = 0;
+    int w2 = 0;               // 1: solves run the two-waves-per-SIMD build of the 256-thread kernel (w2::launch_solve)
     int ldsres = 0;           // 1: solves run the LDS-resident kernel (ldsres::launch_solve), slabs copied in and out per instance
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
@@ -608,6 +609,16 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         bpc = forced > 0 ? std::min(forced, bpc) : best_r;
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
+    // 256 threads at <= 2 workgroups per CU: the build with 256 VGPRs per thread (the default one is held to 168 so that three fit)
+    h->w2 = 0;
+    if (!h->ldsres && h->threads == 256 && bpc <= 2 && env_int("EICOS_W2", 1, 0, 1)) {
+        int got = 0;
+        HIP_TRY_H(w2::solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
+        HIP_TRY_H(w2::solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &got));
+        if (got >= bpc) h->w2 = 1;
+    }
+    auto v_set_max_lds = h->w2 ? w2::solve_set_max_lds : solve_set_max_lds;
+    auto v_occupancy = h->w2 ? w2::solve_occupancy : solve_occupancy;
     // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
     // scattered stores and the read-back stay on chip.  Verified against the runtime's occupancy for the enlarged allocation.
     D.e_lds = 0; D.e_off = 0;
@@ -616,8 +627,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         size_t xs = room > base + 4096 + 1024 ? std::min<size_t>((size_t)NV, (room - base - 4096 - 1024) / sizeof(double)) & ~(size_t)15 : 0;
         while (xs > 0) {
             int got = 0;
-            HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, base + xs * sizeof(double)));
-            HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, base + xs * sizeof(double), &got));
+            HIP_TRY_H(v_set_max_lds(h->threads, h->nlds, h->dp.idx16, base + xs * sizeof(double)));
+            HIP_TRY_H(v_occupancy(h->threads, h->nlds, h->dp.idx16, base + xs * sizeof(double), &got));
             if (got >= bpc) break;
             xs = (xs * 3 / 4) & ~(size_t)15;
         }
@@ -656,6 +667,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (h->pslot < 0) return bail(EICOS_E_INVALID, "too many live handles on this device (64)");
     HIP_TRY_H(upload_pattern(h->pslot, h->dp));
     if (h->ldsres) HIP_TRY_H(ldsres::upload_pattern(h->pslot, h->dp));
+    if (h->w2) HIP_TRY_H(w2::upload_pattern(h->pslot, h->dp));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
@@ -799,6 +811,9 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (h->ldsres)
         HIP_TRY(ldsres::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
                                      h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
+    else if (h->w2)
+        HIP_TRY(w2::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
+                                 h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
     else
         HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
                              h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));

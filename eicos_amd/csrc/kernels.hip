@@ -43,6 +43,13 @@
 #ifndef EICOS_LDSRES
 #define EICOS_LDSRES 0
 #endif
+// A third compilation (kernels_w2.o, namespace eicos::w2, EICOS_W2 = 1): the 256-thread solve kernel with the register budget of TWO
+// waves per SIMD (256 VGPRs) for launches that run at most two workgroups per CU -- the default 256-thread build is held to 168
+// VGPRs so that three fit (batches >= 1536).  Same box: +2.7 % at batch 1024, +8 % on lp_adlittle (profiles/r03_log_wpe.log).
+#ifndef EICOS_W2
+#define EICOS_W2 0
+#endif
+#define EICOS_MAIN_BUILD (!EICOS_LDSRES && !EICOS_W2)
 
 namespace eicos {
 #if EICOS_LDSRES
@@ -54,6 +61,9 @@ namespace ldsres {
 #endif
 typedef double EICOS_DATA *gdbl_p;        // (shadow the global-memory typedefs of device_types.hpp)
 typedef const double EICOS_DATA *gcdbl_p;
+#elif EICOS_W2
+namespace w2 {
+#define EICOS_DATA EICOS_GLOBAL
 #else
 #define EICOS_DATA EICOS_GLOBAL
 #endif
@@ -74,8 +84,13 @@ constexpr int EX_NOT_CONVERGED = -87;
 // attributor propagates the kernel's budget to the non-inlined stage functions.
 #if EICOS_LDSRES
 template <int T> constexpr int waves_per_eu() { return 2; } // LDS allows at most three small workgroups per CU
+#elif EICOS_W2
+template <int T> constexpr int waves_per_eu() { return 2; }
 #else
-template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : (T == 512 ? 2 : 4); }
+#ifndef EICOS_WPE256
+#define EICOS_WPE256 3
+#endif
+template <int T> constexpr int waves_per_eu() { return T == 256 ? EICOS_WPE256 : (T == 512 ? 2 : 4); }
 #endif
 
 // Multiply-accumulate of the sparse inner loops (products, sweeps, factor program).  The file is compiled with
@@ -2268,7 +2283,7 @@ __global__ __launch_bounds__(1024) void k_order(int ps, const double *inst, int 
 // (The KKT "AG" scatter of updateKKTAG :1990-2030 is implicit: the factor kernel reads the
 //  equilibrated A/G values in place through DevPat::Lsrc.)
 // ============================================================================================
-#if !EICOS_LDSRES // (updateData and the debug kernels work on the slabs in HBM: main build only)
+#if EICOS_MAIN_BUILD // (updateData and the debug kernels work on the slabs in HBM: main build only)
 template <int T>
 __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, int count,
                                               const double *Gpr, const double *Apr, const double *cin,
@@ -2518,7 +2533,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
     if (threadIdx.x == 0) ok[0] = (st == ST_FACTOR) ? 1 : 0;
 }
 
-#endif // !EICOS_LDSRES
+#endif // EICOS_MAIN_BUILD
 
 // ---- launchers (called from api.cpp) ----
 #ifndef EICOS_ISA_PROBE // (tools/dev/isa_probe.sh compiles single stage functions without the kernel instantiations)
@@ -2544,9 +2559,13 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
         if (nlds == 1) return f((const void *)k_solve<T, 1, false>);
         return f((const void *)k_solve<T, 0, false>);
     };
+#if EICOS_W2
+    return byT(std::integral_constant<int, 256>{}); // (this build exists for 256 threads only)
+#else
     if (threads == 512) return byT(std::integral_constant<int, 512>{});
     if (threads == 128) return byT(std::integral_constant<int, 128>{});
     return byT(std::integral_constant<int, 256>{});
+#endif
 }
 #endif
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
@@ -2568,7 +2587,7 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
 }
-#if !EICOS_LDSRES
+#if EICOS_MAIN_BUILD
 hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,
                          const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, int vals_in_lds, hipStream_t st) {
     if (count <= 0) return hipSuccess;
@@ -2604,7 +2623,7 @@ hipError_t launch_debug_scalings(int ps, double *inst, double *work, int i, int 
     }
     return hipGetLastError();
 }
-#endif // !EICOS_LDSRES
+#endif // EICOS_MAIN_BUILD
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu) {
     return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, threads, dyn_lds);
@@ -2624,6 +2643,8 @@ hipError_t upload_pattern(int ps, const DevPat &P) {
 #endif // EICOS_ISA_PROBE
 #if EICOS_LDSRES
 } // namespace ldsres
+#elif EICOS_W2
+} // namespace w2
 #else
 int max_patterns() { return MAX_PATTERNS; }
 #endif

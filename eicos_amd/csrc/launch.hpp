@@ -23,4 +23,12 @@ hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
 } // namespace ldsres
+// 256-thread k_solve with the register budget of two waves per SIMD (kernels_w2.hip = kernels.hip compiled with EICOS_W2)
+namespace w2 {
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
+hipError_t upload_pattern(int ps, const DevPat &P);
+} // namespace w2
 } // namespace eicos

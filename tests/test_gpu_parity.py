@@ -162,6 +162,7 @@ def test_dense_front_socp():
                                  {"EICOS_FAC_L0": "0"}, {"EICOS_FAC_L0": "0", "EICOS_TILES": "0", "EICOS_THREADS": "256"},
                                  {"EICOS_E_LDS": "0"}, {"EICOS_E_LDS": "0", "EICOS_NLDS": "1", "EICOS_DUAL": "0"}, {"EICOS_E_LDS": "1", "EICOS_NLDS": "1", "EICOS_DUAL": "0"},
                                  {"EICOS_E_LDS": "1", "EICOS_NLDS": "1", "EICOS_DUAL": "0", "EICOS_TILES": "2", "EICOS_THREADS": "256"},
+                                 {"EICOS_W2": "0", "EICOS_THREADS": "256"}, {"EICOS_W2": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "0"},
                                  {"EICOS_FAC_DEFER": "0"}, {"EICOS_FAC_DEFER": "1", "EICOS_TILES": "2"}, {"EICOS_FAC_DEFER": "1", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
                                  {"EICOS_FAC_DEFER": "1", "EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_NLDS": "1"}, {"EICOS_FAC_DEFER": "1", "EICOS_FAC_L0": "0"},
                                  {"EICOS_LDSRES": "0"}, {"EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_TILES": "0"},
