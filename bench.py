@@ -111,6 +111,7 @@ class Job:
         self.step_no = 0
         self.solver = eicos_amd.BatchSolver(self.pat, B, device=local_rank)
         self.dims = self.solver.dims()
+        self.dims["kernel_build"] = self.solver.kernel_build()
         if args.warm > 0:
             self.solver.set_warm_start(args.warm)
 
@@ -177,6 +178,7 @@ class Job:
             "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
             "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
             "factor_path": ("scalar", "tile", "hybrid")[dims.get("factor_path", 0)], "lds_resident": bool(dims.get("lds_resident", 0)),
+            "kernel_build": dims.get("kernel_build"),
             "update_kernel_ms": r["update_ms"],
             "kernel_ms_min_over_ranks": r["kernel_ms_min_over_ranks"], "kernel_ms_max_over_ranks": r["kernel_ms_max_over_ranks"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -78,6 +78,7 @@ def _lib():
         L.eicos_batch_info.argtypes = [vp, C.POINTER(Info)]
         L.eicos_batch_solution_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.eicos_batch_dims.argtypes = [vp, C.POINTER(Dims)]
+        L.eicos_batch_kernel_build.argtypes = [vp]
         L.eicos_batch_set_stream.argtypes = [vp, vp]
         L.eicos_batch_set_warm_start.argtypes = [vp, C.c_double]
         L.eicos_batch_set_warm_start.restype = C.c_int
@@ -214,6 +215,13 @@ class BatchSolver:
         d = Dims()
         _chk(_lib().eicos_batch_dims(self._h, C.byref(d)))
         return d.asdict()
+
+    def kernel_build(self) -> str:
+        """Which compilation of the solve kernel the handle launches: 'default', 'lds-resident' or 'w2' (256 VGPRs, <= 2 workgroups per CU)."""
+        v = _lib().eicos_batch_kernel_build(self._h)
+        if v < 0:
+            _chk(v)
+        return ("default", "lds-resident", "w2")[v]
 
     def last_solve_ms(self) -> float:
         ms = C.c_float()

@@ -894,6 +894,11 @@ int eicos_batch_solution_device(eicos_batch *h, const double **dx, size_t *strid
     return EICOS_OK;
 }
 
+int eicos_batch_kernel_build(eicos_batch *h) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    return h->ldsres ? 1 : (h->w2 ? 2 : 0);
+}
+
 int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     if (!h || !o) return fail(EICOS_E_INVALID, "NULL argument");
     const Symbolic &S = h->sym;

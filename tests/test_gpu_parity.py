@@ -208,6 +208,21 @@ def test_deferred_l_factorisation_is_bit_identical_to_the_stored_l_one(name, mon
         assert np.array_equal(a_, b_)
 
 
+def test_kernel_build_reported_for_the_handle(monkeypatch):
+    # which compilation of k_solve a handle launches is part of its description: 256-thread workgroups at <= 2 per CU take the
+    # 256-VGPR build ("w2"), small patterns the LDS-resident one, everything else the default one; EICOS_W2=0 forbids the first
+    pat, sets = load_fixture("MPC02")
+    g = eicos_amd.BatchSolver(pat, 4); d = g.dims(); kb = g.kernel_build(); g.close()
+    assert kb == ("w2" if d["threads_per_block"] == 256 else "default") and not d["lds_resident"]
+    monkeypatch.setenv("EICOS_THREADS", "256")
+    g = eicos_amd.BatchSolver(pat, 4); assert g.kernel_build() == "w2"; g.close()
+    monkeypatch.setenv("EICOS_W2", "0")
+    g = eicos_amd.BatchSolver(pat, 4); assert g.kernel_build() == "default"; g.close()
+    monkeypatch.delenv("EICOS_W2"); monkeypatch.delenv("EICOS_THREADS")
+    pat, sets = load_fixture("lp_afiro")
+    g = eicos_amd.BatchSolver(pat, 4); d = g.dims(); assert (g.kernel_build() == "lds-resident") == bool(d["lds_resident"]); g.close()
+
+
 def test_g_tile_products_match_the_ell_products_on_dense_fronts(monkeypatch):
     # dense-front pattern: G goes to 16 x 16 tiles (one pass for G x and G' z); same iteration counts and solutions as with
     # the sliced-ELL products (the sums are associated differently, so not bit for bit); m and n not multiples of 16,
