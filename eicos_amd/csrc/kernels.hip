@@ -35,17 +35,17 @@
 #include "device_types.hpp"
 #include "launch.hpp"
 
-// This file is compiled twice.  EICOS_LDSRES = 0 (kernels.o): the slabs of an instance live in HBM.  EICOS_LDSRES = 1
+// This file is compiled three times.  EICOS_LDSRES = 0 (kernels.o): the slabs of an instance live in HBM.  EICOS_LDSRES = 1
 // (kernels_ldsres.o, namespace eicos::ldsres): the LDS-RESIDENT variant for small patterns -- k_solve copies the
 // instance slab and the workspace slab into LDS, solves there and copies both back, so every "slab" pointer below is an
 // LDS pointer (address space 3, ds_read / ds_write) and a dependent step of the sparse programs costs an LDS round trip
-// instead of an L2 one.  The shared pattern tables stay global in both builds.
+// instead of an L2 one.  The shared pattern tables stay global in every build.
 #ifndef EICOS_LDSRES
 #define EICOS_LDSRES 0
 #endif
 // A third compilation (kernels_w2.o, namespace eicos::w2, EICOS_W2 = 1): the 256-thread solve kernel with the register budget of TWO
 // waves per SIMD (256 VGPRs) for launches that run at most two workgroups per CU -- the default 256-thread build is held to 168
-// VGPRs so that three fit (batches >= 1536).  Same box: +2.7 % at batch 1024, +8 % on lp_adlittle (profiles/r03_log_wpe.log).
+// VGPRs so that three fit (batches >= 1536).  Same box: +3.4 % at batch 1024, +7.6 % on lp_adlittle (profiles/r03_log_wpe.log).
 #ifndef EICOS_W2
 #define EICOS_W2 0
 #endif
