@@ -268,7 +268,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     for (int c = 0; c < S.nc; c++) { const int e0 = S.n + S.p + S.cone_off[c] + 2 * c + S.q[c]; ipv[c] = posK(e0); ipu[c] = posK(e0 + 1); }
     D.inst_stride = L.size;
     SlabLayout Wl;
-    D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m); D.w_blam = Wl.add(S.m);
+    // second buffer set of the iterate (ShI::cur / best in kernels.hip): same spacing of y and z as in the instance slab -- the stacked
+    // product [A' G'] gathers (y, z) through ONE index array relative to y
+    D.w_lam = Wl.add(S.m); D.w_bx = Wl.add(S.n); D.w_by = Wl.add(S.p); D.w_bz = Wl.add(S.m); D.w_bs = Wl.add(S.m);
+    if (D.w_bz - D.w_by != D.i_z - D.i_y) { delete h; return fail(EICOS_E_INVALID, "internal: the two buffer sets of the iterate are laid out differently"); }
     D.w_rz = Wl.add(S.m);
     D.w_rhs1k = Wl.add((size_t)S.n + S.p + S.m); D.w_rhs2k = Wl.add((size_t)S.n + S.p + S.m);       // [x | y | z] order
     D.w_dx1 = Wl.add((size_t)S.n + S.p + S.m); D.w_dy1 = D.w_dx1 + S.n; D.w_dz1 = D.w_dy1 + S.p; // [dx | dy | dz]: one array each

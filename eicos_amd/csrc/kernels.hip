@@ -125,11 +125,15 @@ struct ShI {
     DevInfo wi, bi;
     double sv[SV_COUNT];
     int fl[FL_COUNT];
+    // The iterate (x, y, z, s) has two buffer sets: 0 = the instance slab (where the host reads the result), 1 = the workspace slab.
+    // `cur` holds the current iterate, `best` the reference's best iterate (-1: none yet).  Saving the best iterate is `best = cur`;
+    // the next update then writes the new iterate into the OTHER set instead of in place -- no copy of the iterate per pass.
+    int cur, best;
     double dots[2][3]; // c'dx, b'dy, h'dz of the last solve with right-hand side 1 / 2 (kkt_solve's epilogue; kkt_post's d tau needs them)
     int kref, kref2, done; // refinement steps of the last KKT solve (kref2: of the second right-hand side of a dual solve); 1 = this instance has finished
     unsigned long long tick[12]; // per-phase time of the current solve (100 MHz ticks), thread 0; [7] = start
 };
-struct Sh : ShI {
+struct alignas(16) Sh : ShI {
     double red[2 * RED_SLOTS];
     double dyn_delta, dyn_eps; // dynamic regularisation of the pivots (extension; 0 = off), set by k_solve
     int next; // next instance of this workgroup (k_solve's queue)
@@ -139,8 +143,10 @@ enum { TK_FACTOR = 0, TK_LDL, TK_KRES, TK_KPOST, TK_RESID, TK_FWD, TK_COUNT, TK_
 #define TICK_BEGIN unsigned long long tk0_ = (threadIdx.x == 0) ? wall_clock64() : 0ull
 #define TICK_END(slot) do { if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[slot] += t1_ - tk0_; tk0_ = t1_; } } while (0)
 static_assert(sizeof(Sh) <= 4096, "api.cpp budgets 4 KB of static LDS per workgroup");
-__shared__ Sh g_S;
-extern __shared__ double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | slice tables of both sweeps
+__shared__ __attribute__((aligned(16))) Sh g_S;
+struct IterBuf { gdbl_p x, y, z, s; };
+// (16-byte aligned: the dual right-hand-side vectors are read and written as 16-byte LDS accesses)
+extern __shared__ __attribute__((aligned(16))) double g_dyn[]; // E[Npad] (NLDS>=1) | X[Npad] (NLDS>=2) | slice tables of both sweeps
 
 // Arguments of non-inlined device functions arrive in VGPRs; the values below are workgroup-uniform,
 // so move them to SGPRs: address math and branches on them become scalar (s_load, s_cbranch) instead
@@ -1370,6 +1376,12 @@ __device__ __forceinline__ void g_tile_products(const DevPat &P, gcdbl_p Gt, gin
     __syncthreads();
 }
 
+// the buffer set `which` of the iterate (ShI::cur / ShI::best): 0 = instance slab, 1 = workspace slab (same spacing of y and z in both)
+__device__ __forceinline__ IterBuf iter_buf(const DevPat &P, gdbl_p I, gdbl_p W, int which) {
+    which = uni(which);
+    return which ? IterBuf{W + P.w_bx, W + P.w_by, W + P.w_bz, W + P.w_bs} : IterBuf{I + P.i_x, I + P.i_y, I + P.i_z, I + P.i_s};
+}
+
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
 template <int T, int NLDS, bool I16>
 __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
@@ -1377,10 +1389,11 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     iter = uni(iter);
     gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
     gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, Vv = I + P.i_Vv;
-    gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
     gdbl_p lam = W + P.w_lam, rz = W + P.w_rz, rhs2k = W + P.w_rhs2k;
     gdbl_p lpw = W + P.w_lpw, lpv = W + P.w_lpv, csc = W + P.w_csc, qv = W + P.w_qv;
     __syncthreads();
+    const IterBuf it = iter_buf(P, I, W, g_S.cur); // (after the barrier: the previous stage's thread 0 may just have switched sets)
+    gdbl_p wx = it.x, wy = it.y, wz = it.z, wsl = it.s;
     TICK_BEGIN;
     // ---- computeResiduals (ref :643-689) + updateStatistics (ref :691-754) ----
     const double tau = wi.tau;
@@ -1477,32 +1490,23 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
                     action = ACT_BREAK;
                 }
             } else action = ACT_BREAK;
-            if (action == ACT_CONTINUE && (iter == 0 || dev_better_than())) { g_S.bi = wi; save = 1; } // ref :1150-1158
+            if (action == ACT_CONTINUE && (iter == 0 || dev_better_than())) { g_S.bi = wi; save = 1; g_S.best = g_S.cur; } // ref :1150-1158: w_best = w, by reference
         }
         g_S.fl[FL_ACTION] = action; g_S.fl[FL_RESTORE] = restore; g_S.fl[FL_SAVE] = save; g_S.fl[FL_CODE] = code;
     }
     __syncthreads();
-    gdbl_p bx_ = W + P.w_bx, by_ = W + P.w_by, bz_ = W + P.w_bz, bs_ = W + P.w_bs, blam = W + P.w_blam;
-    if (g_S.fl[FL_RESTORE]) { // w = w_best (vectors)
-        FOR_T(j, n) wx[j] = bx_[j];
-        FOR_T(j, p) wy[j] = by_[j];
-        FOR_T(i, m) { wz[i] = bz_[i]; wsl[i] = bs_[i]; lam[i] = blam[i]; }
-    }
     if (g_S.fl[FL_ACTION] == ACT_BREAK) {
-        // backscale (ref :1271-1277)
-        __syncthreads();
+        // w = w_best (ref :1014 ff.: only ever followed by the exit) = read the best buffer set; backscale (ref :1271-1277) into the
+        // instance slab, where the host reads the result.  (lambda is not restored: nothing reads it after the exit.)
+        const IterBuf src = iter_buf(P, I, W, g_S.fl[FL_RESTORE] ? g_S.best : g_S.cur), dst = iter_buf(P, I, W, 0);
         gcdbl_p xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
         const double tau2 = wi.tau;
-        FOR_T(j, n) wx[j] = wx[j] / (xe[j] * tau2);
-        FOR_T(r, p) wy[r] = wy[r] / (ae[r] * tau2);
-        FOR_T(i, m) { wz[i] = wz[i] / (ge[i] * tau2); wsl[i] = wsl[i] * (ge[i] / tau2); }
+        FOR_T(j, n) dst.x[j] = src.x[j] / (xe[j] * tau2);
+        FOR_T(r, p) dst.y[r] = src.y[r] / (ae[r] * tau2);
+        FOR_T(i, m) { dst.z[i] = src.z[i] / (ge[i] * tau2); dst.s[i] = src.s[i] * (ge[i] / tau2); }
+        __syncthreads();
+        if (tid == 0) g_S.cur = 0;
         return ST_DONE;
-    }
-    if (g_S.fl[FL_SAVE]) { // w_best = w (vectors; ref :1153,1157)
-        for_t_pre<T, 4>(n, [&](int j) { return V1{wx[j]}; }, [&](int j, const V1 &r) { bx_[j] = r.a; });
-        for_t_pre<T, 4>(p, [&](int j) { return V1{wy[j]}; }, [&](int j, const V1 &r) { by_[j] = r.a; });
-        for_t_pre<T, 4>(m, [&](int i) { return V3{wz[i], wsl[i], lam[i]}; },
-                        [&](int i, const V3 &r) { bz_[i] = r.a; bs_[i] = r.b; blam[i] = r.c; });
     }
     // ---- updateScalings (ref :411-479) + updateKKTScalings (ref :1691-1732) ----
     // the scaling block goes to the instance slab (Vv) and to the factor's target-ordered value stream (Kt)
@@ -1901,7 +1905,8 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     const int tid = threadIdx.x;
     DevInfo &wi = g_S.wi;
     gdbl_p cv = I + P.i_c;
-    gdbl_p wx = I + P.i_x, wy = I + P.i_y, wz = I + P.i_z, wsl = I + P.i_s;
+    const IterBuf it = iter_buf(P, I, W, g_S.cur); // the current iterate's buffer set (switched only at the end of a stage, before its last barrier)
+    gdbl_p wx = it.x, wy = it.y, wz = it.z, wsl = it.s;
     gdbl_p lam = W + P.w_lam, rz = W + P.w_rz;
     gdbl_p rhs1k = W + P.w_rhs1k, rhs2k = W + P.w_rhs2k; // the right-hand sides as [x | y | z] (kkt_solve scatters them into the sweep vector)
     gdbl_p dx1 = W + P.w_dx1, dy1 = W + P.w_dy1, dz1 = W + P.w_dz1, dx2 = W + P.w_dx2, dy2 = W + P.w_dy2, dz2 = W + P.w_dz2;
@@ -2034,12 +2039,17 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         }
         const double st = GAMMA * dev_line_search<T, true>(ps, W, tau, dtau, kap, dkap, rmin, smin);
         if (P.nc > 0) dev_scale<T, true>(ps, W, dsw, dsa);
-        for_t_pre<T, 4>(n, [&](int j) { return V2{wx[j], dx2[j]}; }, [&](int j, const V2 &r) { wx[j] = r.a + st * r.b; });
-        for_t_pre<T, 4>(p, [&](int j) { return V2{wy[j], dy2[j]}; }, [&](int j, const V2 &r) { wy[j] = r.a + st * r.b; });
+        // the new iterate goes to the OTHER buffer set when the current one is the saved best iterate (ShI::best), else in place
+        const int tgt = uni(g_S.best == g_S.cur ? 1 - g_S.cur : g_S.cur);
+        const IterBuf nw = iter_buf(P, I, W, tgt);
+        for_t_pre<T, 4>(n, [&](int j) { return V2{wx[j], dx2[j]}; }, [&](int j, const V2 &r) { nw.x[j] = r.a + st * r.b; });
+        for_t_pre<T, 4>(p, [&](int j) { return V2{wy[j], dy2[j]}; }, [&](int j, const V2 &r) { nw.y[j] = r.a + st * r.b; });
         // LP rows: ds = W dsw formed in registers
-        for_t_pre<T, 4>(l, [&](int i) { return CB{wz[i], dz2[i], lpw[i], dsw[i], wsl[i]}; }, [&](int i, const CB &r) { wz[i] = r.z2 + st * r.z1; wsl[i] = r.lam + st * (r.w * r.ds); });
-        for_t_pre<T, 4>(m - l, [&](int i) { return V4{wz[l + i], dz2[l + i], wsl[l + i], dsa[l + i]}; }, [&](int i, const V4 &r) { wz[l + i] = r.a + st * r.b; wsl[l + i] = r.c + st * r.d; });
+        for_t_pre<T, 4>(l, [&](int i) { return CB{wz[i], dz2[i], lpw[i], dsw[i], wsl[i]}; }, [&](int i, const CB &r) { nw.z[i] = r.z2 + st * r.z1; nw.s[i] = r.lam + st * (r.w * r.ds); });
+        for_t_pre<T, 4>(m - l, [&](int i) { return V4{wz[l + i], dz2[l + i], wsl[l + i], dsa[l + i]}; }, [&](int i, const V4 &r) { nw.z[l + i] = r.a + st * r.b; nw.s[l + i] = r.c + st * r.d; });
+        __syncthreads(); // (every thread has read g_S.cur / best)
         if (tid == 0) {
+            g_S.cur = tgt;
             wi.nitref3 = kref; wi.step = st;
             wi.kap = kap + st * dkap;
             wi.tau = tau + st * dtau;
@@ -2071,6 +2081,7 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double wa
             g_S.fl[FL_WARM] = (warm > 0. && wi.n_factor > 0 && (wi.exitcode == 0 || wi.exitcode == 10)) ? 1 : 0;
             wi.n_factor = 0; wi.n_ldlsolve = 0;
             g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7; g_S.done = 0; g_S.kref = 0;
+            g_S.cur = 0; g_S.best = -1; // the iterate starts in the instance slab (warm start: the previous solution is there), no best iterate yet
             for (int q = 0; q < 12; q++) g_S.tick[q] = 0;
             g_S.tick[7] = wall_clock64();
         }
@@ -2174,7 +2185,16 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         if (stage == ST_FACTOR) {
             if (P.tile != 1) { if (P.fac_defer) stage_factor<T, NLDS, I16, true>(ps, W); else stage_factor<T, NLDS, I16, false>(ps, W); } // scalar program (hybrid: everything below the top block + its image)
             if (P.tile) stage_factor_tiles<T, NLDS>(ps, I, W, iter);
-            if (g_S.fl[FL_FATAL]) { instance_end(P, I, W); stage = ST_DONE; } // zero pivot -> fatal, no backscale (ref :901-905,1166-1170)
+            if (g_S.fl[FL_FATAL]) { // zero pivot -> fatal, no backscale (ref :901-905,1166-1170): the iterate as it stands is the result
+                if (g_S.cur != 0) {
+                    const IterBuf src = iter_buf(P, I, W, 1), dst = iter_buf(P, I, W, 0);
+                    for (int j = threadIdx.x; j < P.n; j += T) dst.x[j] = src.x[j];
+                    for (int j = threadIdx.x; j < P.p; j += T) dst.y[j] = src.y[j];
+                    for (int i = threadIdx.x; i < P.m; i += T) { dst.z[i] = src.z[i]; dst.s[i] = src.s[i]; }
+                    __syncthreads();
+                }
+                instance_end(P, I, W); stage = ST_DONE;
+            }
             else stage = (iter < 0) ? ST_KKT_INIT1 : ST_KKT1;
         } else if (stage == ST_RESID) {
             if (stage_resid<T, NLDS, I16>(ps, I, W, iter) == ST_DONE) { __syncthreads(); instance_end(P, I, W); stage = ST_DONE; }
@@ -2525,6 +2545,7 @@ __global__ __launch_bounds__(T, waves_per_eu<T>()) void k_debug_scalings(int ps,
         for (int k = 0; k < FL_COUNT; k++) g_S.fl[k] = 0;
         for (int k = 0; k < 12; k++) g_S.tick[k] = 0;
         g_S.dyn_delta = 0.; g_S.dyn_eps = 0.;
+        g_S.cur = 0; g_S.best = -1;
     }
     for (int j = threadIdx.x; j < P.n; j += T) I[P.i_x + j] = 0.;
     for (int j = threadIdx.x; j < P.p; j += T) I[P.i_y + j] = 0.;
