@@ -2021,8 +2021,7 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         const double bkap = kap * tau + dkapaff * dtauaff - sigma * wi.mu;
         const double dtau = ((1. - sigma) * g_S.sv[SV_RT] - bkap / tau + e3[0] + e3[1] + e3[2]) / g_S.sv[SV_DTAUDEN];
         const double dkap = -(bkap + kap * dtau) / tau;
-        for_t_pre<T, 4>(n, [&](int j) { return V2{dx2[j], dx1[j]}; }, [&](int j, const V2 &r) { dx2[j] = r.a + dtau * r.b; });
-        for_t_pre<T, 4>(p, [&](int j) { return V2{dy2[j], dy1[j]}; }, [&](int j, const V2 &r) { dy2[j] = r.a + dtau * r.b; });
+        // (dx2 += dtau dx1, dy2 += dtau dy1 are formed inside the update of x and y below: nothing else reads the combined dx, dy)
         // LP rows, one pass: dz2 += dtau dz1, wdz = W dz2 (registers), dsw = -(dsw + wdz) and the line search's ratios
         double rmin = DBL_MAX, smin = DBL_MAX;
         struct CB { double z2, z1, w, ds, lam; };
@@ -2042,8 +2041,8 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         // the new iterate goes to the OTHER buffer set when the current one is the saved best iterate (ShI::best), else in place
         const int tgt = uni(g_S.best == g_S.cur ? 1 - g_S.cur : g_S.cur);
         const IterBuf nw = iter_buf(P, I, W, tgt);
-        for_t_pre<T, 4>(n, [&](int j) { return V2{wx[j], dx2[j]}; }, [&](int j, const V2 &r) { nw.x[j] = r.a + st * r.b; });
-        for_t_pre<T, 4>(p, [&](int j) { return V2{wy[j], dy2[j]}; }, [&](int j, const V2 &r) { nw.y[j] = r.a + st * r.b; });
+        for_t_pre<T, 4>(n, [&](int j) { return V3{wx[j], dx2[j], dx1[j]}; }, [&](int j, const V3 &r) { nw.x[j] = r.a + st * (r.b + dtau * r.c); });
+        for_t_pre<T, 4>(p, [&](int j) { return V3{wy[j], dy2[j], dy1[j]}; }, [&](int j, const V3 &r) { nw.y[j] = r.a + st * (r.b + dtau * r.c); });
         // LP rows: ds = W dsw formed in registers
         for_t_pre<T, 4>(l, [&](int i) { return CB{wz[i], dz2[i], lpw[i], dsw[i], wsl[i]}; }, [&](int i, const CB &r) { nw.z[i] = r.z2 + st * r.z1; nw.s[i] = r.lam + st * (r.w * r.ds); });
         for_t_pre<T, 4>(m - l, [&](int i) { return V4{wz[l + i], dz2[l + i], wsl[l + i], dsa[l + i]}; }, [&](int i, const V4 &r) { nw.z[l + i] = r.a + st * r.b; nw.s[l + i] = r.c + st * r.d; });
