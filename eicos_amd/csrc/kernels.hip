@@ -758,6 +758,28 @@ __device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, do
     return fmin(fmax(alpha, STEPMIN), STEPMAX);
 }
 
+// lineSearch for a pattern WITHOUT second-order cones, inlined (no call: the caller keeps per-row values in registers across it).
+// rmin, smin: the thread's min(ds / lam), min(dz / lam) over its LP rows; same arithmetic as dev_line_search with nc = 0.
+template <int T>
+__device__ __forceinline__ double lp_line_search(double rmin, double smin, int l, double tau, double dtau, double kap, double dkap) {
+    int phase = 0;
+    __syncthreads();
+    double v4[4] = {-rmin, -smin, 0., 0.};
+    blk_reduce<OpMax, T, 4>(phase, v4);
+    rmin = -v4[0]; smin = -v4[1];
+    double alpha;
+    if (l > 0) {
+        const double eps = 1e-13;
+        if (-smin > -rmin) alpha = smin < 0. ? 1. / (-smin) : 1. / eps;
+        else alpha = rmin < 0. ? 1. / (-rmin) : 1. / eps;
+    } else alpha = 10.;
+    const double mtd = -tau / dtau, mkd = -kap / dkap;
+    if (mtd > 0. && mtd < alpha) alpha = mtd;
+    if (mkd > 0. && mkd < alpha) alpha = mkd;
+    __syncthreads();
+    return fmin(fmax(alpha, STEPMIN), STEPMAX);
+}
+
 // ---------------- checkExitConditions (ref :526-641), thread 0 only, on g_S.wi ----------------
 __device__ __forceinline__ int dev_check_exit(bool reduced) {
     DevInfo &wi = g_S.wi;
@@ -1897,7 +1919,9 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
 }
 
 // ---------------- the KKT stages, part 2: post-processing of one instance (its state is in g_S) ----------------
-template <int T>
+// RF: the register-resident fast path (below) for the affine / combined stages -- its own instantiation, so that the generic one keeps
+// the code (and instruction-cache footprint) it had; kkt_post_any picks per pattern.
+template <int T, bool RF>
 __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W); stage = uni(stage);
     const DevPat &P = c_pat[ps];
@@ -1913,6 +1937,22 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     gdbl_p dsw = W + P.w_dsw, wdz = W + P.w_wdz, dsa = W + P.w_dsa, t1 = W + P.w_t1, t2 = W + P.w_t2;
     gdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
     const int kref = g_S.kref;
+    // Register-resident fast path of the affine / combined post-processing: no second-order cone and at most RL LP rows per thread --
+    // W dz, ds (and the combined dz) of a thread's rows stay in registers across the line search instead of going through HBM.
+    // Only in builds compiled for <= 2 waves per SIMD (256 VGPRs).
+    constexpr int RL = 16, RH = 8;
+    // (and only when at least a quarter of the RL slots of a thread are used: on small patterns the unrolled rounds mostly issue clamped loads)
+    constexpr bool regfast = RF; // (kkt_post_any: builds for <= 2 waves per SIMD, no cone, RL T / 4 < l <= RL T)
+    auto for_rl = [&](auto &&ld, auto &&fn) __attribute__((always_inline)) { // (two half rounds: RH rows of a thread in flight)
+#pragma unroll
+        for (int h = 0; h < RL / RH; h++) {
+            decltype(ld(0)) r[RH];
+#pragma unroll
+            for (int u = 0; u < RH; u++) { const int i = tid + (h * RH + u) * T; r[u] = ld(i < l ? i : 0); }
+#pragma unroll
+            for (int u = 0; u < RH; u++) { const int i = tid + (h * RH + u) * T; if (i < l) fn(h * RH + u, i, r[u]); }
+        }
+    };
     __syncthreads();
     TICK_BEGIN;
     if (stage == ST_KKT_INIT1) { // ref :933-939
@@ -1943,6 +1983,17 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         // LP rows, one pass: dz2 += dtauaff dz1 (kept in registers: nothing reads the affine dz2 of an LP row again), wdz = W dz2,
         // dsw = -wdz - lam and the line search's ratios -- the element-wise operations of the four separate passes, unchanged
         double rmin = DBL_MAX, smin = DBL_MAX;
+        double wv[RL], dv[RL]; // fast path: W dz and ds of the thread's LP rows stay in registers across the line search
+        double step_aff;
+        if constexpr (regfast) {
+            for_rl([&](int i) { return V4{dz2[i], dz1[i], lpw[i], lam[i]}; }, [&](int k, int, const V4 &r) {
+                const double z2 = r.a + dtauaff * r.b, w = r.c * z2, d = -w - r.d;
+                wv[k] = w; dv[k] = d;
+                rmin = fmin(rmin, d / r.d); smin = fmin(smin, w / r.d);
+            });
+            if (tid == 0) { g_S.sv[SV_DTAUDEN] = dtau_denom; g_S.sv[SV_DTAUAFF] = dtauaff; g_S.sv[SV_DKAPAFF] = dkapaff; }
+            step_aff = lp_line_search<T>(rmin, smin, l, tau, dtauaff, kap, dkapaff);
+        } else {
         for_t_pre<T, 4>(l, [&](int i) { return V4{dz2[i], dz1[i], lpw[i], lam[i]}; }, [&](int i, const V4 &r) {
             const double z2 = r.a + dtauaff * r.b, w = r.c * z2, d = -w - r.d;
             wdz[i] = w; dsw[i] = d;
@@ -1955,7 +2006,8 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
             dev_scale<T, true>(ps, W, dz2, wdz);
             for_t_pre<T, 8>(m - l, [&](int i) { return V2{wdz[l + i], lam[l + i]}; }, [&](int i, const V2 &r) { dsw[l + i] = -r.a - r.b; });
         }
-        const double step_aff = dev_line_search<T, true>(ps, W, tau, dtauaff, kap, dkapaff, rmin, smin);
+        step_aff = dev_line_search<T, true>(ps, W, tau, dtauaff, kap, dkapaff, rmin, smin);
+        }
         const double oms_ = 1. - step_aff;
         const double sigma = fmin(fmax(oms_ * oms_ * oms_, SIGMAMIN), SIGMAMAX);
         const double mu = wi.mu;
@@ -1964,7 +2016,13 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         // ---- RHScombined (ref :1282-1325) ----
         const double sigmamu = sigma * mu, oms = 1. - sigma;
         struct RC { double lam, ds, wz, w, rz; };
-        for_t_pre<T, 4>(l, [&](int i) { return RC{lam[i], dsw[i], wdz[i], lpw[i], rz[i]}; }, [&](int i, const RC &r) {
+        if constexpr (regfast) for_rl([&](int i) { return V3{lam[i], lpw[i], rz[i]}; }, [&](int k, int i, const V3 &r) {
+            const double d1_ = r.a * r.a + dv[k] * wv[k] - sigmamu; // (the same expressions as below, ds and W dz from the registers)
+            const double q_ = d1_ / r.a;
+            dsw[i] = q_;
+            rhs2k[np + i] = -oms * r.c + r.b * q_;
+        });
+        else for_t_pre<T, 4>(l, [&](int i) { return RC{lam[i], dsw[i], wdz[i], lpw[i], rz[i]}; }, [&](int i, const RC &r) {
             // LP part: ds1 = lam*lam + dsw*wdz - sigmamu ; dsw = ds1/lam ; t1 = w*dsw (in registers) ; rhs2 row = -(1 - sigma) rz + t1
             const double d1_ = r.lam * r.lam + r.ds * r.wz - sigmamu;
             const double q_ = d1_ / r.lam;
@@ -2025,6 +2083,16 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
         // LP rows, one pass: dz2 += dtau dz1, wdz = W dz2 (registers), dsw = -(dsw + wdz) and the line search's ratios
         double rmin = DBL_MAX, smin = DBL_MAX;
         struct CB { double z2, z1, w, ds, lam; };
+        double zv[RL], dv[RL]; // fast path: the combined dz and ds of the thread's LP rows stay in registers across the line search
+        double st;
+        if constexpr (regfast) {
+            for_rl([&](int i) { return CB{dz2[i], dz1[i], lpw[i], dsw[i], lam[i]}; }, [&](int k, int, const CB &r) {
+                const double z2 = r.z2 + dtau * r.z1, w = r.w * z2, d = -(r.ds + w);
+                zv[k] = z2; dv[k] = d;
+                rmin = fmin(rmin, d / r.lam); smin = fmin(smin, w / r.lam);
+            });
+            st = GAMMA * lp_line_search<T>(rmin, smin, l, tau, dtau, kap, dkap);
+        } else {
         for_t_pre<T, 4>(l, [&](int i) { return CB{dz2[i], dz1[i], lpw[i], dsw[i], lam[i]}; }, [&](int i, const CB &r) {
             const double z2 = r.z2 + dtau * r.z1, w = r.w * z2, d = -(r.ds + w);
             dz2[i] = z2; dsw[i] = d;
@@ -2036,15 +2104,17 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
             dev_scale<T, true>(ps, W, dz2, wdz);
             for_t_pre<T, 8>(m - l, [&](int i) { return V2{dsw[l + i], wdz[l + i]}; }, [&](int i, const V2 &r) { dsw[l + i] = -(r.a + r.b); });
         }
-        const double st = GAMMA * dev_line_search<T, true>(ps, W, tau, dtau, kap, dkap, rmin, smin);
+        st = GAMMA * dev_line_search<T, true>(ps, W, tau, dtau, kap, dkap, rmin, smin);
         if (P.nc > 0) dev_scale<T, true>(ps, W, dsw, dsa);
+        }
         // the new iterate goes to the OTHER buffer set when the current one is the saved best iterate (ShI::best), else in place
         const int tgt = uni(g_S.best == g_S.cur ? 1 - g_S.cur : g_S.cur);
         const IterBuf nw = iter_buf(P, I, W, tgt);
         for_t_pre<T, 4>(n, [&](int j) { return V3{wx[j], dx2[j], dx1[j]}; }, [&](int j, const V3 &r) { nw.x[j] = r.a + st * (r.b + dtau * r.c); });
         for_t_pre<T, 4>(p, [&](int j) { return V3{wy[j], dy2[j], dy1[j]}; }, [&](int j, const V3 &r) { nw.y[j] = r.a + st * (r.b + dtau * r.c); });
         // LP rows: ds = W dsw formed in registers
-        for_t_pre<T, 4>(l, [&](int i) { return CB{wz[i], dz2[i], lpw[i], dsw[i], wsl[i]}; }, [&](int i, const CB &r) { nw.z[i] = r.z2 + st * r.z1; nw.s[i] = r.lam + st * (r.w * r.ds); });
+        if constexpr (regfast) for_rl([&](int i) { return V3{wz[i], lpw[i], wsl[i]}; }, [&](int k, int i, const V3 &r) { nw.z[i] = r.a + st * zv[k]; nw.s[i] = r.c + st * (r.b * dv[k]); });
+        else for_t_pre<T, 4>(l, [&](int i) { return CB{wz[i], dz2[i], lpw[i], dsw[i], wsl[i]}; }, [&](int i, const CB &r) { nw.z[i] = r.z2 + st * r.z1; nw.s[i] = r.lam + st * (r.w * r.ds); });
         for_t_pre<T, 4>(m - l, [&](int i) { return V4{wz[l + i], dz2[l + i], wsl[l + i], dsa[l + i]}; }, [&](int i, const V4 &r) { nw.z[l + i] = r.a + st * r.b; nw.s[l + i] = r.c + st * r.d; });
         __syncthreads(); // (every thread has read g_S.cur / best)
         if (tid == 0) {
@@ -2058,6 +2128,15 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     }
     TICK_END(TK_KPOST);
     return stage;
+}
+
+template <int T>
+__device__ __forceinline__ int kkt_post_any(int ps, gdbl_p I, gdbl_p W, int stage) {
+    const DevPat &P = c_pat[ps];
+    constexpr int RL = 16; // (= kkt_post's)
+    const bool rf = waves_per_eu<T>() <= 2 && P.nc == 0 && 4 * P.l > RL * T && P.l <= RL * T && (stage == ST_KKT_AFF || stage == ST_KKT_COMB);
+    if (rf) return kkt_post<T, true>(ps, I, W, stage);
+    return kkt_post<T, false>(ps, I, W, stage);
 }
 
 // ---------------- per-instance prologue of a solve (its state ends up in g_S); returns 1 if it was warm-started ----------------
@@ -2201,20 +2280,20 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
         } else if (NLDS == 1 && P.dual && (stage == ST_KKT_INIT1 || stage == ST_KKT1)) {
             // the two right-hand sides of this point of the algorithm do not depend on each other: one dual solve
             if constexpr (NLDS == 1) {
-                if (stage == ST_KKT1) kkt_post<T>(ps, I, W, ST_KKT1); // RHSaffine (ref :1176) needs the residuals only
+                if (stage == ST_KKT1) kkt_post_any<T>(ps, I, W, ST_KKT1); // RHSaffine (ref :1176) needs the residuals only
                 kkt_solve<T, 1, I16, 2, true>(ps, I, I, W, stage, 3);
                 const int second = (stage == ST_KKT1) ? ST_KKT_AFF : ST_KKT_INIT2;
-                if (stage == ST_KKT_INIT1) kkt_post<T>(ps, I, W, ST_KKT_INIT1);
+                if (stage == ST_KKT_INIT1) kkt_post_any<T>(ps, I, W, ST_KKT_INIT1);
                 __syncthreads();
                 if (threadIdx.x == 0) g_S.kref = g_S.kref2;
                 __syncthreads();
-                const int next = kkt_post<T>(ps, I, W, second);
+                const int next = kkt_post_any<T>(ps, I, W, second);
                 if (next == ST_RESID) iter = 0; // (after the initialisation pair)
                 stage = next;
             }
         } else {
             kkt_solve<T, NLDS, I16, 1>(ps, I, I, W, stage, 1);
-            const int next = kkt_post<T>(ps, I, W, stage);
+            const int next = kkt_post_any<T>(ps, I, W, stage);
             if (next == ST_RESID) iter = (stage == ST_KKT_INIT2) ? 0 : iter + 1; // a pass of the main loop completed
             stage = next;
         }
