@@ -1,6 +1,7 @@
 #!/bin/bash
 # ISA of ONE stage function of kernels.hip in seconds (the full file takes two minutes):
-#   tools/dev/isa_probe.sh 'stage_factor<256, 1, true, 1>(ps, (gdbl_p)w)' > /tmp/x.s      (ps: int, w: double *, i: double *)
+#   tools/dev/isa_probe.sh 'stage_factor<256, 1, true, true>(ps, (gdbl_p)w)' > /tmp/x.s      (ps, a, b: int, w, i: double *; WPE=2 for the 256-VGPR budget)
+#   WPE=2 tools/dev/isa_probe.sh 'a = kkt_post<256, true>(ps, (gdbl_p)i, (gdbl_p)w, a); w[0] = a' | grep -E 'NumVgprs|ScratchSize'
 set -e
 d=$(mktemp -d)
 cat > $d/p.hip <<EOT
