@@ -15,8 +15,10 @@ Metric value = sum over instances of Information.iter / time.
           at N = 8): "scaling": "strong".  `--batch B` forces B instances per GPU instead (weak scaling).
 Instances are independent: no data-path collective; only the timing / iteration counters are reduced.
 
-The line also carries a "soc" object: the same step on the MPC-SOC variant of the pattern (332 second-order cones of
-dimension 3) with its own value and roofline, so that the metric's "SOCP" is what gets timed.
+`config.summary` of the line carries one compact entry per workload: the headline, "soc" -- the same step on the MPC-SOC
+variant of the pattern (332 second-order cones of dimension 3), so that the metric's "SOCP" is what
+gets timed -- and, at N = 1, every other BASELINE.json config (dense-front batch 512, three LPnetlib patterns at batch 256,
+MPC02 at batch 512 and 4096).  The full per-workload objects go to stderr / gpurun_out/bench_details.json.
 """
 import argparse
 import hashlib
@@ -56,14 +58,16 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def algorithmic_bytes(dims, ia):
+def algorithmic_bytes(dims, ia, sweeps="n_ldlsolve"):
     """Algorithmic HBM bytes of ONE solve launch (fp64 values only; shared index arrays excluded),
-    SURVEY.md 8(d) formula with the measured counters of every instance."""
+    SURVEY.md 8(d) formula with the measured counters of every instance.
+    sweeps="n_sweep": charge the passes over L, A, G that were really made (a dual right-hand-side solve streams them once for
+    two solves) instead of one pass per LDL solve -- the stricter yardstick for paths that use dual solves (`frac_dual`)."""
     n, p, m = dims["n"], dims["p"], dims["m"]
     N, nnzK, nnzL = dims["dim_K"], dims["nnzK"], dims["nnzL"]
     nnzAG = dims["nnzA"] + dims["nnzG"]
     f = ia["n_factor"].astype(np.float64).sum()
-    r = ia["n_ldlsolve"].astype(np.float64).sum()
+    r = ia[sweeps].astype(np.float64).sum()
     it = (ia["iter"].astype(np.float64) + 1).sum()
     per_factor = nnzK + nnzL + N                 # read K values, write L and D
     per_solve = 2 * nnzL + 3 * N                 # L forward + L backward, D, rhs in / x out
@@ -169,7 +173,9 @@ class Job:
         dims, ia = self.dims, r["ia"]
         abytes = algorithmic_bytes(dims, ia)
         achieved = abytes / (r["kernel_ms"] * 1e-3) / 1e9
+        abytes_dual = algorithmic_bytes(dims, ia, "n_sweep")
         traffic, src = pmc_traffic(tag)
+        inst_ms = np.sort(ia["solve_us"]) * 1e-3  # device wall time of every instance's solve (its workgroup): the launch's tail
         return {
             "value": r["iters"] * steps / r["dt"], "unit": "iter/s", "ms_per_step": r["dt"] / steps * 1e3,
             "solves_per_sec": r["instances"] * steps / r["dt"], "optimal": r["ok"], "instances": r["instances"],
@@ -180,10 +186,14 @@ class Job:
             "factor_path": ("scalar", "tile", "hybrid")[dims.get("factor_path", 0)], "lds_resident": bool(dims.get("lds_resident", 0)),
             "kernel_build": dims.get("kernel_build"),
             "update_kernel_ms": r["update_ms"],
+            # how much of the launch is its slowest instances: a launch cannot end before its slowest instance does
+            "instance_ms": {"mean": float(inst_ms.mean()), "p95": float(inst_ms[int(0.95 * (len(inst_ms) - 1))]), "max": float(inst_ms[-1])},
             "kernel_ms_min_over_ranks": r["kernel_ms_min_over_ranks"], "kernel_ms_max_over_ranks": r["kernel_ms_max_over_ranks"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-                         "kernel": "k_solve", "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": abytes},
+                         "kernel": "k_solve", "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": abytes,
+                         # the same with the passes over L / A / G a dual right-hand-side solve really makes (= frac when no dual solves ran)
+                         "frac_dual": abytes_dual / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_dual": abytes_dual},
         }
 
     def cpu_baseline(self, ia, target_s=30.0):
@@ -192,7 +202,7 @@ class Job:
         data, pat, B = self.data, self.pat, self.B
         cores = usable_cores()
         sub = lambda k, a, b: data[k][a:b]
-        run = lambda a, b: orc.batch_solve(pat, sub("Gpr", a, b), sub("Apr", a, b), sub("c", a, b), sub("h", a, b), sub("b", a, b), cores)
+        run = lambda a, b: orc.batch_solve(pat, sub("Gpr", a, b), sub("Apr", a, b), sub("c", a, b), sub("h", a, b), sub("b", a, b), cores, native=True)
         # bounded sample: a pilot of one instance per core sizes the sample to 10..30 s of CPU work (capped at four passes over
         # the batch; the pilot runs cold and overestimates the time per instance by up to 3x, hence the target of 30), so that
         # small and large patterns are both timed over a comparable span
@@ -201,17 +211,20 @@ class Job:
         per_inst_cpu = (r0["seconds"] + r0["update_seconds"]) * min(cores, npil) / npil
         want = int(max(npil, min(4 * B, target_s / max(per_inst_cpu, 1e-9))))
         reps, ns = (1, want) if want <= B else (min(4, -(-want // B)), B)
-        tot_iters, wall, match, maxdiff = 0, 0.0, True, 0
+        tot_iters, wall, match, maxdiff, native = 0, 0.0, True, 0, False
         for _ in range(reps):
             r = run(0, ns)
+            native = r["native"]
             tot_iters += int(r["iters"].sum()); wall += r["seconds"] + r["update_seconds"]
             diff = np.abs(r["iters"].astype(np.int64) - ia["iter"][:ns].astype(np.int64))
             match = match and bool(diff.max() == 0)
             maxdiff = max(maxdiff, int(diff.max()))
             n_eq, n_1, n_code = int((diff == 0).sum()), int((diff <= 1).sum()), int((r["exitcodes"] == ia["exitcode"][:ns]).sum())
         return {"value": float(tot_iters / wall), "unit": "iter/s", "cores": cores, "kind": "port",
-                "sample": f"first {ns} instances of the same batch x {reps} pass(es), one instance per thread at a time "
-                          f"(updateData+solve), {wall:.2f}s wall = {wall * cores:.0f} core-seconds",
+                "sample": f"first {ns} instances x {reps} pass(es), one instance per thread at a time (updateData+solve), "
+                          f"{wall:.2f}s wall = {wall * cores:.0f} core-s; oracle built {'-O2 -march=native on this host (reference Release flags)' if native else '-O2 (portable)'}; "
+                          "symbolic analysis hoisted out of the timed solve (the reference repeats analyzePattern in every solve(), src/eicos.cpp:897)",
+                "build": "-O2 -march=native" if native else "-O2",
                 # parity tolerance on iteration counts is +-1: rounding may move an exit by one pass
                 # (a perturbed, ill-conditioned instance can stall for tens of passes before a reduced-accuracy exit: which pass
                 # that is depends on rounding; the exit codes still agree)
@@ -244,6 +257,22 @@ def refinement_profile(job, n=16):
             "ldl_solves_gpu": tot_g, "ldl_solves_oracle": tot_o, "solveKKT_calls": calls,
             "mean_refinement_steps_per_solveKKT": tot_g / max(1, calls) - 1.0,
             "ldl_solves_per_factorisation": tot_g / max(1, passes), "first": rows[:2]}
+
+def summarise(rep):
+    """Compact form of one workload's report for `config.summary` (short keys, numbers rounded: the whole line stays below 6 KB)."""
+    roof, cpu = rep["roofline"], rep.get("cpu_baseline")
+    r3 = lambda v: None if v is None else float(f"{v:.4g}")
+    o = {"value": r3(rep["value"]), "batch": rep["instances"], "optimal": rep["optimal"], "mean_iter": r3(rep["mean_iter"]),
+         "ldl_per_iter": r3(rep["mean_ldl_solves_per_iter"]), "path": rep["factor_path"] + "/" + str(rep.get("kernel_build")),
+         "kernel_ms": r3(roof["kernel_ms"]), "frac": r3(roof["frac"]), "frac_dual": r3(roof["frac_dual"]),
+         "algo_GB": r3(roof["algorithmic_bytes_per_launch"] / 1e9),
+         "traffic_ratio": r3(roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof.get("traffic") else None,
+         "inst_ms_p95": r3(rep["instance_ms"]["p95"]), "inst_ms_max": r3(rep["instance_ms"]["max"])}
+    if cpu:
+        o.update({"cpu": r3(cpu["value"]), "cpu_cores": cpu["cores"], "x_cpu": r3(rep["value"] / cpu["value"]),
+                  "iters_equal": f"{cpu['iters_equal']}/{cpu['instances_compared']}", "codes_equal": f"{cpu['exitcodes_equal']}/{cpu['instances_compared']}"})
+    return o
+
 
 def run_config(args, name, pattern, batch, local_rank, perturb=False, soc=False, steps=3, warmup=1, cpu_s=6.0):
     """One additional BASELINE.json config on this GPU, timed like the headline (updateData + solve per step): its own
@@ -389,32 +418,55 @@ def main():
     if rank == 0:
         dims = job.dims
         roof = main_rep.pop("roofline")
+        value, unit, ms_per_step = main_rep.pop("value"), main_rep.pop("unit"), main_rep.pop("ms_per_step")
+        details = {"headline": {**main_rep, "value": value, "roofline": roof, "cpu_baseline": cpu}}
+        # One compact entry per workload INSIDE `config` (the driver's record keeps `config` whole but only a tail of stdout):
+        # value (iter/s), roofline fraction by algorithmic bytes (and with the passes a dual solve really makes), kernel ms per launch,
+        # PMC traffic / algorithmic bytes (null without a hash-matched summary in profiles/), the launch's tail, CPU baseline and parity counts
+        summary = {"headline": summarise({**main_rep, "value": value, "roofline": roof, "cpu_baseline": cpu})}
+        if soc_rep is not None:
+            details["soc"] = soc_rep
+            summary["soc"] = summarise(soc_rep)
+        if default_workload and world == 1 and not args.no_configs and not args.soc and args.batch is None and args.total is None:
+            # every other BASELINE.json config, driver-run: configs[4] dense-front (MFMA path), configs[3] LPnetlib (three of the
+            # ten patterns: the smallest, a mid-size hybrid one, the deepest), the per-GPU share of configs[2] and north_star's
+            # ">= 10x the host at batch 4096 on one GPU" configuration
+            cfg = {}
+            cfg["dense_front_b512"] = run_config(args, "dense_front", "dense-front", 512, local_rank, steps=2, warmup=1, cpu_s=8.0)
+            for nm in ("lp_afiro", "lp_bandm", "lp_25fv47"):
+                cfg[f"{nm}_b256"] = run_config(args, nm, nm, 256, local_rank, perturb=True, steps=5, warmup=1, cpu_s=4.0)
+            cfg["mpc_b512"] = run_config(args, "mpc_b512", "MPC02", 512, local_rank, steps=5, warmup=1, cpu_s=6.0)
+            cfg["mpc_b4096"] = run_config(args, "mpc_b4096", "MPC02", 4096, local_rank, steps=3, warmup=1, cpu_s=6.0)
+            for k, v in cfg.items():
+                details[k] = v
+                summary[k] = summarise(v)
         out = {
-            "metric": "ipm_iterations_per_sec", "value": main_rep.pop("value"), "unit": main_rep.pop("unit"),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rep.pop("ms_per_step"),
+            "metric": "ipm_iterations_per_sec", "value": value, "unit": unit,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{total} instances total = {B}/GPU x {world} GPU ({scaling}), {args.pattern}{'-SOC' if args.soc else ''} pattern "
                                    f"(n={dims['n']} m={dims['m']} p={dims['p']} cones={dims['ncones']}), "
                                    f"{'perturbed (c,h)' if args.perturb else 'strictly feasible generated (c,h,b)'}, updateData+solve per step",
-                       "batch_per_gpu": B, "total_instances": total, **main_rep,
-                       "generator": "perturbed" if args.perturb else "feasible",
+                       "batch_per_gpu": B, "total_instances": total,
+                       "solves_per_sec": main_rep["solves_per_sec"], "optimal": main_rep["optimal"], "mean_iter": main_rep["mean_iter"],
+                       "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"], "levels": dims["nlevels"],
+                       "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"], "kernel_build": dims["kernel_build"],
+                       "kernel_ms_min_over_ranks": main_rep["kernel_ms_min_over_ranks"], "kernel_ms_max_over_ranks": main_rep["kernel_ms_max_over_ranks"],
                        "io": ("root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms,
-                       **({"resolve_eps": args.resolve, "warm_shift": args.warm} if args.resolve > 0 else {})},
+                       **({"resolve_eps": args.resolve, "warm_shift": args.warm} if args.resolve > 0 else {}),
+                       "summary": summary},
             "roofline": roof,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        if soc_rep is not None:
-            out["soc"] = soc_rep
-        if default_workload and world == 1 and not args.no_configs and not args.soc and args.batch is None and args.total is None:
-            # every other BASELINE.json config, driver-run: configs[4] dense-front (MFMA path), configs[3] LPnetlib (three of the
-            # ten patterns: the smallest, a mid-size hybrid one, the deepest), and the per-GPU share of configs[2]
-            cfg = {}
-            cfg["dense_front_b512"] = run_config(args, "dense_front", "dense-front", 512, local_rank, steps=2, warmup=1, cpu_s=8.0)
-            for nm in ("lp_afiro", "lp_bandm", "lp_25fv47"):
-                cfg[f"lpnetlib_{nm}_b256"] = run_config(args, nm, nm, 256, local_rank, perturb=True, steps=5, warmup=1, cpu_s=4.0)
-            cfg["mpc_b512"] = run_config(args, "mpc_b512", "MPC02", 512, local_rank, steps=5, warmup=1, cpu_s=6.0)
-            out["configs"] = cfg
+        # the full per-workload objects (dims, exit-code histograms, refinement profile of the SOC leg, ...) go to stderr and,
+        # when the directory exists, to gpurun_out/bench_details.json: stdout carries exactly ONE json line
+        try:
+            sys.stderr.write("bench details: " + json.dumps(details) + "\n")
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                json.dump(details, open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "w"))
+        except (OSError, TypeError, ValueError):
+            pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

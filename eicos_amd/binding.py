@@ -26,7 +26,7 @@ class Info(C.Structure):
         "pcost", "dcost", "pres", "dres", "gap", "relgap", "sigma", "mu", "step", "step_aff",
         "kapovert", "pinfres", "dinfres", "tau", "kap")] + [(k, C.c_int) for k in (
         "has_relgap", "has_pinfres", "has_dinfres", "pinf", "dinf", "iter", "nitref1", "nitref2",
-        "nitref3", "exitcode", "n_factor", "n_ldlsolve")]
+        "nitref3", "exitcode", "n_factor", "n_ldlsolve", "n_sweep", "reserved_")] + [("solve_us", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -38,7 +38,7 @@ class Dims(C.Structure):
                [("factor_pairs", C.c_longlong), ("inst_bytes", C.c_size_t), ("work_bytes", C.c_size_t),
                 ("pattern_bytes", C.c_size_t), ("threads_per_block", C.c_int), ("resident_blocks", C.c_int),
                 ("lds_bytes", C.c_int), ("instances_per_block", C.c_int),
-                ("lds_resident", C.c_int), ("factor_path", C.c_int)]
+                ("lds_resident", C.c_int), ("factor_path", C.c_int), ("cone_order", C.c_int), ("dual_rhs", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -207,8 +207,7 @@ class BatchSolver:
     def info_arrays(self):
         arr = (Info * self.batch)()
         _chk(_lib().eicos_batch_info(self._h, arr))
-        raw = np.frombuffer(arr, dtype=np.dtype([(k, "f8") for k, t in Info._fields_ if t is C.c_double] +
-                                                [(k, "i4") for k, t in Info._fields_ if t is C.c_int]))
+        raw = np.frombuffer(arr, dtype=np.dtype([(k, "f8" if t is C.c_double else "i4") for k, t in Info._fields_]))  # (declaration order)
         return {k: raw[k].copy() for k in raw.dtype.names}
 
     def dims(self) -> dict:

@@ -318,6 +318,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (!tile1) { planF = build_tri_plan(S, h->threads, true); planB = build_tri_plan(S, h->threads, false); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
+    // every section of a sweep plan is a whole number of queue-depth trips (tri_sweep's remainder loop executes full trips)
+    if (D.nfs % TRI_DEPTH || D.nbs % TRI_DEPTH || D.nfs_ext % TRI_DEPTH || D.nfs_solo % TRI_DEPTH_SOLO || D.nbs_solo % TRI_DEPTH_SOLO) {
+        delete h; return fail(EICOS_E_INVALID, "internal: a section of a sweep plan is not padded to its queue depth");
+    }
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
     h->posB = planB.pos;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
@@ -856,6 +860,7 @@ int eicos_batch_info(eicos_batch *h, eicos_info *info) {
         o.has_relgap = d.has_relgap; o.has_pinfres = d.has_pinfres; o.has_dinfres = d.has_dinfres;
         o.pinf = d.pinf; o.dinf = d.dinf; o.iter = d.iter; o.nitref1 = d.nitref1; o.nitref2 = d.nitref2;
         o.nitref3 = d.nitref3; o.exitcode = d.exitcode; o.n_factor = d.n_factor; o.n_ldlsolve = d.n_ldlsolve;
+        o.n_sweep = d.n_sweep; o.reserved_ = 0; o.solve_us = d.solve_us;
     }
     return EICOS_OK;
 }
@@ -911,7 +916,7 @@ int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     o->inst_bytes = h->dp.inst_stride * sizeof(double); o->work_bytes = h->dp.work_stride * sizeof(double);
     o->pattern_bytes = h->pattern_ints * sizeof(int);
     o->threads_per_block = h->threads; o->resident_blocks = h->grid; o->lds_bytes = (int)h->dyn_lds; o->instances_per_block = 1;
-    o->lds_resident = h->ldsres; o->factor_path = h->sym.tile;
+    o->lds_resident = h->ldsres; o->factor_path = h->sym.tile; o->cone_order = h->sym.cone_order; o->dual_rhs = h->dp.dual;
     return EICOS_OK;
 }
 

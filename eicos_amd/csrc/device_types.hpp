@@ -23,9 +23,11 @@ struct DevInfo {
     double pcost, dcost, pres, dres, gap, relgap, sigma, mu, step, step_aff, kapovert;
     double pinfres, dinfres, tau, kap, cx, by, hz;
     int has_relgap, has_pinfres, has_dinfres, pinf, dinf;
-    int iter, nitref1, nitref2, nitref3, exitcode, n_factor, n_ldlsolve, equilibrated, pad_;
+    int iter, nitref1, nitref2, nitref3, exitcode, n_factor, n_ldlsolve, equilibrated;
+    int n_sweep;     // passes over the factor L in the last solve: = n_ldlsolve, except that a dual right-hand-side solve counts once for both
+    double solve_us; // wall time this instance's workgroup spent on the last solve (100 MHz counter), for the launch's tail statistics
 };
-static_assert(sizeof(DevInfo) == 200, "DevInfo layout");
+static_assert(sizeof(DevInfo) == 208, "DevInfo layout");
 constexpr int DEVINFO_DOUBLES = 32;
 
 // One slice of a sliced-ELL triangular-solve plan: `cnt` consecutive rows (or columns) of L

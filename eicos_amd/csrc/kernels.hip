@@ -817,8 +817,8 @@ __device__ __forceinline__ bool dev_better_than() {
            (a.kapovert > 0. && a.kapovert < o.kapovert) && mu_ok;
 }
 __device__ __forceinline__ void restore_scalars() { // w = w_best (scalars), counters kept
-    const int nf = g_S.wi.n_factor, ns = g_S.wi.n_ldlsolve;
-    g_S.wi = g_S.bi; g_S.wi.n_factor = nf; g_S.wi.n_ldlsolve = ns;
+    const int nf = g_S.wi.n_factor, ns = g_S.wi.n_ldlsolve, nw = g_S.wi.n_sweep;
+    g_S.wi = g_S.bi; g_S.wi.n_factor = nf; g_S.wi.n_ldlsolve = ns; g_S.wi.n_sweep = nw;
 }
 
 // Slice table `which` of the current pattern: the LDS copy (NLDS >= 1) or the one in global memory.
@@ -1776,6 +1776,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
         if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < KI; k++) if (!rdone[k]) state(k).wi.n_ldlsolve++;
+            g_S.wi.n_sweep++; // (one pass over L, whatever the number of right-hand sides)
         }
 #pragma unroll
         for (int k = 0; k < KI; k++) if (!rdone[k]) kcnt[k]++;
@@ -2157,7 +2158,7 @@ __device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double wa
             wi = *ginfo; g_S.bi = wi;
             // warm start (N3, not in the reference): needs a previous OPTIMAL solve of this instance
             g_S.fl[FL_WARM] = (warm > 0. && wi.n_factor > 0 && (wi.exitcode == 0 || wi.exitcode == 10)) ? 1 : 0;
-            wi.n_factor = 0; wi.n_ldlsolve = 0;
+            wi.n_factor = 0; wi.n_ldlsolve = 0; wi.n_sweep = 0;
             g_S.fl[FL_FATAL] = 0; g_S.fl[FL_CODE] = -7; g_S.done = 0; g_S.kref = 0;
             g_S.cur = 0; g_S.best = -1; // the iterate starts in the instance slab (warm start: the previous solution is there), no best iterate yet
             for (int q = 0; q < 12; q++) g_S.tick[q] = 0;
@@ -2241,6 +2242,7 @@ __device__ __forceinline__ void instance_end(const DevPat &P, gdbl_p I, gdbl_p W
     if (threadIdx.x == 0) {
         DevInfo &wi = g_S.wi;
         wi.exitcode = g_S.fl[FL_FATAL] ? -7 : g_S.fl[FL_CODE];
+        wi.solve_us = (double)(wall_clock64() - g_S.tick[7]) * 0.01;
         *(DevInfo *)(I + P.i_info) = wi;
         // phase timers (microseconds) into the last row of the trace buffer: factor, LDL solves, refinement
         // residuals, KKT post-processing, residual/statistics/scalings stage, forward part of the solves, [6] total

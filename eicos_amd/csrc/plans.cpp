@@ -76,10 +76,13 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
             first = false;
         }
     };
-    auto pad = [&]() { // empty slices: no loop tail in the kernel's software pipeline (trips of TRI_TRIP slices, remainder in trips of TRI_DEPTH)
-        while (pl.sl.size() % TRI_DEPTH) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0});
-    };
-    auto pad_solo = [&]() { while (pl.sl.size() % TRI_DEPTH_SOLO) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); };
+    // empty slices: no loop tail in the kernel's software pipeline (trips of TRI_TRIP slices, remainder in trips of the queue depth).  Every
+    // SECTION of a plan (wide / solo / ext: each is walked by its own tri_sweep call) is padded to a multiple of ITS queue depth, counted
+    // from the section's first slice -- the two depths need not divide each other
+    size_t sec0 = 0;
+    auto pad_to = [&](int depth) { while ((pl.sl.size() - sec0) % depth) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); sec0 = pl.sl.size(); };
+    auto pad = [&]() { pad_to(TRI_DEPTH); };
+    auto pad_solo = [&]() { pad_to(TRI_DEPTH_SOLO); };
     // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
     const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
     int vs = nlev;

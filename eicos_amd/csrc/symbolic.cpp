@@ -218,6 +218,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     // rows first -> 140..157 x the DINF certificate the reference's test asserts, the CPU oracle: 182).
     ivec hold;
     if (S.nc > 0 && cone_order) {
+        S.cone_order = 1;
         hold.assign(N, -1);
         int k0 = S.n + S.p + S.l;
         for (int c = 0; c < S.nc; c++) {

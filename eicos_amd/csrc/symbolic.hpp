@@ -52,6 +52,7 @@ struct Symbolic {
     double flops_factor = 0;            // 2*npairs + divisions
     int max_row_len = 0, max_col_len = 0;
     int order_mode = 0;                 // slack+1 actually used
+    int cone_order = 0;                 // 1: ordered with the constraint "cone rows -> v -> u" for every second-order cone (analyze_mode)
     // ---- tile mode (patterns with dense fronts; tiles.hpp): the elimination order is an etree postorder cut into
     // blocks of <= 16 consecutive nodes aligned with the supernodes, blocks renumbered by block level.  L is then a
     // block-sparse matrix of dense 16 x 16 tiles; the scalar factor program (tp/pa/pb/pk, ftask) is not built.

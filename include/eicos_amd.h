@@ -52,6 +52,11 @@ typedef struct eicos_info {
     int iter, nitref1, nitref2, nitref3, exitcode;
     int n_factor;   /* numeric LDL' factorisations in the last solve (1 + completed passes) */
     int n_ldlsolve; /* LDL' solves in the last solve (incl. refinement solves)             */
+    int n_sweep;    /* passes over the factor L in the last solve: = n_ldlsolve, except that a solve of two right-hand
+                     * sides at once (eicos_dims.dual_rhs) counts one pass for both                  */
+    int reserved_;
+    double solve_us; /* device wall time of this instance's last solve (its workgroup, microseconds): max / p95 over the batch
+                      * against eicos_batch_last_solve_ms shows how much of a launch is its slowest instances */
 } eicos_info;
 
 /* Pattern / size report of a handle (for byte accounting and tests). */
@@ -65,6 +70,9 @@ typedef struct eicos_dims {
     int instances_per_block; /* always 1 (field kept for ABI stability: the lock-step pairs of round 2 were measured slower and removed) */
     int lds_resident; /* 1: small pattern, the solve works on LDS copies of the instance's slabs (lds_bytes includes them) */
     int factor_path;  /* 0 scalar level-scheduled program, 1 dense 16x16 tiles (MFMA), 2 hybrid: tiles for the top of the tree */
+    int cone_order;   /* 1: the two expansion columns of every second-order cone are eliminated after the cone's own rows (the
+                       * numerically preferable order, csrc/symbolic.cpp); 0: unconstrained minimum degree (or no cones) */
+    int dual_rhs;     /* 1: the two independent KKT systems of the initialisation and of every pass are solved in one sweep */
 } eicos_dims;
 
 /* ---- construction: replaces Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)

@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_NATIVE = None
 
 
 class OracleInfo(C.Structure):
@@ -32,6 +33,37 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
+
+
+def build_native() -> str | None:
+    """The same oracle compiled on THIS machine with the reference's Release flags (`-O2 -march=native`, reference
+    CMakeLists.txt:22) -- used by bench.py's cpu_baseline leg for the timing only.  Built where it runs (a -march=native
+    object must not travel between machines: liboracle_native.so is git- and gpurun-ignored); None if the compiler is missing."""
+    so = os.path.join(_HERE, "liboracle_native.so")
+    src = os.path.join(_HERE, "eicos_oracle.cpp")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return so
+
+
+def _prototype_batch(L):
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.oracle_batch_solve.restype = C.c_double
+    L.oracle_batch_solve.argtypes = [C.c_int] * 4 + [ip] * 5 + [C.c_int] + [dp] * 5 + [C.c_int, ip, ip, dp, dp, dp,
+                                                                              C.POINTER(C.c_longlong)]
+    return L
+
+
+def lib_native():
+    """liboracle_native.so (only oracle_batch_solve is prototyped), or None when it cannot be built here."""
+    global _LIB_NATIVE
+    if _LIB_NATIVE is None:
+        so = build_native()
+        _LIB_NATIVE = _prototype_batch(C.CDLL(so)) if so else False
+    return _LIB_NATIVE or None
 
 
 def lib():
@@ -163,9 +195,10 @@ class OracleSolver:
             pass
 
 
-def batch_solve(pat, Gpr, Apr, c, h, b, nthreads: int, want_x: bool = False):
-    """CPU baseline: arrays [B][...]; returns dict with wall seconds of the solve phase."""
-    L = lib()
+def batch_solve(pat, Gpr, Apr, c, h, b, nthreads: int, want_x: bool = False, native: bool = False):
+    """CPU baseline: arrays [B][...]; returns dict with wall seconds of the solve phase.
+    native=True: run the `-O2 -march=native` build of the same source (build_native) when it is available."""
+    L = (lib_native() if native else None) or lib()
     B = c.shape[0] if pat.n else h.shape[0]
     Gpr, Apr, c, h, b = (np.ascontiguousarray(a, dtype=np.float64) for a in (Gpr, Apr, c, h, b))
     q = np.ascontiguousarray(pat.q.astype(np.int32))
@@ -180,4 +213,4 @@ def batch_solve(pat, Gpr, Apr, c, h, b, nthreads: int, want_x: bool = False):
                                 _ip(pat.Air), B, dpn(Gpr), dpn(Apr), dpn(c), dpn(h), dpn(b), nthreads, _ip(ex), _ip(it),
                                 dpn(pc), dpn(xo) if want_x else None, C.byref(upd), C.byref(ns))
     return dict(seconds=wall, update_seconds=upd.value, exitcodes=ex, iters=it, pcost=pc, x=xo,
-                ldlsolves=int(ns.value))
+                ldlsolves=int(ns.value), native=bool(native and L is not lib()))
