@@ -100,6 +100,26 @@ def _lib():
         for f in ("create", "update", "update_device", "solve", "solve_async", "sync", "solution", "duals", "info",
                   "solution_device", "dims", "set_stream", "last_solve_ms", "last_update_ms", "destroy"):
             getattr(L, "eicos_batch_" + f).restype = C.c_int
+        # multi-GPU layer (one process, several devices)
+        L.eicos_multi_last_error.restype = C.c_char_p
+        L.eicos_multi_create.argtypes = [C.c_int] * 5 + [ip] * 5 + [C.c_int, ip, C.c_int, C.POINTER(vp)]
+        L.eicos_multi_update.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+        L.eicos_multi_update_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.eicos_multi_solve.argtypes = [vp, ip]
+        L.eicos_multi_solve_async.argtypes = [vp]
+        L.eicos_multi_sync.argtypes = [vp]
+        L.eicos_multi_solution.argtypes = [vp, dp]
+        L.eicos_multi_duals.argtypes = [vp, dp, dp, dp]
+        L.eicos_multi_info.argtypes = [vp, C.POINTER(Info)]
+        L.eicos_multi_set_warm_start.argtypes = [vp, C.c_double]
+        L.eicos_multi_set_dynamic_regularization.argtypes = [vp, C.c_double, C.c_double]
+        L.eicos_multi_num_shards.argtypes = [vp]
+        L.eicos_multi_shard.argtypes = [vp, C.c_int, C.POINTER(vp), ip, ip, ip]
+        L.eicos_multi_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.eicos_multi_destroy.argtypes = [vp]
+        for f in ("create", "update", "update_device", "solve", "solve_async", "sync", "solution", "duals", "info", "set_warm_start",
+                  "set_dynamic_regularization", "num_shards", "shard", "last_solve_ms", "destroy"):
+            getattr(L, "eicos_multi_" + f).restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -271,6 +291,112 @@ class BatchSolver:
     def close(self):
         if getattr(self, "_h", None):
             _lib().eicos_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _mchk(rc):
+    if rc != 0:
+        raise RuntimeError(f"eicos_amd error {rc}: {_lib().eicos_multi_last_error().decode()}")
+
+
+class MultiBatchSolver:
+    """One sparsity pattern, `batch` instances in contiguous shards over `device_ids` (eicos_multi_* of include/eicos_amd.h):
+    ONE process drives every listed GPU, one handle + stream per list entry, no collective.  Arrays are [batch, ...] in global
+    instance order; a device may be listed more than once (its shards run concurrently on that GPU)."""
+
+    def __init__(self, pat, batch: int, device_ids):
+        L = _lib()
+        self.pat, self.batch = pat, int(batch)
+        self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (pat.q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)]
+        q, Gjc, Gir, Ajc, Air = self._keep
+        dev = np.ascontiguousarray(device_ids, dtype=np.int32)
+        h = C.c_void_p()
+        _mchk(L.eicos_multi_create(pat.n, pat.m, pat.p, pat.l, pat.ncones, _ip(q) if pat.ncones else None,
+                                   _ip(Gjc) if pat.m > 0 else None, _ip(Gir) if pat.m > 0 else None,
+                                   _ip(Ajc) if pat.p > 0 else None, _ip(Air) if pat.p > 0 else None,
+                                   self.batch, _ip(dev), len(dev), C.byref(h)))
+        self._h = h
+
+    def update(self, Gpr=None, Apr=None, c=None, h=None, b=None, first: int = 0, count: int | None = None):
+        """Host arrays shaped [count, ...]; None keeps the group (reference semantics)."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (Gpr, Apr, c, h, b)]
+        if count is None:
+            count = next((a.shape[0] for a in arrs if a is not None and a.ndim == 2), self.batch)
+        ptr = [(_dp(a) if (a is not None and a.size) else (_dp(np.zeros(1)) if a is not None else None)) for a in arrs]
+        _mchk(_lib().eicos_multi_update(self._h, first, count, *ptr))
+
+    def update_device(self, src_device: int, dG=0, dA=0, dc=0, dh=0, db=0, first: int = 0, count: int | None = None):
+        """Raw pointers into the HBM of GPU `src_device` (arrays [count, ...]); 0 keeps the group."""
+        count = self.batch if count is None else count
+        _mchk(_lib().eicos_multi_update_device(self._h, int(src_device), first, count, *[C.c_void_p(int(p) or None) for p in (dG, dA, dc, dh, db)]))
+
+    def solve(self):
+        codes = np.zeros(self.batch, np.int32)
+        _mchk(_lib().eicos_multi_solve(self._h, _ip(codes)))
+        return codes
+
+    def solve_async(self):
+        _mchk(_lib().eicos_multi_solve_async(self._h))
+
+    def sync(self):
+        _mchk(_lib().eicos_multi_sync(self._h))
+
+    def solution(self):
+        x = np.zeros((self.batch, self.pat.n))
+        if self.pat.n:
+            _mchk(_lib().eicos_multi_solution(self._h, _dp(x)))
+        return x
+
+    def duals(self):
+        pat = self.pat
+        y, z, s = np.zeros((self.batch, pat.p)), np.zeros((self.batch, pat.m)), np.zeros((self.batch, pat.m))
+        _mchk(_lib().eicos_multi_duals(self._h, _dp(y) if pat.p else None, _dp(z) if pat.m else None, _dp(s) if pat.m else None))
+        return y, z, s
+
+    def info_arrays(self):
+        arr = (Info * self.batch)()
+        _mchk(_lib().eicos_multi_info(self._h, arr))
+        raw = np.frombuffer(arr, dtype=np.dtype([(k, "f8" if t is C.c_double else "i4") for k, t in Info._fields_]))
+        return {k: raw[k].copy() for k in raw.dtype.names}
+
+    def shards(self):
+        """[(first, count, device)] of every shard."""
+        out = []
+        for s in range(_lib().eicos_multi_num_shards(self._h)):
+            hh, f, c, d = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+            _mchk(_lib().eicos_multi_shard(self._h, s, C.byref(hh), C.byref(f), C.byref(c), C.byref(d)))
+            out.append((f.value, c.value, d.value))
+        return out
+
+    def shard_dims(self, s: int = 0) -> dict:
+        hh = C.c_void_p()
+        _mchk(_lib().eicos_multi_shard(self._h, s, C.byref(hh), None, None, None))
+        d = Dims()
+        _chk(_lib().eicos_batch_dims(hh, C.byref(d)))
+        return d.asdict()
+
+    def last_solve_ms(self):
+        """(max over the shards, [per shard]) of the most recent solve's HIP-event duration."""
+        n = _lib().eicos_multi_num_shards(self._h)
+        mx, per = C.c_float(), (C.c_float * n)()
+        _mchk(_lib().eicos_multi_last_solve_ms(self._h, C.byref(mx), per))
+        return float(mx.value), [float(v) for v in per]
+
+    def set_warm_start(self, shift: float):
+        _mchk(_lib().eicos_multi_set_warm_start(self._h, float(shift)))
+
+    def set_dynamic_regularization(self, delta: float, eps: float):
+        _mchk(_lib().eicos_multi_set_dynamic_regularization(self._h, float(delta), float(eps)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().eicos_multi_destroy(self._h)
             self._h = None
 
     def __del__(self):

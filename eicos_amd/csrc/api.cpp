@@ -520,6 +520,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return bail(EICOS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+    // (device set-up -- kernel attributes, occupancy probes, allocations, the constant-memory slot -- one handle at a time: the shards
+    // of an eicos_multi are created on parallel host threads, which overlaps their symbolic analyses above)
+    static std::mutex g_create_mu;
+    std::lock_guard<std::mutex> create_lock(g_create_mu);
     HIP_TRY_H(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY_H(hipGetDeviceProperties(&prop, device));
@@ -765,8 +769,10 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     return EICOS_OK;
 }
 
-int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, const double *A,
-                       const double *c, const double *hh, const double *b) {
+// updateData from buffers that are not on the handle's device: host memory (src_dev < 0) or the HBM of another GPU (src_dev = that
+// device: peer copies over xGMI, eicos_multi_update_device) -- staged through the handle's persistent buffer in chunks of 256 instances
+int eicos_internal_update_staged(eicos_batch *h, int first, int count, const double *G, const double *A,
+                                 const double *c, const double *hh, const double *b, int src_dev) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     if (first < 0 || count < 0 || first + count > h->batch) return fail(EICOS_E_INVALID, "instance range out of bounds");
     const DevPat &D = h->dp;
@@ -793,6 +799,7 @@ int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, co
         double *dh = dc + (size_t)cnt * D.n + 8, *db = dh + (size_t)cnt * D.m + 8;
         auto up = [&](double *dst, const double *src, size_t w) -> hipError_t {
             if (!src || w == 0) return hipSuccess;
+            if (src_dev >= 0) return hipMemcpyPeerAsync(dst, h->device, src + (size_t)o * w, src_dev, (size_t)cnt * w * sizeof(double), h->stream);
             return hipMemcpyAsync(dst, src + (size_t)o * w, (size_t)cnt * w * sizeof(double), hipMemcpyHostToDevice, h->stream);
         };
         hipError_t e = up(dG, G, D.nnzG);
@@ -809,6 +816,11 @@ int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, co
     h->in_chunked_update = false;
     if (rc == EICOS_OK) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
     return rc;
+}
+
+int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, const double *A,
+                       const double *c, const double *hh, const double *b) {
+    return eicos_internal_update_staged(h, first, count, G, A, c, hh, b, -1);
 }
 
 int eicos_batch_solve_async(eicos_batch *h) {
@@ -906,6 +918,8 @@ int eicos_batch_kernel_build(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     return h->ldsres ? 1 : (h->w2 ? 2 : 0);
 }
+
+int eicos_internal_device(const eicos_batch *h) { return h ? h->device : -1; }
 
 int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     if (!h || !o) return fail(EICOS_E_INVALID, "NULL argument");

@@ -2732,8 +2732,11 @@ hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int
 }
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds) {
     if (dyn_lds == 0) return hipSuccess;
+    // The attribute belongs to the kernel, not to a handle: several live handles (other patterns, the shards of an eicos_multi on one
+    // device) launch the same instantiation with different dynamic LDS sizes, so it is always raised to the device's ceiling (160 KB
+    // minus the 4 KB budgeted for the static block) and never lowered; the size a launch really uses is its own dyn_lds.
     return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     });
 }
 

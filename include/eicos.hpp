@@ -103,62 +103,86 @@ namespace EiCOS
         }
     }
 
-    // Batched engine: one pattern, `batch` instances.  Arrays are [batch][...] row-major.
+    // Batched engine: one pattern, `batch` instances.  Arrays are [batch][...] row-major in global instance order.
+    // One GPU (device, -1 = current) or several: with a list of device ids the batch is cut into contiguous shards, one per
+    // list entry, solved concurrently (eicos_multi_* of eicos_amd.h; a device may be listed more than once).
     class BatchSolver
     {
     public:
         BatchSolver(int n, int m, int p, int ncones, const int *q,
                     const int *Gjc, const int *Gir, const int *Ajc, const int *Air, int batch, int device = -1)
+            : BatchSolver(n, m, p, ncones, q, Gjc, Gir, Ajc, Air, batch, std::vector<int>{device}) {}
+        BatchSolver(int n, int m, int p, int ncones, const int *q,
+                    const int *Gjc, const int *Gir, const int *Ajc, const int *Air, int batch, const std::vector<int> &device_ids)
             : n_(n), m_(m), p_(p), batch_(batch)
         {
-            detail::check(eicos_batch_create(n, m, p, -1, ncones, q, Gjc, Gir, Ajc, Air, batch, device, &h_), "eicos_batch_create");
-            eicos_dims d; eicos_batch_dims(h_, &d);
+            mcheck(eicos_multi_create(n, m, p, -1, ncones, q, Gjc, Gir, Ajc, Air, batch, device_ids.data(), (int)device_ids.size(), &h_), "eicos_multi_create");
+            eicos_dims d; eicos_batch_dims(handle(), &d);
             n_ = d.n; m_ = d.m; p_ = d.p;
         }
         BatchSolver(const BatchSolver &) = delete;
         BatchSolver &operator=(const BatchSolver &) = delete;
-        ~BatchSolver() { eicos_batch_destroy(h_); }
+        ~BatchSolver() { eicos_multi_destroy(h_); }
 
         void updateData(const double *Gpr, const double *Apr, const double *c, const double *h, const double *b,
                         int first = 0, int count = -1)
         {
-            detail::check(eicos_batch_update(h_, first, count < 0 ? batch_ : count, Gpr, Apr, c, h, b), "eicos_batch_update");
+            mcheck(eicos_multi_update(h_, first, count < 0 ? batch_ : count, Gpr, Apr, c, h, b), "eicos_multi_update");
+        }
+        // inputs already resident in the HBM of GPU `src_device`: no PCIe traffic; shards on other GPUs pull their rows over xGMI
+        void updateDataDevice(int src_device, const double *dGpr, const double *dApr, const double *dc, const double *dh, const double *db,
+                              int first = 0, int count = -1)
+        {
+            mcheck(eicos_multi_update_device(h_, src_device, first, count < 0 ? batch_ : count, dGpr, dApr, dc, dh, db), "eicos_multi_update_device");
         }
         // Extension (not in the reference): re-solves start from the previous solution, see eicos_amd.h
-        void setWarmStart(double shift) { detail::check(eicos_batch_set_warm_start(h_, shift), "eicos_batch_set_warm_start"); }
+        void setWarmStart(double shift) { mcheck(eicos_multi_set_warm_start(h_, shift), "eicos_multi_set_warm_start"); }
         // Extension: ECOS-style dynamic regularisation (the reference's Settings::delta / ::eps are never read)
         void setDynamicRegularization(double delta, double eps)
         {
-            detail::check(eicos_batch_set_dynamic_regularization(h_, delta, eps), "eicos_batch_set_dynamic_regularization");
+            mcheck(eicos_multi_set_dynamic_regularization(h_, delta, eps), "eicos_multi_set_dynamic_regularization");
         }
         std::vector<exitcode> solve()
         {
             std::vector<int> codes(batch_);
-            detail::check(eicos_batch_solve(h_, codes.data()), "eicos_batch_solve");
+            mcheck(eicos_multi_solve(h_, codes.data()), "eicos_multi_solve");
             std::vector<exitcode> out(batch_);
             for (int i = 0; i < batch_; i++) out[i] = static_cast<exitcode>(codes[i]);
             return out;
         }
+        void solveAsync() { mcheck(eicos_multi_solve_async(h_), "eicos_multi_solve_async"); } // enqueue on every shard's stream
+        void sync() { mcheck(eicos_multi_sync(h_), "eicos_multi_sync"); }
         std::vector<double> solution() const
         {
             std::vector<double> x((size_t)batch_ * n_);
-            if (n_ > 0) detail::check(eicos_batch_solution(h_, x.data()), "eicos_batch_solution");
+            if (n_ > 0) mcheck(eicos_multi_solution(h_, x.data()), "eicos_multi_solution");
             return x;
         }
         std::vector<Information> getInfo() const
         {
             std::vector<eicos_info> raw(batch_);
-            detail::check(eicos_batch_info(h_, raw.data()), "eicos_batch_info");
+            mcheck(eicos_multi_info(h_, raw.data()), "eicos_multi_info");
             std::vector<Information> out;
             for (auto &r : raw) out.push_back(Information::from(r));
             return out;
         }
         int batch() const { return batch_; }
         int n_var() const { return n_; }
-        eicos_batch *handle() const { return h_; }
+        int num_shards() const { return eicos_multi_num_shards(h_); }
+        eicos_batch *handle(int shard = 0) const
+        {
+            eicos_batch *b = nullptr;
+            mcheck(eicos_multi_shard(h_, shard, &b, nullptr, nullptr, nullptr), "eicos_multi_shard");
+            return b;
+        }
+        eicos_multi *multi_handle() const { return h_; }
 
     private:
-        eicos_batch *h_ = nullptr;
+        static void mcheck(int rc, const char *what)
+        {
+            if (rc != EICOS_OK) throw std::runtime_error(std::string(what) + ": " + eicos_multi_last_error());
+        }
+        eicos_multi *h_ = nullptr;
         int n_, m_, p_, batch_;
     };
 

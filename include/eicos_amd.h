@@ -15,7 +15,8 @@
  *
  * One handle = one sparsity pattern (G: m x n CSC, A: p x n CSC, cone sizes q) analysed once
  * on the host + `batch` numeric instances resident in HBM on one GPU.  Instances are
- * independent; a multi-GPU job creates one handle per rank with its shard of the batch.
+ * independent: several GPUs of one node are driven from ONE process through eicos_multi_* (below: contiguous shards, one handle
+ * and stream per device), or from one process per GPU with one handle each (bench.py --gpus N under torch.distributed).
  */
 #ifndef EICOS_AMD_H
 #define EICOS_AMD_H
@@ -163,6 +164,42 @@ int eicos_solve(eicos_batch *hd, int *exitcode);
 int eicos_solution(eicos_batch *hd, double *x);
 int eicos_info_get(eicos_batch *hd, eicos_info *info);
 int eicos_destroy(eicos_batch *hd);
+
+/* ---- multi-GPU (SURVEY.md 8b "eicos_batch_create(pattern, B, device_ids...)", 8e): ONE pattern, `batch` instances in contiguous
+ * shards over the listed devices -- shard s = instances [s*base + min(s, rem), ...) with base = batch / ndev, rem = batch % ndev, the
+ * first `rem` shards one instance longer.  Host C++ above the single-GPU entry points: one eicos_batch handle and one HIP stream per
+ * list entry, no collective on the data path (instances are independent), no torch / RCCL dependency.  The reference has no
+ * counterpart (EiCOS::Solver solves one problem on one core, include/eicos.hpp:137-163); every call mirrors its eicos_batch_*
+ * namesake over the whole batch, arrays [batch][...] row-major in GLOBAL instance order.  A device may be listed several times: its
+ * shards then run concurrently on separate streams of that GPU.  Errors: eicos_multi_last_error() (names the failing shard). */
+typedef struct eicos_multi eicos_multi; /* opaque */
+int eicos_multi_create(int n, int m, int p, int l, int ncones, const int *q,
+                       const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
+                       int batch, const int *device_ids, int ndev, eicos_multi **out);
+/* updateData from HOST arrays: every shard stages its rows over its own GPU's PCIe link, all shards in parallel (one host thread each) */
+int eicos_multi_update(eicos_multi *mh, int first, int count, const double *Gpr, const double *Apr,
+                       const double *c, const double *h, const double *b);
+/* updateData from arrays resident in the HBM of ONE GPU (src_device): shards on that GPU read them in place, the others pull their
+ * rows with peer copies (hipMemcpyPeerAsync: xGMI) on their own streams -- the "batch scatter" of north_star without a collective */
+int eicos_multi_update_device(eicos_multi *mh, int src_device, int first, int count, const double *dGpr, const double *dApr,
+                              const double *dc, const double *dh, const double *db);
+/* solve: async = enqueue every shard's kernels on its stream and return; sync waits for all; eicos_multi_solve = both (+ exit codes, may be NULL) */
+int eicos_multi_solve_async(eicos_multi *mh);
+int eicos_multi_sync(eicos_multi *mh);
+int eicos_multi_solve(eicos_multi *mh, int *exitcodes);
+/* results gathered into the caller's host arrays in global instance order (the "gather" of north_star: per-device copies) */
+int eicos_multi_solution(eicos_multi *mh, double *x);
+int eicos_multi_duals(eicos_multi *mh, double *y, double *z, double *s);
+int eicos_multi_info(eicos_multi *mh, eicos_info *info /* [batch] */);
+int eicos_multi_set_warm_start(eicos_multi *mh, double shift);
+int eicos_multi_set_dynamic_regularization(eicos_multi *mh, double delta, double eps);
+/* the shards: their number, and shard s's single-GPU handle (every eicos_batch_* call works on it), instance range and device */
+int eicos_multi_num_shards(eicos_multi *mh);
+int eicos_multi_shard(eicos_multi *mh, int s, eicos_batch **handle, int *first, int *count, int *device);
+/* HIP-event duration of the most recent solve of every shard (ms): the maximum, and optionally each ([num_shards]) */
+int eicos_multi_last_solve_ms(eicos_multi *mh, float *ms_max, float *per_shard);
+int eicos_multi_destroy(eicos_multi *mh);
+const char *eicos_multi_last_error(void);
 
 const char *eicos_last_error(void);
 /* number of visible HIP devices (0 when there is no GPU); never initialises a context */

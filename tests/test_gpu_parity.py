@@ -839,8 +839,9 @@ def test_bench_emits_the_contract_json_line():
     assert full["soc"]["cones"] == 332 and full["soc"]["roofline"]["bound"] == "hbm" and "refinement_vs_oracle" in full["soc"]
     # traffic is only quoted from a PMC summary of exactly this code + workload (none for batch 64) -> null
     assert r["traffic"] is None and s["traffic_ratio"] is None
-    # no dual right-hand-side solves on this workload: the two yardsticks coincide; the launch's tail is reported
-    assert abs(r["frac_dual"] - r["frac"]) < 1e-12 and s["inst_ms_max"] >= s["inst_ms_p95"] > 0
+    # a batch of 64 fits one workgroup per CU: the two independent KKT systems of a pass are solved as one dual solve, so the yardstick
+    # that charges the passes over L really made is the stricter one; the launch's tail is reported
+    assert 0 < r["frac_dual"] < r["frac"] and s["inst_ms_max"] >= s["inst_ms_p95"] > 0
     assert len(out.stdout.strip().splitlines()[-1]) < 6144
 
 
