@@ -95,7 +95,7 @@ def pmc_traffic(tag):
 class Job:
     """One workload on this rank's GPU: inputs resident in HBM, solver handle, step()."""
 
-    def __init__(self, args, pat, sets, first, B, local_rank, soc=False):
+    def __init__(self, args, pat, sets, first, B, local_rank, soc=False, multi_ids=None):
         import torch
         import eicos_amd
         from eicos_amd.generate import SEED, feasible_batch, mpc_soc_variant, perturbed_batch
@@ -104,6 +104,19 @@ class Job:
         self.base = sets[0]
         gen = perturbed_batch if args.perturb else feasible_batch
         self.data = gen(self.pat, sets[0], first, B, SEED)
+        self.multi = multi_ids
+        if multi_ids:
+            # --multi: ONE process drives every listed device through the product's own multi-GPU layer (eicos_multi_* of
+            # include/eicos_amd.h: contiguous shards, one handle + stream per list entry); every shard's inputs are resident in the
+            # HBM of ITS device before the timed region (no copy in a step)
+            self.solver = eicos_amd.MultiBatchSolver(self.pat, B, multi_ids)
+            self.shards = self.solver.shards()
+            self.sdevs = [{k: torch.from_numpy(v[f:f + c]).to(f"cuda:{dv}") for k, v in self.data.items()} for (f, c, dv) in self.shards]
+            self.devs = [self.sdevs[0]]
+            self.dims = self.solver.shard_dims(0)
+            self.dims["kernel_build"] = "per shard"
+            self.step_no = 0
+            return
         dev = f"cuda:{local_rank}"
         self.devs = [{k: torch.from_numpy(v).to(dev) for k, v in self.data.items()}]
         if args.resolve > 0:
@@ -120,6 +133,13 @@ class Job:
             self.solver.set_warm_start(args.warm)
 
     def step(self):
+        if self.multi:
+            for s, d in enumerate(self.sdevs):
+                ptr = lambda k: d[k].data_ptr() if d[k].numel() else 0
+                self.solver.shard_update_device(s, ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))
+            self.solver.solve_async()  # every shard's kernels are enqueued on its own stream before any is waited for
+            self.step_no += 1
+            return
         d = self.devs[self.step_no % len(self.devs)]
         ptr = lambda k: d[k].data_ptr() if d[k].numel() else 0
         self.solver.update_device(ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))
@@ -134,7 +154,8 @@ class Job:
             if dist is not None:
                 dist.barrier()
             self.solver.sync()
-            torch.cuda.synchronize()
+            for dv in (sorted(set(self.multi)) if self.multi else [None]):
+                torch.cuda.synchronize(dv)
 
         # one untimed parity step first: the counters of every instance's FIRST solve are what the CPU sample is compared
         # with (the reference's pinfres / dinfres are sticky across solve() calls on one object -- SURVEY App. A.2 -- so an
@@ -150,8 +171,11 @@ class Job:
         for _ in range(steps):
             self.step()
             # per-launch kernel duration from HIP events recorded on the solver's own stream
-            kernel_ms.append(self.solver.last_solve_ms())
-            update_ms.append(self.solver.last_update_ms())
+            if self.multi:
+                kernel_ms.append(self.solver.last_solve_ms()[0]); update_ms.append(0.0)  # (slowest shard of the step)
+            else:
+                kernel_ms.append(self.solver.last_solve_ms())
+                update_ms.append(self.solver.last_update_ms())
         fence()
         dt = time.perf_counter() - t0
         ia = self.solver.info_arrays()
@@ -321,6 +345,9 @@ def main():
                     "nearby data (not the headline workload)")
     ap.add_argument("--warm", type=float, default=0.0, metavar="SHIFT", help="with --resolve: warm-start each solve from the "
                     "previous solution (extension, eicos_batch_set_warm_start); 0 = cold start as in the reference")
+    ap.add_argument("--multi", default=None, metavar="IDS", help="ONE process, several devices through the product's own multi-GPU layer "
+                    "(eicos_multi_* of include/eicos_amd.h; no torch.distributed): comma-separated device ids, one contiguous shard per entry; "
+                    "a device may be listed twice (0,0 = two concurrent shards on one GPU).  Default total: 4096 (1024 on one distinct device)")
     ap.add_argument("--io", choices=("local", "root"), default="local", help="local: every rank regenerates its own shard "
                     "(no collective, default); root: rank 0 holds the whole batch and scatters shards over RCCL/xGMI "
                     "before the timed region, results are gathered back after it (times reported in config)")
@@ -356,7 +383,14 @@ def main():
         pat, sets = eicos_amd.read_problem(path)
 
     # ---- which instances does this rank own? ----
-    if args.batch is not None:                       # weak: B per GPU
+    multi_ids = [int(t) for t in args.multi.split(",")] if args.multi else None
+    if multi_ids:
+        if world > 1:
+            raise SystemExit("--multi is the single-process multi-GPU path: do not launch it under torch.distributed.run")
+        ndist = len(set(multi_ids))
+        total = args.total if args.total is not None else (args.batch * len(multi_ids) if args.batch is not None else (1024 if ndist == 1 else TOTAL_STRONG))
+        B, first, scaling = total, 0, ("weak" if args.batch is not None else "strong")
+    elif args.batch is not None:                     # weak: B per GPU
         B, first, scaling, total = args.batch, rank * args.batch, "weak", args.batch * world
     else:                                            # strong: fixed total in contiguous shards
         total = args.total if args.total is not None else (1024 if world == 1 else TOTAL_STRONG)
@@ -364,7 +398,7 @@ def main():
         scaling = "strong"
     default_workload = args.pattern == "MPC02" and not args.perturb and args.resolve == 0
 
-    job = Job(args, pat, sets, first, B, local_rank, soc=args.soc)
+    job = Job(args, pat, sets, first, B, local_rank, soc=args.soc, multi_ids=multi_ids)
     io_ms = {}
     if args.io == "root" and dist is not None and world > 1:
         # the batch originates on rank 0's GPU: scatter the shards (outside the timed region: inputs are resident in
@@ -397,7 +431,7 @@ def main():
 
     # ---- the SOC variant of the same workload, timed the same way (its own solver handle; the LP one is released) ----
     soc_rep = None
-    if default_workload and not args.soc and not args.no_soc:
+    if default_workload and not args.soc and not args.no_soc and not multi_ids:
         main_rep = job.report(res, args.steps, f"MPC02 batch={B}") if rank == 0 else None
         cpu = job.cpu_baseline(job.ia_first) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
         job.solver.close()
@@ -427,7 +461,7 @@ def main():
         if soc_rep is not None:
             details["soc"] = soc_rep
             summary["soc"] = summarise(soc_rep)
-        if default_workload and world == 1 and not args.no_configs and not args.soc and args.batch is None and args.total is None:
+        if default_workload and world == 1 and not args.no_configs and not args.soc and args.batch is None and args.total is None and not multi_ids:
             # every other BASELINE.json config, driver-run: configs[4] dense-front (MFMA path), configs[3] LPnetlib (three of the
             # ten patterns: the smallest, a mid-size hybrid one, the deepest), the per-GPU share of configs[2] and north_star's
             # ">= 10x the host at batch 4096 on one GPU" configuration
@@ -442,17 +476,19 @@ def main():
                 summary[k] = summarise(v)
         out = {
             "metric": "ipm_iterations_per_sec", "value": value, "unit": unit,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": (len(set(multi_ids)) if multi_ids else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{total} instances total = {B}/GPU x {world} GPU ({scaling}), {args.pattern}{'-SOC' if args.soc else ''} pattern "
+            "config": {"workload": (f"{total} instances total in {len(multi_ids)} shard(s) over devices {sorted(set(multi_ids))} from one process ({scaling}), " if multi_ids else
+                                    f"{total} instances total = {B}/GPU x {world} GPU ({scaling}), ") + f"{args.pattern}{'-SOC' if args.soc else ''} pattern "
                                    f"(n={dims['n']} m={dims['m']} p={dims['p']} cones={dims['ncones']}), "
                                    f"{'perturbed (c,h)' if args.perturb else 'strictly feasible generated (c,h,b)'}, updateData+solve per step",
-                       "batch_per_gpu": B, "total_instances": total,
+                       "batch_per_gpu": (total // len(set(multi_ids)) if multi_ids else B), "total_instances": total,
                        "solves_per_sec": main_rep["solves_per_sec"], "optimal": main_rep["optimal"], "mean_iter": main_rep["mean_iter"],
                        "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"], "levels": dims["nlevels"],
                        "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"], "kernel_build": dims["kernel_build"],
                        "kernel_ms_min_over_ranks": main_rep["kernel_ms_min_over_ranks"], "kernel_ms_max_over_ranks": main_rep["kernel_ms_max_over_ranks"],
-                       "io": ("root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms,
+                       "io": (f"one process, eicos_multi_* over devices {multi_ids} (shards {job.shards}), inputs resident per shard" if multi_ids else
+                              "root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms,
                        **({"resolve_eps": args.resolve, "warm_shift": args.warm} if args.resolve > 0 else {}),
                        "summary": summary},
             "roofline": roof,

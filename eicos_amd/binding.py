@@ -374,6 +374,13 @@ class MultiBatchSolver:
             out.append((f.value, c.value, d.value))
         return out
 
+    def shard_update_device(self, s: int, dG=0, dA=0, dc=0, dh=0, db=0):
+        """updateData of shard s from raw pointers into the HBM of THAT shard's GPU (arrays [count of the shard, ...]): inputs resident
+        on every device -- no copy at all (eicos_batch_update_device on the shard's handle)."""
+        hh, c = C.c_void_p(), C.c_int()
+        _mchk(_lib().eicos_multi_shard(self._h, s, C.byref(hh), None, C.byref(c), None))
+        _chk(_lib().eicos_batch_update_device(hh, 0, c.value, *[C.c_void_p(int(p) or None) for p in (dG, dA, dc, dh, db)]))
+
     def shard_dims(self, s: int = 0) -> dict:
         hh = C.c_void_p()
         _mchk(_lib().eicos_multi_shard(self._h, s, C.byref(hh), None, None, None))

@@ -1376,6 +1376,24 @@ static double host_check_tiles_impl(int n, int m, int p, int ncones, const int *
 }
 
 
+// Host-only: the elimination order and block partition the tile path would use (perm[new] = KKT index, blk_ptr[nblk + 1]); returns the
+// number of blocks, < 0 on error.  Development aid for ordering studies (tools/dev), no GPU needed.
+int eicos_debug_host_tile_order(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
+                                const int *Ajc, const int *Air, int order_mode, int *perm, int *blk_ptr, int *stats) {
+    try {
+        ProblemPattern P;
+        P.n = n; P.m = m; P.p = p; P.nc = ncones; P.q.assign(q, q + ncones);
+        if (Gjc && Gir) { P.Gjc.assign(Gjc, Gjc + n + 1); P.Gir.assign(Gir, Gir + Gjc[n]); } else { P.Gjc.assign(n + 1, 0); P.m = 0; P.nc = 0; P.q.clear(); }
+        if (Ajc && Air) { P.Ajc.assign(Ajc, Ajc + n + 1); P.Air.assign(Air, Air + Ajc[n]); } else { P.Ajc.assign(n + 1, 0); P.p = 0; }
+        Symbolic S = analyze(P, order_mode, 1);
+        TilePlan TP = build_tile_plan(S);
+        if (perm) std::copy(S.perm.begin(), S.perm.end(), perm);
+        if (blk_ptr) std::copy(S.blk_ptr.begin(), S.blk_ptr.end(), blk_ptr);
+        if (stats) { stats[0] = S.N; stats[1] = S.nnzL; stats[2] = TP.nb; stats[3] = TP.nt; stats[4] = TP.nblev; stats[5] = (int)std::min<int64_t>(TP.npairs, 2147483647); stats[6] = S.order_mode; stats[7] = S.cone_order; }
+        return S.nblk;
+    } catch (const std::exception &e) { g_err = e.what(); return -2; }
+}
+
 double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
                                     const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats) {
     return host_check_tiles_impl(n, m, p, ncones, q, Gjc, Gir, Ajc, Air, seed, order_mode, stats, 1);

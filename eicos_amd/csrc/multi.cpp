@@ -8,6 +8,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -111,7 +113,11 @@ int eicos_multi_update_device(eicos_multi *mh, int src_device, int first, int co
     if (src_device < 0) return mfail(EICOS_E_INVALID, "src_device must name the GPU that holds the inputs");
     return for_range(mh, first, count, [&](int s, int f, int cnt, size_t off) {
         const double *G = at(dGpr, off, mh->nnzG), *A = at(dApr, off, mh->nnzA), *cc = at(dc, off, mh->n), *hh = at(dh, off, mh->m), *bb = at(db, off, mh->p);
-        if (mh->device[s] == src_device) return eicos_batch_update_device(mh->shard[s], f, cnt, G, A, cc, hh, bb); // already in this GPU's HBM: no copy
+        // (experiment knob, honoured like the others only under EICOS_EXPERIMENT=1: take the peer-copy path even on the source GPU, so
+        // that a single-GPU box exercises it -- hipMemcpyPeerAsync with equal devices is a device-to-device copy)
+        static const bool force_peer = [] { const char *e = std::getenv("EICOS_EXPERIMENT"), *k = std::getenv("EICOS_MULTI_FORCE_PEER");
+                                            return e && !std::strcmp(e, "1") && k && !std::strcmp(k, "1"); }();
+        if (mh->device[s] == src_device && !force_peer) return eicos_batch_update_device(mh->shard[s], f, cnt, G, A, cc, hh, bb); // already in this GPU's HBM: no copy
         return eicos_internal_update_staged(mh->shard[s], f, cnt, G, A, cc, hh, bb, src_device);                  // peer copies (xGMI), then the same kernel
     });
 }

@@ -298,11 +298,56 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
             if (ca.size() == cb.size() + 1 && !ca.empty() && ca[0] == b) return std::equal(cb.begin(), cb.end(), ca.begin() + 1);
             return false;
         };
-        ivec blk_start; // first node of every block
-        for (int k = 0, run = 0; k < N; k++) {
-            if (k == 0 || !joins(k - 1, k) || run == 16) { blk_start.push_back(k); run = 0; }
-            run++;
+        // Fundamental supernodes first (no size limit), then RELAXED AMALGAMATION of supernodes that are neighbours in the postorder,
+        // then every (merged) supernode is cut into blocks of 16.  Any partition into runs of consecutive nodes is correct for the tile
+        // code (tiles.cpp derives tiles, pairs and levels from the scalar pattern; structural zeros inside a tile are just zeros), so the
+        // partition is purely a cost choice, and the cost is what the kernels stream: off-diagonal tiles + diagonal tiles + level
+        // barriers.  Strict supernodes waste tiles on tiny supernodes -- on the dense-front config the v column of every cone (one node:
+        // 5 tiles at 1/16 fill, next to a 62-node supernode with the same row structure) and the 1..3-node supernodes at the top of
+        // the tree (variables shared by two cones): 59 of its 316 blocks, ~30 % of its 1120 tiles.  A boundary between two
+        // neighbouring supernodes is dropped when that lowers the cost (exact recount), greedily in elimination order.
+        ivec sn_start; // first node of every fundamental supernode
+        for (int k = 0; k < N; k++) if (k == 0 || !joins(k - 1, k)) sn_start.push_back(k);
+        auto cut16 = [&](const ivec &sn) { // supernode starts -> block starts (runs of <= 16 nodes inside every supernode)
+            ivec bs;
+            for (size_t s = 0; s < sn.size(); s++) {
+                const int a = sn[s], b = s + 1 < sn.size() ? sn[s + 1] : N;
+                for (int k = a; k < b; k += 16) bs.push_back(k);
+            }
+            return bs;
+        };
+        ivec blk_of(N), last_hit, lev_of;
+        auto cost_of = [&](const ivec &bs) { // tiles + blocks + 4 x block levels (= the tile path's cost model in analyze())
+            const int nbk = (int)bs.size();
+            for (int b = 0; b < nbk; b++) for (int k = bs[b]; k < (b + 1 < nbk ? bs[b + 1] : N); k++) blk_of[k] = b;
+            last_hit.assign(nbk, -1); lev_of.assign(nbk, 0);
+            long long nt = 0;
+            int maxlev = 0;
+            for (int j = 0; j < N; j++)
+                for (int i : cols[j]) { const int I = blk_of[i], J = blk_of[j]; if (I != J && last_hit[I] != J) { last_hit[I] = J; nt++; } }
+            for (int i = 0; i < N; i++)
+                for (int j : rows[i]) { const int I = blk_of[i], J = blk_of[j]; if (I != J && lev_of[I] <= lev_of[J]) { lev_of[I] = lev_of[J] + 1; maxlev = std::max(maxlev, lev_of[I]); } }
+            return (double)nt + (double)nbk + 4.0 * (maxlev + 1);
+        };
+        if (env_knob("EICOS_TILE_AMALG", 1, 0, 1)) {
+            double cur = cost_of(cut16(sn_start));
+            // a merge can only pay when it saves a block: ceil((a + b) / 16) < ceil(a / 16) + ceil(b / 16); the recounts are bounded
+            // (each is O(nnz(L))) so that huge patterns do not spend minutes here
+            long long nnz_rows = 0;
+            for (int i = 0; i < N; i++) nnz_rows += (long long)rows[i].size();
+            long long budget = std::min<long long>(4000, 3000000000LL / std::max<long long>(1, 2 * nnz_rows));
+            for (size_t s = 0; s + 1 < sn_start.size() && budget > 0;) {
+                const int a = sn_start[s + 1] - sn_start[s], b = (s + 2 < sn_start.size() ? sn_start[s + 2] : N) - sn_start[s + 1];
+                if ((a + b + 15) / 16 >= (a + 15) / 16 + (b + 15) / 16) { s++; continue; }
+                ivec trial(sn_start);
+                trial.erase(trial.begin() + s + 1);
+                const double c = cost_of(cut16(trial));
+                budget--;
+                if (c < cur) { cur = c; sn_start.swap(trial); } // merged: the same position now faces the next supernode
+                else s++;
+            }
         }
+        ivec blk_start = cut16(sn_start); // first node of every block
         const int nb = (int)blk_start.size();
         blk_start.push_back(N);
         ivec blk(N);

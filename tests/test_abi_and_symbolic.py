@@ -204,3 +204,23 @@ def test_tile_and_hybrid_plans_on_the_host():
         pat, _ = random_socp_pattern(40 + 10 * seed, 8, 12, [20, 3, 17], density=0.4, seed=seed)
         r, st = b.host_check_tiles(pat, seed=seed + 1)
         assert 0 <= r < 1e-12, (seed, r)
+
+
+def test_multi_gpu_layer_refuses_bad_arguments_and_has_no_cpu_fallback():
+    # eicos_multi_* (SURVEY.md 8b / 8e): argument checks run before any device is touched; without a GPU creation fails with
+    # EICOS_E_NOGPU like the single-GPU entry point (no CPU fallback anywhere)
+    import ctypes as C
+    import numpy as np
+    from eicos_amd.binding import _lib, _ip
+    pat, _ = load_fixture("lp_afiro")
+    L = _lib()
+    q, Gjc, Gir, Ajc, Air = [np.ascontiguousarray(a, dtype=np.int32) for a in (pat.q, pat.Gjc, pat.Gir, pat.Ajc, pat.Air)]
+    h = C.c_void_p()
+    dev = np.zeros(2, np.int32)
+    create = lambda batch, devs, nd: L.eicos_multi_create(pat.n, pat.m, pat.p, pat.l, 0, None, _ip(Gjc), _ip(Gir), _ip(Ajc), _ip(Air), batch, devs, nd, C.byref(h))
+    assert create(8, None, 2) == -1 and b"device" in L.eicos_multi_last_error()
+    assert create(8, _ip(dev), 0) == -1
+    assert create(1, _ip(dev), 2) == -1 and b"batch smaller" in L.eicos_multi_last_error()
+    if eicos_amd.device_count() == 0:
+        assert create(8, _ip(dev), 2) == -2 and b"no HIP device" in L.eicos_multi_last_error() and not h.value
+    assert L.eicos_multi_destroy(None) == 0 and L.eicos_multi_sync(None) == -1 and L.eicos_multi_num_shards(None) == -1
