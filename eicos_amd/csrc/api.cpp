@@ -429,6 +429,18 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     }
     put(D.cq, S.q); put(D.cone_off, S.cone_off); put(D.cone_vbase, cone_vbase); put(D.cone_small, cone_small); put(D.cone_big, cone_big);
     D.n_small = (int)cone_small.size(); D.n_big = (int)cone_big.size();
+    {   // tiny cones (dimension <= TINY_D): descriptor table for the register-resident cone loops; the rest of the small cones
+        std::vector<int> tiny_tab, cone_mid;
+        for (int c : cone_small) {
+            const int d = S.q[c], o = S.cone_off[c];
+            if (d > TINY_D) { cone_mid.push_back(c); continue; }
+            int rec[TINY_INTS] = {o, d, c, ipv[c], ipu[c], 0, 0, 0, 0, cone_vbase[c], 0, 0};
+            for (int k = 0; k < TINY_D; k++) rec[5 + k] = ipz[o + std::min(k, d - 1)]; // (slots past the dimension repeat the last row: loads stay in range)
+            tiny_tab.insert(tiny_tab.end(), rec, rec + TINY_INTS);
+        }
+        D.n_tiny = (int)tiny_tab.size() / TINY_INTS; D.n_mid = (int)cone_mid.size();
+        put(D.cone_tiny, tiny_tab); put(D.cone_mid, cone_mid);
+    }
     put(D.zdsign, zdsign);
     put(D.f_idx, planF.idx); put(D.b_idx, planB.idx);
     put(D.f_idx16, f_w16); put(D.b_idx16, b_w16); put(D.cag_k16, cag_k_w16); put(D.cag_yz16, cag_yz_w16);

@@ -110,6 +110,12 @@ struct DevPat {
     // cones
     gint_p cq, cone_off, cone_vbase, cone_small, cone_big;
     int n_small, n_big;
+    // "tiny" cones (dimension <= TINY_D): the hot per-cone loops keep a tiny cone's rows in registers, one thread per cone, all loads of
+    // a thread's cones issued up front (kernels.hip: for_tiny).  cone_tiny = TINY_INTS ints per tiny cone: first row o, dimension d, cone
+    // id c, elimination slot of its v and u expansion rows, elimination slots of its rows, first slot of its scaling block (cone_vbase);
+    // cone_mid = the other cones below CONE_BIG
+    gint_p cone_tiny, cone_mid;
+    int n_tiny, n_mid;
     gint_p zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
     // LDL' pattern, level ordered
     // triangular solves: sliced-ELL plans (see SliceMeta).  UF = unit-lower L in the forward (row) slot order,
@@ -197,7 +203,8 @@ constexpr int FOP_INIT = 1, FOP_END = 2, FOP_PAD = 4, FOP_SHIFT = 4; // tile fac
 constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each
-constexpr int CSC_STRIDE = 20;     // doubles of scaling state per cone
+constexpr int TINY_D = 4, TINY_INTS = 12; // tiny cones: dimension <= TINY_D (DevPat::cone_tiny)
+constexpr int CSC_STRIDE = 24;     // doubles of scaling state per cone: three 64-byte sectors, the committed scalars CS_* (what the per-solve cone loops read) fill the first
 // per-cone scaling scalars (reference struct SOCone, include/eicos.hpp:81-95): CS_* committed,
 // CN_* candidates of the current updateScalings pass (committed only if no earlier cone failed)
 enum { CS_A = 0, CS_D1, CS_W, CS_ETA, CS_ETA2, CS_U0, CS_U1, CS_V1,

@@ -292,6 +292,52 @@ __device__ __forceinline__ void for_cones(int ps, Body &&body) {
     for (int q = tid >> 6; q < P.n_big; q += T / 64) body(P.cone_big[q], std::integral_constant<int, 64>{}, tid & 63);
 }
 
+// The cones for_tiny does not cover (dimension > TINY_D): DevPat::cone_mid one thread each, cone_big one wavefront each.
+template <int T, class Body>
+__device__ __forceinline__ void for_cones_rest(int ps, Body &&body) {
+    const DevPat &P = c_pat[ps];
+    const int tid = threadIdx.x;
+    for (int q = tid; q < P.n_mid; q += T) body(P.cone_mid[q], std::integral_constant<int, 1>{}, 0);
+    for (int q = tid >> 6; q < P.n_big; q += T / 64) body(P.cone_big[q], std::integral_constant<int, 64>{}, tid & 63);
+}
+
+// Tiny cones (dimension <= TINY_D = 4: the 332 cones of dimension 3 of an MPC-SOC pattern), one thread per cone, REGISTER-RESIDENT:
+// `ld(t)` loads everything the cone's body reads (into a small struct), `fn(t, loaded)` does the arithmetic and the stores.  The
+// descriptors of a thread's U cones are loaded first, then all their data, then the bodies run: a generic per-cone body is a chain of
+// 4..6 dependent global loads (cone id -> first row / dimension -> elimination slots -> values, and a loop over the rows that the
+// compiler will not unroll), repeated for every round of T cones; here a pass over the cones costs two round trips.  The bodies
+// spell out the generic loops with the rows in registers, IN THE SAME ORDER of operations (results are bit-identical).
+typedef int ti4_t __attribute__((ext_vector_type(4)));
+struct Tiny { int o, d, c, ev, eu, ez[TINY_D], vb; }; // first row, dimension, cone id, elimination slots of v / u / the rows, first scaling-block slot
+__device__ __forceinline__ Tiny tiny_at(gint_p tab, int q) {
+    typedef const ti4_t EICOS_GLOBAL *gi4;
+    gi4 p = reinterpret_cast<gi4>(tab + (size_t)q * TINY_INTS);
+    const ti4_t a = p[0], b = p[1], c = p[2];
+    return Tiny{a.x, a.y, a.z, a.w, b.x, {b.y, b.z, b.w, c.x}, c.y};
+}
+template <int T, int U = 2, class L, class F>
+__device__ __forceinline__ void for_tiny(const DevPat &P, L &&ld, F &&fn) {
+    const int nt = P.n_tiny;
+    for (int q0 = threadIdx.x; q0 < nt; q0 += U * T) {
+        Tiny t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) t[u] = tiny_at(P.cone_tiny, min(q0 + u * T, nt - 1)); // (clamped: unconditional loads)
+        decltype(ld(t[0])) r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u] = ld(t[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) if (q0 + u * T < nt) fn(t[u], r[u]);
+    }
+}
+// the TINY_D consecutive doubles of array a at the rows of tiny cone t (indices past the dimension are clamped to the last row)
+struct D4 { double v[TINY_D]; };
+template <class Ptr> __device__ __forceinline__ D4 tiny_rows(Ptr a, const Tiny &t) {
+    D4 r;
+#pragma unroll
+    for (int k = 0; k < TINY_D; k++) r.v[k] = a[t.o + min(k, t.d - 1)];
+    return r;
+}
+
 #define FOR_T(i, cnt) for (int i = threadIdx.x; i < (cnt); i += T)
 
 // Elementwise pass over [0, cnt) whose global loads are issued U iterations at a time: `ld(i)` returns what
@@ -643,7 +689,18 @@ __device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out
     const DevPat &P = c_pat[ps];
     gcdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
     if constexpr (!CONES_ONLY) for_t_pre<T, 8>(P.l, [&](int i) { return V2{lpw[i], zz[i]}; }, [&](int i, const V2 &r) { out[i] = r.a * r.b; });
-    for_cones<T>(ps, [&](int c, auto G, int lane) {
+    struct SC { D4 z, q; double a, eta; };
+    for_tiny<T>(P, [&](const Tiny &t) { gcdbl_p cs = csc + t.c * CSC_STRIDE; return SC{tiny_rows(zz, t), tiny_rows(qv, t), cs[CS_A], cs[CS_ETA]}; },
+                [&](const Tiny &t, const SC &r) { // (the generic body below with the rows in registers)
+        double zeta = 0.;
+#pragma unroll
+        for (int k = 1; k < TINY_D; k++) if (k < t.d) zeta += r.q.v[k] * r.z.v[k];
+        const double z0 = r.z.v[0], factor = z0 + zeta / (1. + r.a);
+#pragma unroll
+        for (int k = 1; k < TINY_D; k++) if (k < t.d) out[t.o + k] = r.eta * (r.z.v[k] + factor * r.q.v[k]);
+        out[t.o] = r.eta * (r.a * z0 + zeta);
+    });
+    for_cones_rest<T>(ps, [&](int c, auto G, int lane) {
         constexpr int g = decltype(G)::value;
         const int o = P.cone_off[c], d = P.cq[c];
         gcdbl_p cs = csc + c * CSC_STRIDE;
@@ -722,7 +779,32 @@ __device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, do
         rn = grp_sum<g>(rn); sn = grp_sum<g>(sn);
         return fmax(0., fmax(sqrt(sn) - sig0, sqrt(rn) - rho0));
     };
-    for_cones<T>(ps, [&](int c, auto G, int lane) {
+    struct LS { D4 lam, ds, dz; };
+    for_tiny<T>(P, [&](const Tiny &t) { return LS{tiny_rows(lam, t), tiny_rows(ds, t), tiny_rows(dz, t)}; }, [&](const Tiny &t, const LS &r) {
+        // cone_step with the rows in registers (same operations in the same order)
+        const int d = t.d;
+        double l1 = 0.;
+#pragma unroll
+        for (int k = 1; k < TINY_D; k++) if (k < d) l1 += r.lam.v[k] * r.lam.v[k];
+        const double lknorm2 = r.lam.v[0] * r.lam.v[0] - l1;
+        if (lknorm2 <= 0.) { bad = 1.; return; }
+        const double lknorm = sqrt(lknorm2), inv = 1. / lknorm, lk0 = r.lam.v[0] / lknorm;
+        double ld = 0., lz = 0.;
+#pragma unroll
+        for (int k = 1; k < TINY_D; k++) if (k < d) { const double lb = r.lam.v[k] / lknorm; ld += lb * r.ds.v[k]; lz += lb * r.dz.v[k]; }
+        const double lds = lk0 * r.ds.v[0] - ld, ldz = lk0 * r.dz.v[0] - lz;
+        const double rho0 = inv * lds, fr = (lds + r.ds.v[0]) / (lk0 + 1.);
+        const double sig0 = inv * ldz, fs = (ldz + r.dz.v[0]) / (lk0 + 1.);
+        double rn = 0., sn = 0.;
+#pragma unroll
+        for (int k = 1; k < TINY_D; k++) if (k < d) {
+            const double lb = r.lam.v[k] / lknorm;
+            const double rr = inv * (r.ds.v[k] - fr * lb), ss = inv * (r.dz.v[k] - fs * lb);
+            rn += rr * rr; sn += ss * ss;
+        }
+        cstep = fmax(cstep, fmax(0., fmax(sqrt(sn) - sig0, sqrt(rn) - rho0)));
+    });
+    for_cones_rest<T>(ps, [&](int c, auto G, int lane) {
         bool sk;
         const double st = cone_step(P.cone_off[c], P.cq[c], G, lane, sk);
         if (sk) bad = 1.; else cstep = fmax(cstep, st);
@@ -1542,7 +1624,43 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     });
     double firstfail = 1e300;
     if (P.nc > 0) {
-        for_cones<T>(ps, [&](int c, auto G, int ln) { // phase 1: candidate scalings per cone
+        // tiny cones: both phases with the cone's rows in registers (same operations in the same order as the generic bodies below)
+        struct S1 { D4 s, z; };
+        for_tiny<T>(P, [&](const Tiny &t) { return S1{tiny_rows(wsl, t), tiny_rows(wz, t)}; }, [&](const Tiny &t, const S1 &r) {
+            const int d = t.d;
+            gdbl_p cs = csc + t.c * CSC_STRIDE;
+            double s1 = 0., z1 = 0.;
+#pragma unroll
+            for (int k = 1; k < TINY_D; k++) if (k < d) { s1 += r.s.v[k] * r.s.v[k]; z1 += r.z.v[k] * r.z.v[k]; }
+            const double s0 = r.s.v[0], z0 = r.z.v[0];
+            const double sres = s0 * s0 - s1, zres = z0 * z0 - z1;
+            bool fail = (sres <= 0. || zres <= 0.);
+            if (!fail) {
+                const double snorm = sqrt(sres), znorm = sqrt(zres);
+                double sz = 0., ww = 0.;
+#pragma unroll
+                for (int k = 0; k < TINY_D; k++) if (k < d) sz += (r.s.v[k] / snorm) * (r.z.v[k] / znorm);
+                const double gam = sqrt(0.5 * (1. + sz));
+                const double a = (0.5 / gam) * (s0 / snorm + z0 / znorm);
+#pragma unroll
+                for (int k = 1; k < TINY_D; k++) if (k < d) { const double qk = (0.5 / gam) * (r.s.v[k] / snorm - r.z.v[k] / znorm); ww += qk * qk; }
+                const double cc = (1. + a) + ww / (1. + a);
+                const double dd = 1. + 2. / (1. + a) + ww / ((1. + a) * (1. + a));
+                const double d1 = fmax(0., 0.5 * (a * a + ww * (1. - cc * cc / (1. + ww * dd))));
+                const double u0sq = a * a + ww - d1;
+                const double c2 = cc * cc / u0sq;
+                const bool late = (c2 - dd <= 0.);
+                if (late) fail = true;
+                cs[CN_ETA2] = snorm / znorm; cs[CN_SN] = snorm; cs[CN_ZN] = znorm; cs[CN_GAM] = gam;
+                cs[CN_MODE] = late ? 2. : 0.;
+                if (!late) {
+                    cs[CN_A] = a; cs[CN_D1] = d1; cs[CN_W] = ww;
+                    cs[CN_U0] = sqrt(u0sq); cs[CN_U1] = sqrt(c2); cs[CN_V1] = sqrt(c2 - dd);
+                }
+            } else cs[CN_MODE] = 1.;
+            if (fail) firstfail = fmin(firstfail, (double)t.c);
+        });
+        for_cones_rest<T>(ps, [&](int c, auto G, int ln) { // phase 1: candidate scalings per cone
             constexpr int g = decltype(G)::value;
             const int o = P.cone_off[c], d = P.cq[c];
             gdbl_p cs = csc + c * CSC_STRIDE;
@@ -1587,7 +1705,50 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
         // and updateKKTScalings (ref :1162, return value of updateScalings ignored) then writes whatever the structs
         // hold: for a cone that failed the LATE test that is the new eta^2 and q with the old d1, u0, u1, v1.
         firstfail = blk_reduce1<OpMin, T>(phase, firstfail);
-        for_cones<T>(ps, [&](int c, auto G, int ln) { // phase 2: commit + updateKKTScalings
+        {
+            constexpr int NVT = 3 * TINY_D + 1;
+            struct S2 { D4 s, z; double eta2, mode, sn, zn, gam, nA, nW, nD1, nU0, nU1, nV1, sD1, sU0, sU1, sV1; int vt[NVT]; };
+            constexpr int U2 = waves_per_eu<T>() <= 2 ? 2 : 1; // (~60 registers per cone in flight)
+            for_tiny<T, U2>(P, [&](const Tiny &t) {
+                S2 r;
+                gcdbl_p cs = csc + t.c * CSC_STRIDE;
+                r.s = tiny_rows(wsl, t); r.z = tiny_rows(wz, t);
+                r.eta2 = cs[CN_ETA2]; r.mode = cs[CN_MODE]; r.sn = cs[CN_SN]; r.zn = cs[CN_ZN]; r.gam = cs[CN_GAM];
+                r.nA = cs[CN_A]; r.nW = cs[CN_W]; r.nD1 = cs[CN_D1]; r.nU0 = cs[CN_U0]; r.nU1 = cs[CN_U1]; r.nV1 = cs[CN_V1];
+                r.sD1 = cs[CS_D1]; r.sU0 = cs[CS_U0]; r.sU1 = cs[CS_U1]; r.sV1 = cs[CS_V1];
+#pragma unroll
+                for (int j = 0; j < NVT; j++) r.vt[j] = P.v2t[t.vb + min(j, 3 * t.d)];
+                return r;
+            }, [&](const Tiny &t, const S2 &r) {
+                if ((double)t.c > firstfail) return;
+                const bool partial = ((double)t.c == firstfail);
+                if (partial && r.mode != 2.) return;
+                const int d = t.d, o = t.o;
+                gdbl_p cs = csc + t.c * CSC_STRIDE;
+                gdbl_p v = Vv + t.vb;
+                const double eta2 = r.eta2;
+                const double d1 = partial ? r.sD1 : r.nD1, u0 = partial ? r.sU0 : r.nU0, u1 = partial ? r.sU1 : r.nU1, v1 = partial ? r.sV1 : r.nV1;
+                const double snorm = r.sn, znorm = r.zn, gam = r.gam;
+                cs[CS_ETA2] = eta2; cs[CS_ETA] = sqrt(eta2);
+                if (!partial) { cs[CS_A] = r.nA; cs[CS_D1] = d1; cs[CS_W] = r.nW; cs[CS_U0] = u0; cs[CS_U1] = u1; cs[CS_V1] = v1; }
+                // (vt[j] = target of scaling-block slot j; d is runtime, so the slots d + k and 2 d + 1 + k are picked by compile-time loops)
+                auto vt_at = [&](int j) { int x = r.vt[0];
+#pragma unroll
+                    for (int q = 1; q < NVT; q++) x = (j == q) ? r.vt[q] : x;
+                    return x; };
+#pragma unroll
+                for (int k = 0; k < TINY_D; k++) if (k < d) {
+                    const double qk = (k >= 1) ? (0.5 / gam) * (r.s.v[k] / snorm - r.z.v[k] / znorm) : 0.;
+                    if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[vt_at(d + k)] = e; }
+                    const double e0 = (k == 0) ? -eta2 * d1 - DELTASTAT : -eta2 - DELTASTAT;
+                    const double e2 = (k == 0) ? -eta2 * u0 : -eta2 * u1 * qk;
+                    v[k] = e0; Kt[r.vt[k]] = e0;
+                    v[2 * d + 1 + k] = e2; Kt[vt_at(2 * d + 1 + k)] = e2;
+                }
+                v[d] = -eta2; Kt[vt_at(d)] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[vt_at(2 * d)] = eta2 + DELTASTAT;
+            });
+        }
+        for_cones_rest<T>(ps, [&](int c, auto G, int ln) { // phase 2: commit + updateKKTScalings
             constexpr int g = decltype(G)::value;
             if ((double)c > firstfail) return;
             const int o = P.cone_off[c], d = P.cq[c];
@@ -1819,7 +1980,40 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
             // cone blocks (expanded): ez += dz_true (init) or scale2add (ref :1629-1662)
 #pragma unroll
             for (int k = 0; k < KI; k++) {
-                for_cones<T>(ps, [&](int c, auto G, int ln) {
+                // tiny cones: the body below with the cone's rows in registers (for_tiny: descriptors, then every value, then the arithmetic)
+                struct RK { double e[TINY_D], x[TINY_D], q[TINY_D], x3, x4, eta2, v1, u1, d1, u0; };
+                for_tiny<T>(P, [&](const Tiny &t) {
+                    RK r;
+                    gcdbl_p cs = csc[k] + t.c * CSC_STRIDE;
+#pragma unroll
+                    for (int q = 0; q < TINY_D; q++) { r.e[q] = ldE(t.ez[q], k); r.x[q] = X[t.ez[q] * KI + k]; r.q[q] = qv[k][t.o + min(q, t.d - 1)]; }
+                    r.x3 = X[t.ev * KI + k]; r.x4 = X[t.eu * KI + k];
+                    r.eta2 = cs[CS_ETA2]; r.v1 = cs[CS_V1]; r.u1 = cs[CS_U1]; r.d1 = cs[CS_D1]; r.u0 = cs[CS_U0];
+                    return r;
+                }, [&](const Tiny &t, const RK &r) {
+                    double mx = 0.;
+                    if (init) {
+#pragma unroll
+                        for (int q = 0; q < TINY_D; q++) if (q < t.d) { const double v = r.e[q] + r.x[q]; stE(t.ez[q], k, v); mx = fmax(mx, fabs(v)); }
+                        stE(t.ev, k, r.x3); stE(t.eu, k, r.x4); mx = fmax(mx, fmax(fabs(r.x3), fabs(r.x4)));
+                    } else {
+                        const double tt = r.v1 * r.x3 + r.u1 * r.x4;
+                        double qtx = 0.;
+#pragma unroll
+                        for (int q = 1; q < TINY_D; q++) if (q < t.d) {
+                            const double v = r.e[q] + r.eta2 * (r.x[q] + tt * r.q[q]);
+                            stE(t.ez[q], k, v); mx = fmax(mx, fabs(v));
+                            qtx += r.q[q] * r.x[q];
+                        }
+                        const double v1 = r.e[0] + r.eta2 * (r.d1 * r.x[0] + r.u0 * r.x4);
+                        const double v3 = r.eta2 * (r.v1 * qtx + r.x3);
+                        const double v4 = r.eta2 * (r.u0 * r.x[0] + r.u1 * qtx - r.x4);
+                        stE(t.ez[0], k, v1); stE(t.ev, k, v3); stE(t.eu, k, v4);
+                        mx = fmax(mx, fmax(fabs(v1), fmax(fabs(v3), fabs(v4))));
+                    }
+                    nez[k] = fmax(nez[k], mx);
+                });
+                for_cones_rest<T>(ps, [&](int c, auto G, int ln) {
                     constexpr int g = decltype(G)::value;
                     const int d = P.cq[c], o = P.cone_off[c];
                     const int p1 = P.ipz[o] * KI + k, p3 = P.ipv[c] * KI + k, p4 = P.ipu[c] * KI + k;
@@ -2032,7 +2226,39 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
             rhs2k[np + i] = v;
         });
         if (P.nc > 0) {
-            for_cones<T>(ps, [&](int c, auto G, int ln) {
+            // tiny cones: both loops below in one register-resident pass (a cone belongs to one thread: no barrier between them; the
+            // ds1 tail t2 stays in registers)
+            struct RC4 { D4 lam, ds, wz, q; double a, eta; };
+            for_tiny<T>(P, [&](const Tiny &t) { gcdbl_p cs = csc + t.c * CSC_STRIDE; return RC4{tiny_rows(lam, t), tiny_rows(dsw, t), tiny_rows(wdz, t), tiny_rows(qv, t), cs[CS_A], cs[CS_ETA]}; },
+                        [&](const Tiny &t, const RC4 &r) {
+                const int d = t.d, o = t.o;
+                double ll = 0., dw = 0., u1sq = 0.;
+#pragma unroll
+                for (int k = 0; k < TINY_D; k++) if (k < d) { ll += r.lam.v[k] * r.lam.v[k]; dw += r.ds.v[k] * r.wz.v[k]; }
+                const double l0 = r.lam.v[0], a0 = r.ds.v[0], w0_ = r.wz.v[0];
+                const double p0 = ll - sigmamu + dw;
+                double zeta = 0., pk[TINY_D], nd[TINY_D];
+#pragma unroll
+                for (int k = 1; k < TINY_D; k++) if (k < d) {
+                    const double lk = r.lam.v[k];
+                    pk[k] = (l0 * lk + l0 * lk) + (a0 * r.wz.v[k] + w0_ * r.ds.v[k]);
+                    u1sq += lk * lk; zeta += lk * pk[k];
+                }
+                const double rho = l0 * l0 - u1sq;
+                const double factor = (zeta / l0 - p0) / rho;
+#pragma unroll
+                for (int k = 1; k < TINY_D; k++) if (k < d) { nd[k] = factor * r.lam.v[k] + pk[k] / l0; dsw[o + k] = nd[k]; }
+                nd[0] = (l0 * p0 - zeta) / rho; dsw[o] = nd[0];
+                // t1 = W * (lam \ ds) on the cone
+                double zeta2 = 0.;
+#pragma unroll
+                for (int k = 1; k < TINY_D; k++) if (k < d) zeta2 += r.q.v[k] * nd[k];
+                const double z0 = nd[0], factor2 = z0 + zeta2 / (1. + r.a);
+#pragma unroll
+                for (int k = 1; k < TINY_D; k++) if (k < d) t1[o + k] = r.eta * (nd[k] + factor2 * r.q.v[k]);
+                t1[o] = r.eta * (r.a * z0 + zeta2);
+            });
+            for_cones_rest<T>(ps, [&](int c, auto G, int ln) {
                 constexpr int g = decltype(G)::value;
                 const int o = P.cone_off[c], d = P.cq[c];
                 // conic products (ref :1357-1378): ds1 = lam o lam + dsw o wdz - sigmamu e
@@ -2056,7 +2282,7 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
                 if (ln == 0) dsw[o] = (l0 * p0 - zeta) / rho;
             });
             __syncthreads();
-            for_cones<T>(ps, [&](int c, auto G, int ln) { // t1 = W * (lam \ ds) on the cone part
+            for_cones_rest<T>(ps, [&](int c, auto G, int ln) { // t1 = W * (lam \ ds) on the cone part
                 constexpr int g = decltype(G)::value;
                 const int o = P.cone_off[c], d = P.cq[c];
                 gcdbl_p cs = csc + c * CSC_STRIDE;

@@ -758,7 +758,6 @@ def test_multi_gpu_layer_two_shards_on_one_device_bit_identical(monkeypatch):
     # and stream per shard).  A single-GPU box can exercise everything but the second device: device_ids = {0, 0} = two shards of 512 on
     # the one GPU, solved concurrently on two streams -- bit-identical to ONE handle on all 1024 MPC02 instances; inputs from host
     # arrays, from device arrays read in place, and through the peer-copy path (forced: hipMemcpyPeerAsync with equal devices)
-    import torch
     pat, sets = load_fixture("MPC02")
     B = 1024
     d = feasible_batch(pat, sets[0], 0, B)
@@ -792,8 +791,22 @@ def test_multi_gpu_layer_two_shards_on_one_device_bit_identical(monkeypatch):
     m.update(None, None, d["c"][500:524], None, None, first=500, count=24)
     assert np.all(m.solve() == 0) and np.array_equal(m.solution(), x1k)
     m.close()
-    dev = {k: torch.from_numpy(v).to("cuda:0") for k, v in d.items()}
-    ptr = lambda k: dev[k].data_ptr() if dev[k].numel() else 0
+    # device-resident inputs without torch: plain hipMalloc / hipMemcpy through the HIP runtime the library itself is linked against
+    import ctypes
+    from eicos_amd.binding import _lib
+    hip = _lib()  # (dlsym on the library's handle reaches its dependency libamdhip64: the SAME runtime instance the solver uses)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    dev = {}
+    for k, v in d.items():
+        pbuf = ctypes.c_void_p()
+        if v.size:
+            v = np.ascontiguousarray(v)
+            assert hip.hipMalloc(ctypes.byref(pbuf), v.nbytes) == 0
+            assert hip.hipMemcpy(pbuf, v.ctypes.data, v.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        dev[k] = pbuf.value or 0
+    ptr = lambda k: dev[k]
     m = eicos_amd.MultiBatchSolver(pat, B, [0, 0])
     m.update_device(0, ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))  # inputs resident on GPU 0: read in place by both shards
     check(m)
@@ -805,6 +818,9 @@ def test_multi_gpu_layer_two_shards_on_one_device_bit_identical(monkeypatch):
     codes = m.solve()
     assert np.array_equal(codes, codes1[:1000]) and np.array_equal(m.solution(), x1[:1000]) and np.array_equal(m.info_arrays()["iter"], ia1["iter"][:1000])
     m.close()
+    for pbuf in dev.values():
+        if pbuf:
+            hip.hipFree(ctypes.c_void_p(pbuf))
 
 
 def test_cpp_batch_solver_over_a_device_list(tmp_path):
