@@ -333,7 +333,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     {   // level 0 of the factor program: the leaves of the elimination tree have no pairs; the kernel streams over their targets
         // (diagonals first: the per-level task order is stable for equal pair counts) instead of walking their slices
         D.fac_s1 = 0; D.fac_nd0 = 0; D.fac_nt0 = 0;
-        if (!tile1 && !planX.sl.empty() && env_int("EICOS_FAC_L0", 1, 0, 1)) {
+        if (!tile1 && !planX.sl.empty()) {
             size_t s1 = 1;
             while (s1 < planX.sl.size() && !(planX.sl[s1].newlev & 1)) s1++;
             const int nt0 = s1 < planX.sl.size() ? planX.sl[s1].row0 : (int)planX.target.size();
@@ -556,7 +556,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             return std::min(wgs_by_regs, (int)((160 * 1024) / (vec + (size_t)slices * sizeof(PackedSlice) + scratch + lds_static)));
         };
         // the factor program's table goes to LDS too when it is small and does not cost a resident workgroup
-        if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total) && env_int("EICOS_FAC_LDS", 1, 0, 1)) {
+        if (D.fac_ns <= 512 && wgs_per_cu(D.lm_total + D.fac_ns) == wgs_per_cu(D.lm_total)) {
             D.lm_fac = D.lm_total; D.lm_total += D.fac_ns;
         } else D.lm_fac = -1;
         const size_t meta = (size_t)D.lm_total * sizeof(PackedSlice) + scratch;
@@ -628,8 +628,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
             const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
             if (cost < best - 1e-12) { best = cost; best_r = r; }
         }
-        const int forced = env_int("EICOS_FORCE_BLOCKS_PER_CU", 0, 0, 8); // experiments: override the estimate (within what fits)
-        bpc = forced > 0 ? std::min(forced, bpc) : best_r;
+        bpc = best_r;
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
     // 256 threads at <= 2 workgroups per CU: the build with 256 VGPRs per thread (the default one is held to 168 so that three fit)
@@ -645,7 +644,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
     // scattered stores and the read-back stay on chip.  Verified against the runtime's occupancy for the enlarged allocation.
     D.e_lds = 0; D.e_off = 0;
-    if (!h->ldsres && h->nlds == 1 && !D.dual && S.tile != 1 && env_int("EICOS_E_LDS", 1, 0, 1)) {
+    if (!h->ldsres && h->nlds == 1 && !D.dual && S.tile != 1) {
         const size_t base = (h->dyn_lds + 15) & ~(size_t)15, room = (160 * 1024) / (size_t)bpc;
         size_t xs = room > base + 4096 + 1024 ? std::min<size_t>((size_t)NV, (room - base - 4096 - 1024) / sizeof(double)) & ~(size_t)15 : 0;
         while (xs > 0) {
@@ -659,7 +658,6 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     }
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min(batch, resident);
-    h->grid = std::max(1, std::min(h->grid, env_int("EICOS_GRID", h->grid, 1, 1 << 20))); // experiments: fewer workgroups than the resident maximum
     h->order_min = prop.multiProcessorCount;
     h->upd_grid = std::min(batch, prop.multiProcessorCount * 4);
     {   // entry-parallel updateData: needs the A / G values and the row / column maxima in LDS and <= 8 vector entries per thread

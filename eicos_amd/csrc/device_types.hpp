@@ -190,14 +190,8 @@ constexpr int TILE_PF = 6;          // tile loads in flight per wavefront in the
 #define EICOS_TILE_FPF 3
 #endif
 constexpr int TILE_FPF = EICOS_TILE_FPF;         // operations (two tiles + a D block each) in flight per wavefront in the tile factorisation
-#ifndef EICOS_TILE_FTRIP
-#define EICOS_TILE_FTRIP EICOS_TILE_FPF
-#endif
-#ifndef EICOS_TILE_STRIP
-#define EICOS_TILE_STRIP 6
-#endif
-constexpr int TILE_FTRIP = EICOS_TILE_FTRIP;     // operations per trip of the unrolled loops (factor / sweeps): see ELL_TRIP; op lists are padded to a multiple
-constexpr int TILE_STRIP = EICOS_TILE_STRIP;
+constexpr int TILE_FTRIP = TILE_FPF;             // operations per trip of the unrolled loops (factor / sweeps): see ELL_TRIP; op lists are padded to a multiple
+constexpr int TILE_STRIP = 6;                    // (longer trips measured in round 3: no change on the bandwidth-bound tile path)
 static_assert(TILE_FTRIP % TILE_FPF == 0 && TILE_STRIP % TILE_PF == 0, "the register queues rotate inside a trip");
 constexpr int FOP_INIT = 1, FOP_END = 2, FOP_PAD = 4, FOP_SHIFT = 4; // tile factor op flags: start a target from its K tile / finish it / padding; target id above
 constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)

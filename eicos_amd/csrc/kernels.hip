@@ -87,26 +87,13 @@ template <int T> constexpr int waves_per_eu() { return 2; } // LDS allows at mos
 #elif EICOS_W2
 template <int T> constexpr int waves_per_eu() { return 2; }
 #else
-#ifndef EICOS_WPE256
-#define EICOS_WPE256 3
-#endif
-template <int T> constexpr int waves_per_eu() { return T == 256 ? EICOS_WPE256 : (T == 512 ? 2 : 4); }
+template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : (T == 512 ? 2 : 4); }
 #endif
 
-// Multiply-accumulate of the sparse inner loops (products, sweeps, factor program).  The file is compiled with
-// -ffp-contract=off; EICOS_USE_FMA = 1 fuses exactly these (one v_fma_f64 instead of v_mul_f64 + v_add_f64).  Measured
-// (same box, round 2): +0.2 ... +0.7 % on every config -- the loops wait for their operands, not for issue slots -- so the
-// default stays unfused: the arithmetic then rounds like the CPU oracle's.
-#ifndef EICOS_USE_FMA
-#define EICOS_USE_FMA 0
-#endif
-__device__ __forceinline__ double madd(double acc, double a, double b) {
-#if EICOS_USE_FMA
-    return __builtin_fma(a, b, acc);
-#else
-    return acc + a * b;
-#endif
-}
+// Multiply-accumulate of the sparse inner loops (products, sweeps, factor program).  The file is compiled with -ffp-contract=off and the
+// product is NOT fused: the arithmetic then rounds like the CPU oracle's.  (One v_fma_f64 instead of v_mul_f64 + v_add_f64 was measured
+// in round 2: +0.2 ... +0.7 % on every config -- the loops wait for their operands, not for issue slots.)
+__device__ __forceinline__ double madd(double acc, double a, double b) { return acc + a * b; }
 constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values per reduction
 
 // scalar slots in LDS (written by thread 0 only)
@@ -354,12 +341,9 @@ struct IV1 { int i; double a; };
 struct IV2 { int i; double a, b; };
 struct IIV { int i, j; double a; };
 struct IIV3 { int i, j; double a, b, c; };
-#ifndef EICOS_PRE_MULT
-#define EICOS_PRE_MULT 1
-#endif
 template <int T, int U0 = 4, class L, class F>
 __device__ __forceinline__ void for_t_pre(int cnt, L &&ld, F &&fn) {
-    constexpr int U = U0 * EICOS_PRE_MULT; // elements per thread in flight
+    constexpr int U = U0; // elements per thread in flight (x2 / x3 measured in round 3: +-0 / -6 %)
     for (int i0 = threadIdx.x; i0 < cnt; i0 += U * T) {
         decltype(ld(0)) r[U];
 #pragma unroll

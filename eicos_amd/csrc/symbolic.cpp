@@ -329,7 +329,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
                 for (int j : rows[i]) { const int I = blk_of[i], J = blk_of[j]; if (I != J && lev_of[I] <= lev_of[J]) { lev_of[I] = lev_of[J] + 1; maxlev = std::max(maxlev, lev_of[I]); } }
             return (double)nt + (double)nbk + 4.0 * (maxlev + 1);
         };
-        if (env_knob("EICOS_TILE_AMALG", 1, 0, 1)) {
+        {
             double cur = cost_of(cut16(sn_start));
             // a merge can only pay when it saves a block: ceil((a + b) / 16) < ceil(a / 16) + ceil(b / 16); the recounts are bounded
             // (each is O(nnz(L))) so that huge patterns do not spend minutes here
@@ -411,7 +411,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     // ---- hybrid: does the scalar schedule end in a chain worth handing to the tile path? ----
     if (!tile && program && hybrid && N > 0) {
         int cut = S.nlev;
-        const int wmax = env_knob("EICOS_HYB_W", 4, 1, 64); // (experiment knob, envknob.hpp)
+        constexpr int wmax = 4;
         while (cut > 0 && S.lev_ptr[cut] - S.lev_ptr[cut - 1] <= wmax) cut--; // maximal tail of levels with <= 4 nodes
         const int nD = N - S.lev_ptr[cut], nbD = (nD + 15) / 16;
         // worth it: the tail is long (each of its levels costs the sweeps a dependent step, one block costs about two)

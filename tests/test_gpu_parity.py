@@ -166,12 +166,10 @@ def test_dense_front_socp():
                                  {"EICOS_THREADS": "256"}, {"EICOS_THREADS": "512"}, {"EICOS_IDX16": "0"}, {"EICOS_IDX16": "0", "EICOS_NLDS": "0"},
                                  {"EICOS_TILES": "1"}, {"EICOS_TILES": "1", "EICOS_NLDS": "0"}, {"EICOS_TILES": "1", "EICOS_THREADS": "128", "EICOS_NLDS": "2"},
                                  {"EICOS_TILES": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "1"},
-                                 {"EICOS_FAC_L0": "0"}, {"EICOS_FAC_L0": "0", "EICOS_TILES": "0", "EICOS_THREADS": "256"},
-                                 {"EICOS_E_LDS": "0"}, {"EICOS_E_LDS": "0", "EICOS_NLDS": "1", "EICOS_DUAL": "0"}, {"EICOS_E_LDS": "1", "EICOS_NLDS": "1", "EICOS_DUAL": "0"},
-                                 {"EICOS_E_LDS": "1", "EICOS_NLDS": "1", "EICOS_DUAL": "0", "EICOS_TILES": "2", "EICOS_THREADS": "256"},
+                                 {"EICOS_NLDS": "1", "EICOS_DUAL": "0"}, {"EICOS_NLDS": "1", "EICOS_DUAL": "0", "EICOS_TILES": "2", "EICOS_THREADS": "256"},
                                  {"EICOS_W2": "0", "EICOS_THREADS": "256"}, {"EICOS_W2": "1", "EICOS_THREADS": "256", "EICOS_NLDS": "0"},
                                  {"EICOS_FAC_DEFER": "0"}, {"EICOS_FAC_DEFER": "1", "EICOS_TILES": "2"}, {"EICOS_FAC_DEFER": "1", "EICOS_IDX16": "0", "EICOS_TILES": "0"},
-                                 {"EICOS_FAC_DEFER": "1", "EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_NLDS": "1"}, {"EICOS_FAC_DEFER": "1", "EICOS_FAC_L0": "0"},
+                                 {"EICOS_FAC_DEFER": "1", "EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_NLDS": "1"},
                                  {"EICOS_LDSRES": "0"}, {"EICOS_LDSRES": "0", "EICOS_THREADS": "128", "EICOS_TILES": "0"},
                                  {"EICOS_TILES": "1", "EICOS_GTILES": "2"}, {"EICOS_TILES": "1", "EICOS_GTILES": "2", "EICOS_DUAL": "0", "EICOS_THREADS": "256"},
                                  {"EICOS_TILES": "1", "EICOS_GTILES": "0"},

@@ -25,7 +25,7 @@ for case in range(ncase):
     if l + sum(q) == 0:
         l = 3
     dens = float(rng.choice([0.05, 0.15, 0.3, 0.6])) / scale
-    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL", "EICOS_FAC_L0", "EICOS_FAC_DEFER", "EICOS_E_LDS", "EICOS_W2", "EICOS_CONE_ORDER"):
+    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL", "EICOS_FAC_DEFER", "EICOS_W2", "EICOS_CONE_ORDER"):
         os.environ.pop(k, None)
     var = {}
     if rng.random() < 0.7:
@@ -44,12 +44,10 @@ for case in range(ncase):
     if rng.random() < 0.3:
         var["EICOS_DUAL"] = "0"
     # round 3: the streamed level 0 of the factor program off, the cone-aware elimination order forced / forbidden
-    if rng.random() < 0.2:
-        var["EICOS_FAC_L0"] = "0"
+    rng.random()  # (round 3 drew EICOS_FAC_L0 here; the knob was removed in round 4 -- the draw is kept so that seeds reproduce the same patterns' variants)
     if rng.random() < 0.4:
         var["EICOS_FAC_DEFER"] = str(rng.choice([0, 1]))
-    if rng.random() < 0.2:
-        var["EICOS_E_LDS"] = "0"
+    rng.random()  # (formerly EICOS_E_LDS)
     if rng.random() < 0.2:
         var["EICOS_W2"] = "0"
     if rng.random() < 0.4:

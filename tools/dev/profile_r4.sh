@@ -1,8 +1,8 @@
-# round 3: rocprofv3 summaries for profiles/ -- kernel stats of the bench command + PMC passes (separate runs, kernel-trace only)
-# for EVERY workload of the default bench line (headline, its SOC leg, and the `configs` object).  Every pass is bounded.
+# round 4: rocprofv3 summaries for profiles/ -- kernel stats of the bench command + PMC passes (separate runs, kernel-trace only)
+# for EVERY workload of the default bench line (headline, its SOC leg, and the configs).  Every pass is bounded.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/prof_r3
+out=gpurun_out/prof_r4
 rm -rf $out; mkdir -p $out
 python3 bench.py --steps 10 --warmup 2 > $out/bench_plain.json 2> $out/bench_plain.err
 tail -1 $out/bench_plain.json | cut -c1-200
@@ -23,6 +23,7 @@ run ""       1
 run soc_     1 --soc
 run tile_    1 --pattern dense-front --batch 512
 run b512_    0 --batch 512
+run b4096_   0 --batch 4096
 run afiro_   0 --pattern lp_afiro --batch 256 --perturb
 run bandm_   0 --pattern lp_bandm --batch 256 --perturb
 run fv47_    0 --pattern lp_25fv47 --batch 256 --perturb

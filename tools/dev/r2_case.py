@@ -22,7 +22,7 @@ import scipy.sparse as sp
 G = [sp.csc_matrix((d["Gpr"][i], pat.Gir, pat.Gjc), shape=(pat.m, pat.n)) for i in range(3)]
 A = [sp.csc_matrix((d["Apr"][i], pat.Air, pat.Ajc), shape=(pat.p, pat.n)) for i in range(3)]
 xs = {}
-KEYS = ("EICOS_LDSRES", "EICOS_TILES", "EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_DUAL", "EICOS_FAC_L0", "EICOS_FAC_DEFER", "EICOS_E_LDS", "EICOS_W2", "EICOS_CONE_ORDER")
+KEYS = ("EICOS_LDSRES", "EICOS_TILES", "EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_DUAL", "EICOS_FAC_DEFER", "EICOS_W2", "EICOS_CONE_ORDER")
 for env in (envv, {}, {"EICOS_TILES": "0", "EICOS_LDSRES": "0"}):
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)

@@ -1,10 +1,11 @@
-# profiles/<tag>_* from gpurun_out/prof_r3 (tools/dev/profile_r3.sh): usage tools/dev/summarize_r3.sh r03_v1
+# profiles/<tag>_* from gpurun_out/prof_r4 (tools/dev/profile_r4.sh): usage tools/dev/summarize_r4.sh r04_v1
 set -e
-t=$1; s=gpurun_out/prof_r3
+t=$1; s=gpurun_out/prof_r4
 python tools/summarize_profile.py $s profiles/$t "MPC02 batch=1024" "" > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_soc "MPC02-SOC batch=1024" soc_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_tile "dense-front batch=512" tile_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_b512 "MPC02 batch=512" b512_ > /dev/null
+python tools/summarize_profile.py $s profiles/${t}_b4096 "MPC02 batch=4096" b4096_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_afiro "lp_afiro batch=256" afiro_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_bandm "lp_bandm batch=256" bandm_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_25fv47 "lp_25fv47 batch=256" fv47_ > /dev/null
