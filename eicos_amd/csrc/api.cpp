@@ -440,6 +440,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         }
         D.n_tiny = (int)tiny_tab.size() / TINY_INTS; D.n_mid = (int)cone_mid.size();
         put(D.cone_tiny, tiny_tab); put(D.cone_mid, cone_mid);
+        std::vector<int> cone_wave, cone_huge;
+        for (int c : cone_big) (S.q[c] <= 64 ? cone_wave : cone_huge).push_back(c);
+        D.n_wave = (int)cone_wave.size(); D.n_huge = (int)cone_huge.size();
+        put(D.cone_wave, cone_wave); put(D.cone_huge, cone_huge);
     }
     put(D.zdsign, zdsign);
     put(D.f_idx, planF.idx); put(D.b_idx, planB.idx);

@@ -116,6 +116,10 @@ struct DevPat {
     // cone_mid = the other cones below CONE_BIG
     gint_p cone_tiny, cone_mid;
     int n_tiny, n_mid;
+    // "wave" cones (CONE_BIG <= dimension <= 64): one wavefront per cone with LANE-PER-ROW registers in the hot loops (kernels.hip: for_wave);
+    // cone_huge = the cones above 64 rows (generic wavefront loops)
+    gint_p cone_wave, cone_huge;
+    int n_wave, n_huge;
     gint_p zdsign;  // [m] +1 / -1: sign of the static-regularisation term in refinement
     // LDL' pattern, level ordered
     // triangular solves: sliced-ELL plans (see SliceMeta).  UF = unit-lower L in the forward (row) slot order,

@@ -279,14 +279,46 @@ __device__ __forceinline__ void for_cones(int ps, Body &&body) {
     for (int q = tid >> 6; q < P.n_big; q += T / 64) body(P.cone_big[q], std::integral_constant<int, 64>{}, tid & 63);
 }
 
-// The cones for_tiny does not cover (dimension > TINY_D): DevPat::cone_mid one thread each, cone_big one wavefront each.
+// The cones neither for_tiny nor for_wave covers: DevPat::cone_mid (TINY_D < dimension < CONE_BIG) one thread each, cone_huge
+// (dimension > 64) one wavefront each.
 template <int T, class Body>
 __device__ __forceinline__ void for_cones_rest(int ps, Body &&body) {
     const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x;
     for (int q = tid; q < P.n_mid; q += T) body(P.cone_mid[q], std::integral_constant<int, 1>{}, 0);
-    for (int q = tid >> 6; q < P.n_big; q += T / 64) body(P.cone_big[q], std::integral_constant<int, 64>{}, tid & 63);
+    for (int q = tid >> 6; q < P.n_huge; q += T / 64) body(P.cone_huge[q], std::integral_constant<int, 64>{}, tid & 63);
 }
+
+// "Wave" cones (CONE_BIG <= dimension <= 64: the 32 cones of dimension 64 of the dense-front config), one wavefront per cone,
+// LANE-PER-ROW REGISTERS: the generic wavefront body is a chain of dependent loads per cone (cone id -> first row / dimension -> row
+// slots -> values) and a workgroup of 8 wavefronts walks 32 cones in 4 such rounds; here the descriptors of a wavefront's U cones are
+// loaded first (`pre`: integers the value loads need as addresses), then all values (`ld`), then the bodies run (`fn`, wavefront
+// reductions).  Lane L holds row L ("shift 0") and / or row L + 1 ("shift 1") of its cone, exactly the rows the generic loops
+// `for (k = lane; ...)` / `for (k = 1 + lane; ...)` give that lane, so every wavefront reduction sums the same values on the same
+// lanes: results are bit-identical to the generic bodies.
+struct WCone { int c, o, d; };
+template <int T, int U, class PreF, class L, class F>
+__device__ __forceinline__ void for_wave(const DevPat &P, PreF &&pre, L &&ld, F &&fn) {
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6);
+    for (int q0 = wave; q0 < P.n_wave; q0 += U * NW) {
+        WCone b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int c = P.cone_wave[min(q0 + u * NW, P.n_wave - 1)]; b[u] = WCone{c, P.cone_off[c], P.cq[c]}; }
+        decltype(pre(b[0], 0)) a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = pre(b[u], lane);
+        decltype(ld(b[0], 0, a[0])) r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u] = ld(b[u], lane, a[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) if (q0 + u * NW < P.n_wave) fn(b[u], lane, a[u], r[u]);
+    }
+}
+struct NoPre {};
+// the lane's value of array a in cone b: row lane + s (clamped to the last row; lanes past the dimension load a valid duplicate)
+template <class Ptr> __device__ __forceinline__ double wrow(Ptr a, const WCone &b, int lane, int s) { return a[b.o + min(lane + s, b.d - 1)]; }
+template <int T> constexpr int wave_cones_in_flight() { return waves_per_eu<T>() <= 2 ? 4 : 2; }
 
 // Tiny cones (dimension <= TINY_D = 4: the 332 cones of dimension 3 of an MPC-SOC pattern), one thread per cone, REGISTER-RESIDENT:
 // `ld(t)` loads everything the cone's body reads (into a small struct), `fn(t, loaded)` does the arithmetic and the stores.  The
@@ -684,6 +716,18 @@ __device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out
         for (int k = 1; k < TINY_D; k++) if (k < t.d) out[t.o + k] = r.eta * (r.z.v[k] + factor * r.q.v[k]);
         out[t.o] = r.eta * (r.a * z0 + zeta);
     });
+    struct SW { double z1, q1, z0, a, eta; };
+    for_wave<T, wave_cones_in_flight<T>()>(P, [](const WCone &, int) { return NoPre{}; },
+        [&](const WCone &b, int lane, NoPre) { gcdbl_p cs = csc + b.c * CSC_STRIDE; return SW{wrow(zz, b, lane, 1), wrow(qv, b, lane, 1), zz[b.o], cs[CS_A], cs[CS_ETA]}; },
+        [&](const WCone &b, int lane, NoPre, const SW &r) {
+        const int k = 1 + lane;
+        double zeta = 0.;
+        if (k < b.d) zeta += r.q1 * r.z1;
+        zeta = wave_reduce<OpSum>(zeta);
+        const double factor = r.z0 + zeta / (1. + r.a);
+        if (k < b.d) out[b.o + k] = r.eta * (r.z1 + factor * r.q1);
+        if (lane == 0) out[b.o] = r.eta * (r.a * r.z0 + zeta);
+    });
     for_cones_rest<T>(ps, [&](int c, auto G, int lane) {
         constexpr int g = decltype(G)::value;
         const int o = P.cone_off[c], d = P.cq[c];
@@ -786,6 +830,32 @@ __device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, do
             const double rr = inv * (r.ds.v[k] - fr * lb), ss = inv * (r.dz.v[k] - fs * lb);
             rn += rr * rr; sn += ss * ss;
         }
+        cstep = fmax(cstep, fmax(0., fmax(sqrt(sn) - sig0, sqrt(rn) - rho0)));
+    });
+    struct LW { double lam1, ds1, dz1, lam0, ds0, dz0; };
+    for_wave<T, wave_cones_in_flight<T>()>(P, [](const WCone &, int) { return NoPre{}; },
+        [&](const WCone &b, int lane, NoPre) { return LW{wrow(lam, b, lane, 1), wrow(ds, b, lane, 1), wrow(dz, b, lane, 1), lam[b.o], ds[b.o], dz[b.o]}; },
+        [&](const WCone &b, int lane, NoPre, const LW &r) { // cone_step with the lane's row in registers
+        const bool act = 1 + lane < b.d;
+        double l1 = 0.;
+        if (act) l1 += r.lam1 * r.lam1;
+        l1 = wave_reduce<OpSum>(l1);
+        const double lknorm2 = r.lam0 * r.lam0 - l1;
+        if (lknorm2 <= 0.) { bad = 1.; return; }
+        const double lknorm = sqrt(lknorm2), inv = 1. / lknorm, lk0 = r.lam0 / lknorm;
+        double ld = 0., lz = 0.;
+        if (act) { const double lb = r.lam1 / lknorm; ld += lb * r.ds1; lz += lb * r.dz1; }
+        ld = wave_reduce<OpSum>(ld); lz = wave_reduce<OpSum>(lz);
+        const double lds = lk0 * r.ds0 - ld, ldz = lk0 * r.dz0 - lz;
+        const double rho0 = inv * lds, fr = (lds + r.ds0) / (lk0 + 1.);
+        const double sig0 = inv * ldz, fs = (ldz + r.dz0) / (lk0 + 1.);
+        double rn = 0., sn = 0.;
+        if (act) {
+            const double lb = r.lam1 / lknorm;
+            const double rr = inv * (r.ds1 - fr * lb), ss = inv * (r.dz1 - fs * lb);
+            rn += rr * rr; sn += ss * ss;
+        }
+        rn = wave_reduce<OpSum>(rn); sn = wave_reduce<OpSum>(sn);
         cstep = fmax(cstep, fmax(0., fmax(sqrt(sn) - sig0, sqrt(rn) - rho0)));
     });
     for_cones_rest<T>(ps, [&](int c, auto G, int lane) {
@@ -1644,6 +1714,46 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
             } else cs[CN_MODE] = 1.;
             if (fail) firstfail = fmin(firstfail, (double)t.c);
         });
+        // wave cones: lane-per-row registers (same operations in the same order and on the same lanes as the generic bodies below)
+        struct S1W { double sA, zA, sB, zB, s0, z0; };
+        for_wave<T, wave_cones_in_flight<T>()>(P, [](const WCone &, int) { return NoPre{}; },
+            [&](const WCone &b, int lane, NoPre) { return S1W{wrow(wsl, b, lane, 0), wrow(wz, b, lane, 0), wrow(wsl, b, lane, 1), wrow(wz, b, lane, 1), wsl[b.o], wz[b.o]}; },
+            [&](const WCone &b, int lane, NoPre, const S1W &r) {
+            const bool actA = lane < b.d, actB = 1 + lane < b.d;
+            gdbl_p cs = csc + b.c * CSC_STRIDE;
+            double s1 = 0., z1 = 0.;
+            if (actB) { s1 += r.sB * r.sB; z1 += r.zB * r.zB; }
+            s1 = wave_reduce<OpSum>(s1); z1 = wave_reduce<OpSum>(z1);
+            const double s0 = r.s0, z0 = r.z0;
+            const double sres = s0 * s0 - s1, zres = z0 * z0 - z1;
+            bool fail = (sres <= 0. || zres <= 0.);
+            if (!fail) {
+                const double snorm = sqrt(sres), znorm = sqrt(zres);
+                double sz = 0., ww = 0.;
+                if (actA) sz += (r.sA / snorm) * (r.zA / znorm);
+                sz = wave_reduce<OpSum>(sz);
+                const double gam = sqrt(0.5 * (1. + sz));
+                const double a = (0.5 / gam) * (s0 / snorm + z0 / znorm);
+                if (actB) { const double qk = (0.5 / gam) * (r.sB / snorm - r.zB / znorm); ww += qk * qk; }
+                ww = wave_reduce<OpSum>(ww);
+                const double cc = (1. + a) + ww / (1. + a);
+                const double dd = 1. + 2. / (1. + a) + ww / ((1. + a) * (1. + a));
+                const double d1 = fmax(0., 0.5 * (a * a + ww * (1. - cc * cc / (1. + ww * dd))));
+                const double u0sq = a * a + ww - d1;
+                const double c2 = cc * cc / u0sq;
+                const bool late = (c2 - dd <= 0.);
+                if (late) fail = true;
+                if (lane == 0) {
+                    cs[CN_ETA2] = snorm / znorm; cs[CN_SN] = snorm; cs[CN_ZN] = znorm; cs[CN_GAM] = gam;
+                    cs[CN_MODE] = late ? 2. : 0.;
+                    if (!late) {
+                        cs[CN_A] = a; cs[CN_D1] = d1; cs[CN_W] = ww;
+                        cs[CN_U0] = sqrt(u0sq); cs[CN_U1] = sqrt(c2); cs[CN_V1] = sqrt(c2 - dd);
+                    }
+                }
+            } else if (lane == 0) cs[CN_MODE] = 1.;
+            if (fail) firstfail = fmin(firstfail, (double)b.c);
+        });
         for_cones_rest<T>(ps, [&](int c, auto G, int ln) { // phase 1: candidate scalings per cone
             constexpr int g = decltype(G)::value;
             const int o = P.cone_off[c], d = P.cq[c];
@@ -1730,6 +1840,41 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
                     v[2 * d + 1 + k] = e2; Kt[vt_at(2 * d + 1 + k)] = e2;
                 }
                 v[d] = -eta2; Kt[vt_at(d)] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[vt_at(2 * d)] = eta2 + DELTASTAT;
+            });
+        }
+        {
+            struct S2A { int vb; };
+            struct S2W { double sA, zA, eta2, mode, sn, zn, gam, nA, nW, nD1, nU0, nU1, nV1, sD1, sU0, sU1, sV1; int t0, t1, t2, td, t2d; };
+            for_wave<T, wave_cones_in_flight<T>()>(P, [&](const WCone &b, int) { return S2A{P.cone_vbase[b.c]}; },
+                [&](const WCone &b, int lane, const S2A &a) {
+                gcdbl_p cs = csc + b.c * CSC_STRIDE;
+                gint_p vt = P.v2t + a.vb;
+                const int k = min(lane, b.d - 1), d = b.d;
+                return S2W{wrow(wsl, b, lane, 0), wrow(wz, b, lane, 0), cs[CN_ETA2], cs[CN_MODE], cs[CN_SN], cs[CN_ZN], cs[CN_GAM], cs[CN_A], cs[CN_W], cs[CN_D1], cs[CN_U0],
+                           cs[CN_U1], cs[CN_V1], cs[CS_D1], cs[CS_U0], cs[CS_U1], cs[CS_V1], vt[k], vt[d + k], vt[2 * d + 1 + k], vt[d], vt[2 * d]};
+            }, [&](const WCone &b, int lane, const S2A &a, const S2W &r) {
+                if ((double)b.c > firstfail) return;
+                const bool partial = ((double)b.c == firstfail);
+                if (partial && r.mode != 2.) return;
+                const int d = b.d, o = b.o, k = lane;
+                gdbl_p cs = csc + b.c * CSC_STRIDE;
+                gdbl_p v = Vv + a.vb;
+                const double eta2 = r.eta2;
+                const double d1 = partial ? r.sD1 : r.nD1, u0 = partial ? r.sU0 : r.nU0, u1 = partial ? r.sU1 : r.nU1, v1 = partial ? r.sV1 : r.nV1;
+                const double snorm = r.sn, znorm = r.zn, gam = r.gam;
+                if (lane == 0) {
+                    cs[CS_ETA2] = eta2; cs[CS_ETA] = sqrt(eta2);
+                    if (!partial) { cs[CS_A] = r.nA; cs[CS_D1] = d1; cs[CS_W] = r.nW; cs[CS_U0] = u0; cs[CS_U1] = u1; cs[CS_V1] = v1; }
+                }
+                if (k < d) {
+                    const double qk = (k >= 1) ? (0.5 / gam) * (r.sA / snorm - r.zA / znorm) : 0.;
+                    if (k >= 1) { qv[o + k] = qk; const double e = -eta2 * v1 * qk; v[d + k] = e; Kt[r.t1] = e; }
+                    const double e0 = (k == 0) ? -eta2 * d1 - DELTASTAT : -eta2 - DELTASTAT;
+                    const double e2 = (k == 0) ? -eta2 * u0 : -eta2 * u1 * qk;
+                    v[k] = e0; Kt[r.t0] = e0;
+                    v[2 * d + 1 + k] = e2; Kt[r.t2] = e2;
+                }
+                if (lane == 0) { v[d] = -eta2; Kt[r.td] = -eta2; v[2 * d] = eta2 + DELTASTAT; Kt[r.t2d] = eta2 + DELTASTAT; }
             });
         }
         for_cones_rest<T>(ps, [&](int c, auto G, int ln) { // phase 2: commit + updateKKTScalings
@@ -1997,6 +2142,41 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
                     }
                     nez[k] = fmax(nez[k], mx);
                 });
+                // wave cones, refinement operator proper (not the initialisation solves): lane-per-row registers
+                struct RWA { int eq, e1, e3, e4; };
+                struct RW { double e, xq, qq, e1v, x1, x3, x4, eta2, v1, u1, d1, u0; };
+                if (!init) for_wave<T, wave_cones_in_flight<T>()>(P, [&](const WCone &b, int lane) {
+                    return RWA{P.ipz[b.o + min(1 + lane, b.d - 1)], P.ipz[b.o], P.ipv[b.c], P.ipu[b.c]};
+                }, [&](const WCone &b, int lane, const RWA &a) {
+                    gcdbl_p cs = csc[k] + b.c * CSC_STRIDE;
+                    return RW{ldE(a.eq, k), X[a.eq * KI + k], qv[k][b.o + min(1 + lane, b.d - 1)], ldE(a.e1, k), X[a.e1 * KI + k], X[a.e3 * KI + k], X[a.e4 * KI + k],
+                              cs[CS_ETA2], cs[CS_V1], cs[CS_U1], cs[CS_D1], cs[CS_U0]};
+                }, [&](const WCone &b, int lane, const RWA &a, const RW &r) {
+                    const bool act = 1 + lane < b.d;
+                    const double tt = r.v1 * r.x3 + r.u1 * r.x4;
+                    double mx = 0., qtx = 0.;
+                    if (act) {
+                        const double v = r.e + r.eta2 * (r.xq + tt * r.qq);
+                        stE(a.eq, k, v); mx = fmax(mx, fabs(v));
+                        qtx += r.qq * r.xq;
+                    }
+                    qtx = wave_reduce<OpSum>(qtx);
+                    if (lane == 0) {
+                        const double v1 = r.e1v + r.eta2 * (r.d1 * r.x1 + r.u0 * r.x4);
+                        const double v3 = r.eta2 * (r.v1 * qtx + r.x3);
+                        const double v4 = r.eta2 * (r.u0 * r.x1 + r.u1 * qtx - r.x4);
+                        stE(a.e1, k, v1); stE(a.e3, k, v3); stE(a.e4, k, v4);
+                        mx = fmax(mx, fmax(fabs(v1), fmax(fabs(v3), fabs(v4))));
+                    }
+                    nez[k] = fmax(nez[k], mx);
+                });
+                else for (int q_ = threadIdx.x >> 6; q_ < P.n_wave; q_ += T / 64) { // (initialisation solves: ez += dz on the cone's rows, the generic body)
+                    const int c = P.cone_wave[q_], ln = threadIdx.x & 63, d = P.cq[c], o = P.cone_off[c];
+                    double mx = 0.;
+                    for (int q = ln; q < d; q += 64) { const int eq = P.ipz[o + q], pq = eq * KI + k; const double v = ldE(eq, k) + X[pq]; stE(eq, k, v); mx = fmax(mx, fabs(v)); }
+                    if (ln == 0) { const int e3 = P.ipv[c], e4 = P.ipu[c]; const double x3 = X[e3 * KI + k], x4 = X[e4 * KI + k]; stE(e3, k, x3); stE(e4, k, x4); mx = fmax(mx, fmax(fabs(x3), fabs(x4))); }
+                    nez[k] = fmax(nez[k], mx);
+                }
                 for_cones_rest<T>(ps, [&](int c, auto G, int ln) {
                     constexpr int g = decltype(G)::value;
                     const int d = P.cq[c], o = P.cone_off[c];
@@ -2241,6 +2421,43 @@ __device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
 #pragma unroll
                 for (int k = 1; k < TINY_D; k++) if (k < d) t1[o + k] = r.eta * (nd[k] + factor2 * r.q.v[k]);
                 t1[o] = r.eta * (r.a * z0 + zeta2);
+            });
+            // wave cones: both loops in one lane-per-row pass (a row's intermediate values stay on its lane; the head's new ds is formed by
+            // every lane from the reduced sums)
+            struct RCW { double lamA, dsA, wzA, lamB, dsB, wzB, qB, l0, a0, w0, a, eta; };
+            for_wave<T, wave_cones_in_flight<T>()>(P, [](const WCone &, int) { return NoPre{}; },
+                [&](const WCone &b, int lane, NoPre) {
+                gcdbl_p cs = csc + b.c * CSC_STRIDE;
+                return RCW{wrow(lam, b, lane, 0), wrow(dsw, b, lane, 0), wrow(wdz, b, lane, 0), wrow(lam, b, lane, 1), wrow(dsw, b, lane, 1), wrow(wdz, b, lane, 1),
+                           wrow(qv, b, lane, 1), lam[b.o], dsw[b.o], wdz[b.o], cs[CS_A], cs[CS_ETA]};
+            }, [&](const WCone &b, int lane, NoPre, const RCW &r) {
+                const int o = b.o, k = 1 + lane;
+                const bool actA = lane < b.d, actB = k < b.d;
+                double ll = 0., dw = 0., u1sq = 0.;
+                if (actA) { ll += r.lamA * r.lamA; dw += r.dsA * r.wzA; }
+                ll = wave_reduce<OpSum>(ll); dw = wave_reduce<OpSum>(dw);
+                const double l0 = r.l0, a0 = r.a0, w0_ = r.w0;
+                const double p0 = ll - sigmamu + dw;
+                double zeta = 0., pk_ = 0.;
+                if (actB) {
+                    const double lk = r.lamB;
+                    pk_ = (l0 * lk + l0 * lk) + (a0 * r.wzB + w0_ * r.dsB);
+                    u1sq += lk * lk; zeta += lk * pk_;
+                }
+                u1sq = wave_reduce<OpSum>(u1sq); zeta = wave_reduce<OpSum>(zeta);
+                const double rho = l0 * l0 - u1sq;
+                const double factor = (zeta / l0 - p0) / rho;
+                const double ndB = factor * r.lamB + pk_ / l0; // the new ds of row k
+                if (actB) dsw[o + k] = ndB;
+                const double nd0 = (l0 * p0 - zeta) / rho;       // ... and of the head
+                if (lane == 0) dsw[o] = nd0;
+                // t1 = W * (lam \ ds) on the cone
+                double zeta2 = 0.;
+                if (actB) zeta2 += r.qB * ndB;
+                zeta2 = wave_reduce<OpSum>(zeta2);
+                const double factor2 = nd0 + zeta2 / (1. + r.a);
+                if (actB) t1[o + k] = r.eta * (ndB + factor2 * r.qB);
+                if (lane == 0) t1[o] = r.eta * (r.a * nd0 + zeta2);
             });
             for_cones_rest<T>(ps, [&](int c, auto G, int ln) {
                 constexpr int g = decltype(G)::value;

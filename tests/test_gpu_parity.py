@@ -702,6 +702,30 @@ def test_ordering_dependent_fatal_seeds_are_pinned():
     assert n_orc_fatal >= 15  # (the oracle-side cases are independent of the GPU path: 18 when this was written)
 
 
+def test_soc_patterns_on_the_unconstrained_order_do_not_depend_on_rounding():
+    # the cone-aware elimination order (a cone's expansion columns after its rows: numerically preferable, symbolic.cpp) is
+    # taken only where it is free under the cost model; MPC-SOC and the dense-front pattern keep the unconstrained order
+    # (eicos_dims.cone_order = 0).  Unlike unboundedMaxSqrt, whose exit is decided by that order, these well-posed patterns must not
+    # care: 64 copies of one instance with ALL data perturbed by 1e-14 give the same exit and iteration counts within one pass, on the
+    # GPU and on the oracle alike.
+    import os
+    from oracle import oracle as orc
+    from eicos_amd.generate import dense_front_pattern as full_dense_front
+    pat0, sets = load_fixture("MPC02")
+    cases = [(mpc_soc_variant(pat0), sets[0]), full_dense_front(600, 8, 64)]
+    for pat, base in cases:
+        d1 = feasible_batch(pat, base, 0, 1)
+        T = 64
+        rng = np.random.default_rng(7)
+        dd = [d1[k][0][None, :] * (1 + 1e-14 * rng.uniform(-1, 1, (T,) + d1[k][0].shape)) for k in ("Gpr", "Apr", "c", "h", "b")]
+        g = eicos_amd.BatchSolver(pat, T)
+        assert g.dims()["cone_order"] == 0
+        g.update(*dd); gc = g.solve(); gi = g.info_arrays()["iter"].astype(int); g.close()
+        r = orc.batch_solve(pat, *dd, len(os.sched_getaffinity(0)))
+        assert np.all(gc == 0) and np.all(r["exitcodes"] == 0)
+        assert gi.max() - gi.min() <= 1 and r["iters"].max() - r["iters"].min() <= 1 and np.all(np.abs(gi - r["iters"].astype(int)) <= 1)
+
+
 def test_ecos_shim_runs_every_registered_reference_test(tmp_path, expected):
     # N2: the reference's registered tests (test/ecostester.cpp:54-72) driven through the ECOS shim of include/ecos.h
     # (ECOS_setup -> ECOS_solve [-> ECOS_updateData -> ECOS_solve] -> ECOS_cleanup) by a compiled C++ runner; the
