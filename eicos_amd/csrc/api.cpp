@@ -1393,7 +1393,7 @@ static double host_check_tiles_impl(int n, int m, int p, int ncones, const int *
 // Host-only: the elimination order and block partition the tile path would use (perm[new] = KKT index, blk_ptr[nblk + 1]); returns the
 // number of blocks, < 0 on error.  Development aid for ordering studies (tools/dev), no GPU needed.
 int eicos_debug_host_tile_order(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
-                                const int *Ajc, const int *Air, int order_mode, int *perm, int *blk_ptr, int *stats) {
+                                const int *Ajc, const int *Air, int order_mode, int *perm, int *blk_ptr, int *stats, int *Lp, int *Li) {
     try {
         ProblemPattern P;
         P.n = n; P.m = m; P.p = p; P.nc = ncones; P.q.assign(q, q + ncones);
@@ -1403,6 +1403,8 @@ int eicos_debug_host_tile_order(int n, int m, int p, int ncones, const int *q, c
         TilePlan TP = build_tile_plan(S);
         if (perm) std::copy(S.perm.begin(), S.perm.end(), perm);
         if (blk_ptr) std::copy(S.blk_ptr.begin(), S.blk_ptr.end(), blk_ptr);
+        if (Lp) std::copy(S.Lp.begin(), S.Lp.end(), Lp);
+        if (Li) std::copy(S.Li.begin(), S.Li.end(), Li);
         if (stats) { stats[0] = S.N; stats[1] = S.nnzL; stats[2] = TP.nb; stats[3] = TP.nt; stats[4] = TP.nblev; stats[5] = (int)std::min<int64_t>(TP.npairs, 2147483647); stats[6] = S.order_mode; stats[7] = S.cone_order; }
         return S.nblk;
     } catch (const std::exception &e) { g_err = e.what(); return -2; }

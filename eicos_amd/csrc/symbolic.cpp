@@ -287,9 +287,14 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
         ivec perm1(N), iperm1(N);
         for (int k = 0; k < N; k++) { perm1[k] = perm0[post[k]]; iperm1[perm1[k]] = k; }
         ivec par1;
-        { auto up = permuted_upper(N, S.K_row, S.K_col, iperm1); etree_rows(N, up, par1, &rows); }
         std::vector<ivec> cols(N); // structure of column j of L (rows > j), ascending
-        for (int i = 0; i < N; i++) for (int j : rows[i]) cols[j].push_back(i);
+        auto structure = [&]() {
+            auto up = permuted_upper(N, S.K_row, S.K_col, iperm1);
+            etree_rows(N, up, par1, &rows);
+            for (auto &c : cols) c.clear();
+            for (int i = 0; i < N; i++) for (int j : rows[i]) cols[j].push_back(i);
+        };
+        structure();
         // supernodes: node k joins node k-1 when struct(k-1) \ {k} == struct(k) (a chain of the tree: fundamental
         // supernode) or struct(k-1) == struct(k) (siblings with one common front, e.g. the rows of one second-order cone)
         auto joins = [&](int a, int b) {
@@ -298,6 +303,33 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
             if (ca.size() == cb.size() + 1 && !ca.empty() && ca[0] == b) return std::equal(cb.begin(), cb.end(), ca.begin() + 1);
             return false;
         };
+        {   // The TOP of the tree: small supernodes all of whose ancestors are small supernodes too (on the dense-front config the
+            // variables shared by two neighbouring cones: 28 supernodes of 1..3 nodes).  In the postorder each of them follows the
+            // subtrees of its children, so they are no neighbours and the amalgamation below cannot merge them -- every one stays a
+            // block whose tiles hold one to three rows (22 % of that config's tiles hold a single row).  The set is closed under
+            // "parent of", so moving it behind all other nodes, in its own postorder, is again a topological order of the tree (same
+            // fill); its supernodes then are neighbours.
+            ivec sn_of(N), sn_first, sn_size;
+            for (int k = 0; k < N; k++) { if (k == 0 || !joins(k - 1, k)) { sn_first.push_back(k); sn_size.push_back(0); } sn_of[k] = (int)sn_first.size() - 1; sn_size.back()++; }
+            const int nsn = (int)sn_first.size();
+            std::vector<char> top(nsn, 0);
+            int ntop = 0;
+            for (int s = nsn - 1; s >= 0; s--) { // (a supernode's parent supernode has a larger number: parents follow children)
+                const int last = sn_first[s] + sn_size[s] - 1, pr = par1[last];
+                top[s] = sn_size[s] <= 8 && (pr < 0 || top[sn_of[pr]]);
+                ntop += top[s];
+            }
+            if (ntop >= 2) {
+                ivec ord; ord.reserve(N);
+                for (int k = 0; k < N; k++) if (!top[sn_of[k]]) ord.push_back(k);
+                for (int k = 0; k < N; k++) if (top[sn_of[k]]) ord.push_back(k);
+                ivec perm2(N);
+                for (int k = 0; k < N; k++) perm2[k] = perm1[ord[k]];
+                perm1.swap(perm2);
+                for (int k = 0; k < N; k++) iperm1[perm1[k]] = k;
+                structure();
+            }
+        }
         // Fundamental supernodes first (no size limit), then RELAXED AMALGAMATION of supernodes that are neighbours in the postorder,
         // then every (merged) supernode is cut into blocks of 16.  Any partition into runs of consecutive nodes is correct for the tile
         // code (tiles.cpp derives tiles, pairs and levels from the scalar pattern; structural zeros inside a tile are just zeros), so the

@@ -230,10 +230,11 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
 double eicos_debug_host_check_tiles(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
                                     const int *Ajc, const int *Air, unsigned seed, int order_mode, int *stats);
 
-/* host-only: elimination order (perm[dim_K]: new -> KKT index) and block partition (blk_ptr[blocks + 1]) of the tile path; returns the
+/* host-only: elimination order (perm[dim_K]: new -> KKT index), block partition (blk_ptr[blocks + 1]) and L pattern of the tile path; returns the
  * number of blocks; stats = {dim_K, nnzL, blocks, off-diagonal tiles, block levels, tile pairs, order_mode, cone_order} */
 int eicos_debug_host_tile_order(int n, int m, int p, int ncones, const int *q, const int *Gjc, const int *Gir,
-                                const int *Ajc, const int *Air, int order_mode, int *perm, int *blk_ptr, int *stats);
+                                const int *Ajc, const int *Air, int order_mode, int *perm, int *blk_ptr, int *stats,
+                                int *Lp /* [dim_K + 1] or NULL */, int *Li /* [nnzL] or NULL: the pattern of L in that order, CSC */);
 
 /* the same for the hybrid path (scalar programs below the cut, tiles on the top block of the tree); returns -10 when the
  * pattern's schedule has no tail worth handing to the tile path */
