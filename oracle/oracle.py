@@ -41,9 +41,15 @@ def build_native() -> str | None:
     object must not travel between machines: liboracle_native.so is git- and gpurun-ignored); None if the compiler is missing."""
     so = os.path.join(_HERE, "liboracle_native.so")
     src = os.path.join(_HERE, "eicos_oracle.cpp")
+    tag = so + ".host"  # which CPU the object was built for: a copy that travelled here from another machine is rebuilt, never run
     try:
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        import hashlib
+        cpu = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+        sig = hashlib.sha256("".join(cpu).encode()).hexdigest()
+        have = open(tag).read().strip() if os.path.exists(tag) else ""
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) or have != sig:
             subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            open(tag, "w").write(sig)
     except (OSError, subprocess.CalledProcessError):
         return None
     return so
