@@ -50,6 +50,14 @@ def test_ecos_shim_and_demo_compile():
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", inc, src])
         subprocess.check_call(["g++", "-std=c++17", "-I", inc, os.path.join(ROOT, "examples", "run_demo.cpp"),
                                "-L", os.path.join(ROOT, "eicos_amd"), "-leicos_amd", "-o", os.path.join(d, "run_demo")])
+        # ... and the multi-GPU demo (EiCOS::BatchSolver over a device list, include/eicos.hpp on top of eicos_multi_*); without a GPU
+        # it must fail loudly at creation, naming the shard (no CPU fallback)
+        exe = os.path.join(d, "multi_gpu_demo")
+        subprocess.check_call(["g++", "-std=c++17", "-I", inc, os.path.join(ROOT, "examples", "multi_gpu_demo.cpp"),
+                               "-L", os.path.join(ROOT, "eicos_amd"), "-leicos_amd", "-Wl,-rpath," + os.path.join(ROOT, "eicos_amd"), "-o", exe])
+        if eicos_amd.device_count() == 0:
+            out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "lp_afiro.epb"), "4", "0,0"], capture_output=True, text=True)
+            assert out.returncode != 0 and "no HIP device" in out.stderr and "shard 0" in out.stderr, out.stderr
 
 
 @pytest.mark.skipif(eicos_amd.device_count() > 0, reason="GPU present")

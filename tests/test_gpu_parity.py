@@ -999,6 +999,18 @@ def test_bench_emits_the_contract_json_line():
     assert len(out.stdout.strip().splitlines()[-1]) < 6144
 
 
+def test_bench_multi_flag_drives_the_product_multi_gpu_layer():
+    # bench.py --multi IDS: the benchmark step from ONE process through eicos_multi_* (device list {0, 0} on this box)
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--multi", "0,0", "--total", "128",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["config"]["total_instances"] == 128 and d["config"]["optimal"] == 128
+    assert "eicos_multi" in d["config"]["io"] and "(0, 64, 0), (64, 64, 0)" in d["config"]["io"] and d["value"] > 0
+
+
 def test_dynamic_regularisation_extension_matches_oracle():
     # N4 (extension, off by default): same rule on both sides -> same result on the instance whose pivot cancels in
     # the oracle's elimination order; and switching it on must not disturb a well-conditioned batch
