@@ -517,7 +517,13 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_STRIP);
     put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
     TileFactorOps TFO;
-    if (tile) TFO = build_tile_factor_ops(TP, h->threads / 64, TILE_FTRIP);
+    if (tile) {
+        // pure tile mode: tiles of the K image no KKT entry lands in (targets that exist through fill only) start from zero without
+        // a load; the image tile they would have read stays zero and is never touched (hybrid: the scalar program writes every tile)
+        std::vector<char> img_zero((size_t)TP.nb + TP.nt, tile1 ? 1 : 0);
+        for (int d : img_dst) img_zero[d / 256] = 0;
+        TFO = build_tile_factor_ops(TP, h->threads / 64, TILE_FTRIP, &img_zero);
+    }
     put(D.tl_facops, TFO.ops); put(D.tl_facptr, TFO.ptr);
     put(D.tl_ident, TP.ident);
     put(D.tl_trow, TP.t_row); put(D.tl_tcol, TP.t_col); put(D.tl_tc_ptr, TP.tc_ptr); put(D.tl_tr_ptr, TP.tr_ptr); put(D.tl_tr_tile, TP.tr_tile);

@@ -197,7 +197,7 @@ constexpr int TILE_FPF = EICOS_TILE_FPF;         // operations (two tiles + a D 
 constexpr int TILE_FTRIP = TILE_FPF;             // operations per trip of the unrolled loops (factor / sweeps): see ELL_TRIP; op lists are padded to a multiple
 constexpr int TILE_STRIP = 6;                    // (longer trips measured in round 3: no change on the bandwidth-bound tile path)
 static_assert(TILE_FTRIP % TILE_FPF == 0 && TILE_STRIP % TILE_PF == 0, "the register queues rotate inside a trip");
-constexpr int FOP_INIT = 1, FOP_END = 2, FOP_PAD = 4, FOP_SHIFT = 4; // tile factor op flags: start a target from its K tile / finish it / padding; target id above
+constexpr int FOP_INIT = 1, FOP_END = 2, FOP_PAD = 4, FOP_ZERO = 8, FOP_SHIFT = 4; // tile factor op flags: start a target from its K tile / finish it / padding / (with INIT) the K tile is structurally zero: start from 0, no 2 KB load; target id above
 constexpr int TILE_SCR = 16 * 17;   // doubles of LDS scratch per wavefront in tile mode (one padded 16 x 16 tile)
 constexpr int TRACE_COLS = 12, TRACE_ROWS = 102; // per-iteration history rows (iter 0..100)
 constexpr int CONE_BIG = 32;       // cones of at least this dimension get a wavefront each

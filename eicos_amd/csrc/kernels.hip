@@ -1254,7 +1254,7 @@ __device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int i
             const d4_t a = qa[u], b = qb[u], dd = qd[u];
             load(o + uu + TILE_FPF, qa[u], qb[u], qd[u]);
             const int fl = op.w, tg = fl >> FOP_SHIFT;
-            if (fl & FOP_INIT) acc = a;
+            if (fl & FOP_INIT) acc = (fl & FOP_ZERO) ? d4_t{0., 0., 0., 0.} : a; // (a structurally zero K tile: its load went to image tile 0, which stays cached)
             else if (!(fl & FOP_PAD)) {
 #pragma unroll
                 for (int st = 0; st < 4; st++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[st], b[st] * dd[st], acc, 0, 0, 0);

@@ -108,7 +108,7 @@ TilePlan build_tile_plan(const Symbolic &S) {
     return T;
 }
 
-TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf) {
+TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf, const std::vector<char> *img_zero) {
     TileFactorOps F;
     F.ptr.assign(1, 0);
     for (int v = 0; v < T.nblev; v++) {
@@ -124,7 +124,8 @@ TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf) {
         for (int w = 0; w < NW; w++) {
             for (int q : mine[w]) {
                 const int tg = T.tgt[q], p0 = T.tp_ptr[q], p1 = T.tp_ptr[q + 1];
-                F.ops.insert(F.ops.end(), {tg, 0, 0, FOP_INIT | (p0 == p1 ? FOP_END : 0) | (tg << FOP_SHIFT)});
+                const int zero = (img_zero && (*img_zero)[tg]) ? FOP_ZERO : 0; // (tg indexes the K image: diagonal tiles first, then the off-diagonal ones)
+                F.ops.insert(F.ops.end(), {zero ? 0 : tg, 0, 0, FOP_INIT | zero | (p0 == p1 ? FOP_END : 0) | (tg << FOP_SHIFT)});
                 for (int e = p0; e < p1; e++) F.ops.insert(F.ops.end(), {T.pa[e], T.pb[e], T.pk[e], (e + 1 == p1 ? FOP_END : 0) | (tg << FOP_SHIFT)});
             }
             while (((int)F.ops.size() / 4 - F.ptr.back()) % pf) F.ops.insert(F.ops.end(), {0, 0, 0, FOP_PAD}); // (unconditional loads: see build_tile_sweeps)

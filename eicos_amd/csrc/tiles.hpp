@@ -65,7 +65,8 @@ struct TileFactorOps {
     std::vector<int> ops;  // 4 ints per op
     std::vector<int> ptr;  // [nblev * NW + 1]
 };
-TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf);
+// img_zero (optional, [nb + nt]): 1 = that tile of the K image holds no KKT entry (a pure fill tile): its INIT operation carries FOP_ZERO
+TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf, const std::vector<char> *img_zero = nullptr);
 
 TilePlan build_tile_plan(const Symbolic &S);
 
