@@ -8,7 +8,7 @@ using namespace eicos;
 
 namespace eicos {
 template <int T>
-__global__ __launch_bounds__(T, (waves_per_eu<T, 1>())) void k_bench_base(const PackedSlice *fsl, const PackedSlice *bsl, int nfs, int nfs_solo, int nbs_solo, int nbs,
+__global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_bench_base(const PackedSlice *fsl, const PackedSlice *bsl, int nfs, int nfs_solo, int nbs_solo, int nbs,
         const int *fidx16, const int *bidx16, int f_d16, int b_d16, const double *UF, const double *UB, const double *invD, size_t sUF, size_t sUB, size_t sD,
         const double *rhs, double *out, int N, int Npad, int nUF, int nUB, int reps) {
     gcdbl_p uf = (gcdbl_p)(UF + (size_t)blockIdx.x * sUF), ub = (gcdbl_p)(UB + (size_t)blockIdx.x * sUB), id = (gcdbl_p)(invD + (size_t)blockIdx.x * sD);
