@@ -700,7 +700,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 // ---------------- lambda = W z (ref scale :485-507); ends with a barrier ----------------
 // CONES_ONLY: the LP rows were done by the caller inside a fused pass (same product, out[i] = lpw[i] * zz[i])
 template <int T, bool CONES_ONLY = false>
-__device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out) {
     ps = uni(ps); W = uni_ptr(W); zz = uni_ptr(zz); out = uni_ptr(out);
     const DevPat &P = c_pat[ps];
     gcdbl_p lpw = W + P.w_lpw, csc = W + P.w_csc, qv = W + P.w_qv;
@@ -746,7 +746,7 @@ __device__ __noinline__ void dev_scale(int ps, gcdbl_p W, gcdbl_p zz, gdbl_p out
 
 // ---------------- bringToCone (ref :761-805): s = sgn*r shifted into the cone ----------------
 template <int T>
-__device__ __noinline__ void dev_bring_to_cone(int ps, gcdbl_p r, double sgn, gdbl_p s) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void dev_bring_to_cone(int ps, gcdbl_p r, double sgn, gdbl_p s) {
     ps = uni(ps); r = uni_ptr(r); s = uni_ptr(s);
     const DevPat &P = c_pat[ps];
     int phase = 0;
@@ -772,7 +772,7 @@ __device__ __noinline__ void dev_bring_to_cone(int ps, gcdbl_p r, double sgn, gd
 // ---------------- lineSearch (ref :1380-1469); result to every thread ----------------
 // LP_DONE: the caller has formed the LP rows' min(ds / lam), min(dz / lam) per thread inside a fused pass (rmin0, smin0)
 template <int T, bool LP_DONE = false>
-__device__ __noinline__ double dev_line_search(int ps, gcdbl_p W, double tau, double dtau,
+static __device__ __noinline__ __attribute__((not_tail_called)) double dev_line_search(int ps, gcdbl_p W, double tau, double dtau,
                                                double kap, double dkap, double rmin0 = DBL_MAX, double smin0 = DBL_MAX) {
     ps = uni(ps); W = uni_ptr(W);
     const DevPat &P = c_pat[ps];
@@ -981,7 +981,7 @@ enum Stage { ST_FACTOR = 0, ST_KKT_INIT1, ST_KKT_INIT2, ST_RESID, ST_KKT1, ST_KK
 // ---------------- ST_FACTOR: numeric LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
 // Wg = the workgroup's workspace slab.  Left-looking sliced-ELL program over the level schedule (host: plans.cpp, api.cpp).
 template <int T, int NLDS, bool I16, bool DEFER>
-__device__ __noinline__ void stage_factor(int ps, gdbl_p Wg) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void stage_factor(int ps, gdbl_p Wg) {
     ps = uni(ps); Wg = uni_ptr(Wg);
     const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x;
@@ -1215,7 +1215,7 @@ __device__ __forceinline__ d4_t tile_ld(gcdbl_p base, int t, int lane) { return 
 
 // ---------------- ST_FACTOR, tile mode: left-looking block LDL' (replaces ldlt.factorize, ref :900,1164) ----------------
 template <int T, int NLDS>
-__device__ __noinline__ int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int iter) {
+static __device__ __noinline__ __attribute__((not_tail_called)) int stage_factor_tiles(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
     constexpr int NW = T / 64;
@@ -1542,7 +1542,7 @@ __device__ __forceinline__ IterBuf iter_buf(const DevPat &P, gdbl_p I, gdbl_p W,
 
 // ---------------- ST_RESID: residuals, statistics, exit logic, scalings ----------------
 template <int T, int NLDS, bool I16>
-__device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
+static __device__ __noinline__ __attribute__((not_tail_called)) int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
     STAGE_PROLOGUE
     iter = uni(iter);
     gcdbl_p cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
@@ -1921,7 +1921,7 @@ __device__ __noinline__ int stage_resid(int ps, gdbl_p I, gdbl_p W, int iter) {
 // flag): the loop runs until both have stopped, one that has stopped keeps its iterate while the other takes further
 // steps (its lanes still compute, the result is discarded).  amask: bit k set = right-hand side k takes part.
 template <int T, int NLDS, bool I16, int KI, bool DUAL = false>
-__device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, int stage, int amask) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, int stage, int amask) {
     ps = uni(ps); I0 = uni_ptr(I0); I1 = uni_ptr(I1); Wg = uni_ptr(Wg); stage = uni(stage); amask = uni(amask);
     const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, N = P.N, np = P.n + P.p;
@@ -2281,7 +2281,7 @@ __device__ __noinline__ void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, 
 // RF: the register-resident fast path (below) for the affine / combined stages -- its own instantiation, so that the generic one keeps
 // the code (and instruction-cache footprint) it had; kkt_post_any picks per pattern.
 template <int T, bool RF>
-__device__ __noinline__ int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
+static __device__ __noinline__ __attribute__((not_tail_called)) int kkt_post(int ps, gdbl_p I, gdbl_p W, int stage) {
     ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W); stage = uni(stage);
     const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, np = P.n + P.p;
@@ -2569,7 +2569,7 @@ __device__ __forceinline__ int kkt_post_any(int ps, gdbl_p I, gdbl_p W, int stag
 
 // ---------------- per-instance prologue of a solve (its state ends up in g_S); returns 1 if it was warm-started ----------------
 template <int T>
-__device__ __noinline__ int instance_begin(int ps, gdbl_p I, gdbl_p W, double warm) {
+static __device__ __noinline__ __attribute__((not_tail_called)) int instance_begin(int ps, gdbl_p I, gdbl_p W, double warm) {
     ps = uni(ps); I = uni_ptr(I); W = uni_ptr(W);
     const DevPat &P = c_pat[ps];
     const int n = P.n, p = P.p, m = P.m, l = P.l, np = P.n + P.p;
