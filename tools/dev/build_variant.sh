@@ -10,9 +10,10 @@ F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-parameter ${FPC:--ffp-contract=off} $*
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F -c kernels_ldsres.hip -o $out/kernels_ldsres.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $F -c kernels_w2.hip -o $out/kernels_w2.o &
 /opt/rocm/bin/hipcc $F -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c api.cpp -o $out/api.o
+/opt/rocm/bin/hipcc $F -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -pthread -c multi.cpp -o $out/multi.o
 /opt/rocm/bin/hipcc $F -x c++ -c symbolic.cpp -o $out/symbolic.o
 /opt/rocm/bin/hipcc $F -x c++ -c plans.cpp -o $out/plans.o
 /opt/rocm/bin/hipcc $F -x c++ -c tiles.cpp -o $out/tiles.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build_exp/lib$tag.so $out/kernels.o $out/kernels_ldsres.o $out/kernels_w2.o $out/api.o $out/symbolic.o $out/plans.o $out/tiles.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -pthread -o ../../build_exp/lib$tag.so $out/kernels.o $out/kernels_ldsres.o $out/kernels_w2.o $out/api.o $out/multi.o $out/symbolic.o $out/plans.o $out/tiles.o
 echo built build_exp/lib$tag.so
