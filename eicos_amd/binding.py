@@ -87,6 +87,12 @@ def _lib():
         L.eicos_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_last_update_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_destroy.argtypes = [vp]
+        L.eicos_batch_last_update_path.argtypes = [vp]
+        L.eicos_batch_last_update_path.restype = C.c_int
+        L.eicos_host_alloc.argtypes = [C.c_size_t]
+        L.eicos_host_alloc.restype = vp
+        L.eicos_host_free.argtypes = [vp]
+        L.eicos_host_free.restype = C.c_int
         L.eicos_debug_factor.argtypes = [vp, C.c_int, dp, dp]
         L.eicos_debug_pattern.argtypes = [vp, ip, ip, ip]
         L.eicos_debug_trace.argtypes = [vp, C.c_int, dp]
@@ -139,6 +145,34 @@ def _ip(a):
 
 def _dp(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class PinnedArray:
+    """A float64 array in pinned host memory (eicos_host_alloc): `.a` is the numpy view.  updateData reads such arrays in place over PCIe
+    (no bounce copy), solution() / duals() write into them with one strided copy.  Freed by close() or with the object."""
+
+    def __init__(self, shape):
+        shape = tuple(int(v) for v in (shape if hasattr(shape, "__len__") else (shape,)))
+        n = int(np.prod(shape)) if shape else 1
+        self._p = _lib().eicos_host_alloc(max(n, 1) * 8)
+        if not self._p:
+            raise RuntimeError("eicos_host_alloc failed: " + _lib().eicos_last_error().decode())
+        self.a = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_double)), shape=(max(n, 1),))[:n].reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.a = None
+            _lib().eicos_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+UPDATE_PATHS = {0: "none", 1: "pinned bounce", 2: "pinned source in place", 3: "peer GPU in place", 4: "staged peer copies"}
 
 
 class BatchSolver:
@@ -251,6 +285,17 @@ class BatchSolver:
         ms = C.c_float()
         _chk(_lib().eicos_batch_last_update_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def last_update_path(self) -> str:
+        """How the most recent host-pointer / peer updateData moved its inputs (UPDATE_PATHS)."""
+        return UPDATE_PATHS[_lib().eicos_batch_last_update_path(self._h)]
+
+    def solution_into(self, x):
+        """solution() into a caller-owned [batch, n] float64 array (e.g. a PinnedArray's `.a`: one strided device-to-host copy)."""
+        assert x.dtype == np.float64 and x.flags.c_contiguous and x.shape == (self.batch, self.pat.n)
+        if self.pat.n:
+            _chk(_lib().eicos_batch_solution(self._h, _dp(x)))
+        return x
 
     def debug_factor(self, inst: int = 0):
         d = self.dims()
@@ -380,6 +425,14 @@ class MultiBatchSolver:
         hh, c = C.c_void_p(), C.c_int()
         _mchk(_lib().eicos_multi_shard(self._h, s, C.byref(hh), None, C.byref(c), None))
         _chk(_lib().eicos_batch_update_device(hh, 0, c.value, *[C.c_void_p(int(p) or None) for p in (dG, dA, dc, dh, db)]))
+
+    def shard_last_update(self, s: int):
+        """(path, HIP-event ms) of shard s's most recent updateData."""
+        hh = C.c_void_p()
+        _mchk(_lib().eicos_multi_shard(self._h, s, C.byref(hh), None, None, None))
+        ms = C.c_float()
+        _chk(_lib().eicos_batch_last_update_ms(hh, C.byref(ms)))
+        return UPDATE_PATHS[_lib().eicos_batch_last_update_path(hh)], float(ms.value)
 
     def shard_dims(self, s: int = 0) -> dict:
         hh = C.c_void_p()

@@ -10,9 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_types.hpp"
@@ -26,7 +31,7 @@ using namespace eicos;
 
 static thread_local std::string g_err;
 static std::mutex g_slot_mu;
-static bool g_slot_used[16][64];
+static std::map<int, std::vector<char>> g_slot_used; // per device: which constant-memory descriptor slots are taken (under g_slot_mu)
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -52,7 +57,15 @@ struct eicos_batch {
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
     int *d_queue = nullptr; // instance queue of the solve kernel (reset per launch)
-    double *d_stage = nullptr; size_t stage_doubles = 0; // host-pointer updateData: persistent staging buffer (one chunk)
+    double *d_stage = nullptr; size_t stage_doubles = 0; // peer-copy updateData without peer access: persistent staging buffer (one chunk)
+    // host-pointer updateData / results (the reference's real signature: updateData(double *...), solution() on the host): two PINNED
+    // bounce buffers (hipHostMalloc).  Input chunk k is copied into pin[k & 1] by the host while the GPU's updateData kernel reads chunk
+    // k - 1 straight out of the other one over PCIe (the kernel's loads are the transfer: no device-side staging copy, no per-chunk
+    // stream synchronisation); results come back through the same buffers, the strided device-to-host copy of chunk k + 1 in flight
+    // while the host copies chunk k out.  pin_ev[i]: the last GPU work that touches pin[i].
+    double *pin[2] = {nullptr, nullptr}; size_t pin_doubles = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_busy[2] = {false, false};
+    int last_update_path = 0; // how the most recent host/peer updateData moved its inputs: 1 pinned bounce, 2 zero-copy (pinned source), 3 peer zero-copy, 4 peer staged copies
     int *d_flag = nullptr;   // debug hooks
     double warm_shift = 0.; // > 0: warm start (eicos_batch_set_warm_start)
     double dyn_delta = 0., dyn_eps = 0.; // > 0: dynamic regularisation (eicos_batch_set_dynamic_regularization)
@@ -542,10 +555,15 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return bail(EICOS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
-    // (device set-up -- kernel attributes, occupancy probes, allocations, the constant-memory slot -- one handle at a time: the shards
-    // of an eicos_multi are created on parallel host threads, which overlaps their symbolic analyses above)
-    static std::mutex g_create_mu;
-    std::lock_guard<std::mutex> create_lock(g_create_mu);
+    // (device set-up -- kernel attributes, occupancy probes, allocations, the constant-memory slot; the shards of an eicos_multi are
+    // created on parallel host threads, which overlaps their symbolic analyses above)
+    // One lock PER DEVICE: the shards of an eicos_multi that live on different GPUs set their devices up in parallel, two handles on one
+    // GPU still take turns (the occupancy probes and hipFuncSetAttribute calls of one device must not interleave).
+    static std::mutex g_create_map_mu;
+    static std::map<int, std::mutex> g_create_mu;
+    std::mutex *dev_mu;
+    { std::lock_guard<std::mutex> lk(g_create_map_mu); dev_mu = &g_create_mu[device]; }
+    std::lock_guard<std::mutex> create_lock(*dev_mu);
     HIP_TRY_H(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY_H(hipGetDeviceProperties(&prop, device));
@@ -616,12 +634,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         }
     }
     int bpc = 1;
-    if (h->ldsres) {
-        HIP_TRY_H(ldsres::solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
-        HIP_TRY_H(ldsres::solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
-    } else {
-        HIP_TRY_H(solve_set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
-        HIP_TRY_H(solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
+    {
+        const SolveBuild sb = solve_build(h->threads, h->ldsres, false);
+        HIP_TRY_H(sb.set_max_lds(h->threads, h->nlds, h->dp.idx16, h->dyn_lds));
+        HIP_TRY_H(sb.occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &bpc));
     }
     bpc = std::max(1, std::min(bpc, 8));
     HIP_TRY_H(update_set_max_lds()); // (per handle = per device, after hipSetDevice: the entry-parallel updateData kernels use up to 160 KB of dynamic LDS)
@@ -649,8 +665,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         HIP_TRY_H(w2::solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &got));
         if (got >= bpc) h->w2 = 1;
     }
-    auto v_set_max_lds = h->w2 ? w2::solve_set_max_lds : solve_set_max_lds;
-    auto v_occupancy = h->w2 ? w2::solve_occupancy : solve_occupancy;
+    const SolveBuild sbuild = solve_build(h->threads, h->ldsres, h->w2);
+    auto v_set_max_lds = sbuild.set_max_lds;
+    auto v_occupancy = sbuild.occupancy;
     // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
     // scattered stores and the read-back stay on chip.  Verified against the runtime's occupancy for the enlarged allocation.
     D.e_lds = 0; D.e_off = 0;
@@ -693,12 +710,13 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     D.fac_sl = reinterpret_cast<const PackedSlice *>(fac_sl_p);
     {
         std::lock_guard<std::mutex> lk(g_slot_mu);
-        for (int q = 0; q < max_patterns() && q < 64; q++) if (!g_slot_used[device % 16][q]) { h->pslot = q; g_slot_used[device % 16][q] = true; break; }
+        std::vector<char> &used = g_slot_used[device];
+        used.resize((size_t)max_patterns(), 0);
+        for (int q = 0; q < max_patterns(); q++) if (!used[q]) { h->pslot = q; used[q] = 1; break; }
     }
     if (h->pslot < 0) return bail(EICOS_E_INVALID, "too many live handles on this device (64)");
-    HIP_TRY_H(upload_pattern(h->pslot, h->dp));
-    if (h->ldsres) HIP_TRY_H(ldsres::upload_pattern(h->pslot, h->dp));
-    if (h->w2) HIP_TRY_H(w2::upload_pattern(h->pslot, h->dp));
+    HIP_TRY_H(upload_pattern(h->pslot, h->dp)); // (the default namespace always: updateData and the debug kernels live there)
+    if (sbuild.upload != upload_pattern) HIP_TRY_H(sbuild.upload(h->pslot, h->dp));
     HIP_TRY_H(hipMalloc(&h->d_inst, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMemset(h->d_inst, 0, (size_t)batch * D.inst_stride * sizeof(double)));
     HIP_TRY_H(hipMalloc(&h->d_work, (size_t)h->grid * D.work_stride * sizeof(double)));
@@ -752,8 +770,9 @@ int eicos_batch_destroy(eicos_batch *h) {
     for (void *ptr : {(void *)h->d_pattern, (void *)h->d_inst, (void *)h->d_work, (void *)h->d_queue, (void *)h->d_scratch,
                       (void *)h->d_stage, (void *)h->d_flag})
         if (ptr) (void)hipFree(ptr);
+    for (int i = 0; i < 2; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
     // the constant-memory descriptor slot is handed out again only after nothing can read it any more
-    if (h->pslot >= 0) { std::lock_guard<std::mutex> lk(g_slot_mu); g_slot_used[h->device % 16][h->pslot] = false; }
+    if (h->pslot >= 0) { std::lock_guard<std::mutex> lk(g_slot_mu); g_slot_used[h->device][h->pslot] = 0; }
     delete h;
     return EICOS_OK;
 }
@@ -789,8 +808,108 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     return EICOS_OK;
 }
 
-// updateData from buffers that are not on the handle's device: host memory (src_dev < 0) or the HBM of another GPU (src_dev = that
-// device: peer copies over xGMI, eicos_multi_update_device) -- staged through the handle's persistent buffer in chunks of 256 instances
+// ---- host memory helpers -------------------------------------------------------------------------------------------------
+// A few persistent host threads that split large memcpy calls between pageable and pinned memory (one core copies ~10 GB/s, a PCIe 5
+// x16 link moves ~50 GB/s: a single-threaded bounce copy would be the slowest stage of a host-pointer updateData).  Shared by every
+// handle of the process, started on first use, joined at exit.
+namespace {
+class CopyPool {
+  public:
+    static CopyPool &get() { static CopyPool p; return p; }
+    // dst[0, bytes) = src[0, bytes), cut into pieces of >= 1 MB over the pool's threads and the caller
+    void copy(void *dst, const void *src, size_t bytes) {
+        const size_t piece = 1u << 20;
+        const int parts = (int)std::min<size_t>((size_t)nthreads_ + 1, (bytes + piece - 1) / piece);
+        if (parts <= 1) { std::memcpy(dst, src, bytes); return; }
+        const size_t per = ((bytes + parts - 1) / parts + 63) & ~(size_t)63;
+        std::atomic<int> left{parts - 1};
+        std::mutex done_mu; std::condition_variable done_cv;
+        for (int k = 1; k < parts; k++) {
+            const size_t a = std::min(bytes, (size_t)k * per), b = std::min(bytes, a + per);
+            push([=, &left, &done_mu, &done_cv] {
+                if (b > a) std::memcpy((char *)dst + a, (const char *)src + a, b - a);
+                if (left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(done_mu); done_cv.notify_one(); }
+            });
+        }
+        std::memcpy(dst, src, std::min(bytes, per));
+        std::unique_lock<std::mutex> lk(done_mu);
+        done_cv.wait(lk, [&] { return left.load() == 0; });
+    }
+  private:
+    CopyPool() {
+        const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+        nthreads_ = (int)std::min(6u, hc > 2 ? hc / 2 - 1 : 0u);
+        for (int i = 0; i < nthreads_; i++) th_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void push(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); } cv_.notify_one(); }
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front()); q_.erase(q_.begin());
+            }
+            f();
+        }
+    }
+    int nthreads_ = 0; bool stop_ = false;
+    std::vector<std::thread> th_;
+    std::vector<std::function<void()>> q_;
+    std::mutex mu_; std::condition_variable cv_;
+};
+
+// Is `p` host memory the GPU can address directly (hipHostMalloc / hipHostRegister / eicos_host_alloc)?  Then kernels read or write it
+// in place over PCIe and no bounce copy is needed.
+bool is_pinned_host(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // (plain malloc memory: "invalid value")
+    return a.type == hipMemoryTypeHost;
+}
+// the handle's two pinned bounce buffers hold at least `doubles` each
+int ensure_pin(eicos_batch *h, size_t doubles) {
+    if (doubles <= h->pin_doubles) return EICOS_OK;
+    for (int i = 0; i < 2; i++) {
+        if (h->pin_busy[i]) { HIP_TRY(hipEventSynchronize(h->pin_ev[i])); h->pin_busy[i] = false; }
+        if (h->pin[i]) { (void)hipHostFree(h->pin[i]); h->pin[i] = nullptr; }
+        if (!h->pin_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
+    }
+    h->pin_doubles = 0;
+    for (int i = 0; i < 2; i++) HIP_TRY(hipHostMalloc((void **)&h->pin[i], doubles * sizeof(double), hipHostMallocDefault));
+    h->pin_doubles = doubles;
+    return EICOS_OK;
+}
+constexpr size_t PIN_CHUNK_BYTES = 16u << 20; // bounce buffer size aimed at (per buffer)
+} // namespace
+
+void *eicos_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g_err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+int eicos_host_free(void *p) {
+    if (!p) return EICOS_OK;
+    HIP_TRY(hipHostFree(p));
+    return EICOS_OK;
+}
+int eicos_batch_last_update_path(eicos_batch *h) { return h ? h->last_update_path : fail(EICOS_E_INVALID, "NULL handle"); }
+
+// updateData from buffers that are not in the handle's HBM: host memory (src_dev < 0) or the HBM of another GPU (src_dev = that device,
+// eicos_multi_update_device).
+//   host, pageable : rows go through the two pinned bounce buffers in chunks -- the host copies chunk k + 1 in (CopyPool) while the
+//                    updateData kernel of chunk k reads its inputs straight from the other buffer over PCIe; returns when the last chunk
+//                    has been COPIED (the caller's arrays are free again), the kernels are still in flight on the handle's stream
+//   host, pinned   : (every given array addressable by the GPU) ONE kernel launch reads the caller's arrays in place; the call
+//                    waits for it, so that the caller may overwrite them on return -- the reference's updateData is synchronous too
+//   peer, access on: the kernel reads the other GPU's HBM in place over xGMI (asynchronous, like eicos_batch_update_device)
+//   peer, no access: hipMemcpyPeerAsync into a device staging buffer, chunk by chunk
 int eicos_internal_update_staged(eicos_batch *h, int first, int count, const double *G, const double *A,
                                  const double *c, const double *hh, const double *b, int src_dev) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
@@ -799,39 +918,99 @@ int eicos_internal_update_staged(eicos_batch *h, int first, int count, const dou
     if (G && !hh && D.m > 0) return fail(EICOS_E_INVALID, "Gpr given without h");
     if (A && !b && D.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
-    const int chunk = 256;
-    const size_t per = (size_t)D.nnzG + D.nnzA + D.n + D.m + D.p + 5 * 8;
-    // persistent staging buffer (one chunk), grown on demand and freed with the handle: no hipMalloc/hipFree (a
-    // device-wide synchronisation) on the MPC closed-loop path
-    const size_t need = (size_t)std::min(count > 0 ? count : 1, chunk) * per;
-    if (need > h->stage_doubles) {
-        if (h->d_stage) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_stage); h->d_stage = nullptr; h->stage_doubles = 0; }
-        HIP_TRY(hipMalloc(&h->d_stage, need * sizeof(double)));
-        h->stage_doubles = need;
+    if (count == 0) return EICOS_OK;
+    const double *hv = G ? hh : nullptr, *bv = A ? b : nullptr; // (h is read only with Gpr, b only with Apr: reference src/eicos.cpp:2053-2074)
+    struct Arr { const double *src; size_t w; };
+    const Arr arr[5] = {{G, (size_t)D.nnzG}, {A, (size_t)D.nnzA}, {c, (size_t)D.n}, {hv, (size_t)D.m}, {bv, (size_t)D.p}};
+    size_t per = 0; // doubles per instance that are actually given (+ 8 of padding per array keeps every row 64-byte aligned)
+    for (const Arr &a : arr) if (a.src) per += a.w;
+    if (per == 0) { // nothing given: everything is kept -- still a valid updateData (re-equilibrates what is there)
+        return eicos_batch_update_device(h, first, count, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
-    double *stage = h->d_stage;
-    int rc = EICOS_OK;
+    auto whole_range = [&](int path) { // one launch on the caller's pointers
+        h->last_update_path = path;
+        return eicos_batch_update_device(h, first, count, G, A, c, hv, bv);
+    };
+    if (src_dev >= 0) {
+        int can = 0;
+        if (src_dev == h->device) can = 1;
+        else if (hipDeviceCanAccessPeer(&can, h->device, src_dev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can && src_dev != h->device) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src_dev, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+            (void)hipGetLastError();
+        }
+        if (can && !env_knob("EICOS_PEER_STAGED", 0, 0, 1)) return whole_range(3);
+        // no peer access: staged peer copies, one chunk at a time through the device staging buffer
+        h->last_update_path = 4;
+        const int chunk = 256;
+        const size_t need = (size_t)std::min(count, chunk) * (per + 5 * 8);
+        if (need > h->stage_doubles) {
+            if (h->d_stage) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_stage); h->d_stage = nullptr; h->stage_doubles = 0; }
+            HIP_TRY(hipMalloc(&h->d_stage, need * sizeof(double)));
+            h->stage_doubles = need;
+        }
+        int rc = EICOS_OK;
+        HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+        h->in_chunked_update = true;
+        for (int o = 0; o < count && rc == EICOS_OK; o += chunk) {
+            const int cnt = std::min(chunk, count - o);
+            const double *dptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            double *at = h->d_stage;
+            for (int k = 0; k < 5 && rc == EICOS_OK; k++) {
+                if (!arr[k].src) continue;
+                dptr[k] = at;
+                if (arr[k].w && hipMemcpyPeerAsync(at, h->device, arr[k].src + (size_t)o * arr[k].w, src_dev, (size_t)cnt * arr[k].w * sizeof(double), h->stream) != hipSuccess)
+                    rc = fail(EICOS_E_HIP, "hipMemcpyPeerAsync failed");
+                at += (size_t)cnt * arr[k].w + 8;
+            }
+            if (rc == EICOS_OK) rc = eicos_batch_update_device(h, first + o, cnt, dptr[0], dptr[1], dptr[2], dptr[3], dptr[4]);
+            // the staging buffer is reused by the next chunk
+            if (rc == EICOS_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(EICOS_E_HIP, "stream sync failed in update");
+        }
+        h->in_chunked_update = false;
+        if (rc == EICOS_OK) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
+        return rc;
+    }
+    // ---- host pointers ----
+    bool all_pinned = true;
+    for (const Arr &a : arr) if (a.src && a.w && !is_pinned_host(a.src)) all_pinned = false;
+    if (all_pinned && !env_knob("EICOS_HOST_BOUNCE", 0, 0, 1)) {
+        const int rc = whole_range(2);
+        if (rc != EICOS_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream)); // the caller may overwrite its arrays on return
+        return EICOS_OK;
+    }
+    h->last_update_path = 1;
+    const size_t row = per + 5 * 8;
+    int chunk = (int)std::max<size_t>(16, PIN_CHUNK_BYTES / (row * sizeof(double)));
+    chunk = std::min(chunk, count);
+    if (count > chunk && count < 2 * chunk) chunk = (count + 1) / 2; // two even chunks rather than a long one and a stub
+    int rc = ensure_pin(h, (size_t)chunk * row);
+    if (rc != EICOS_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
     h->in_chunked_update = true;
-    for (int o = 0; o < count && rc == EICOS_OK; o += chunk) {
-        const int cnt = std::min(chunk, count - o);
-        double *dG = stage, *dA = dG + (size_t)cnt * D.nnzG + 8, *dc = dA + (size_t)cnt * D.nnzA + 8;
-        double *dh = dc + (size_t)cnt * D.n + 8, *db = dh + (size_t)cnt * D.m + 8;
-        auto up = [&](double *dst, const double *src, size_t w) -> hipError_t {
-            if (!src || w == 0) return hipSuccess;
-            if (src_dev >= 0) return hipMemcpyPeerAsync(dst, h->device, src + (size_t)o * w, src_dev, (size_t)cnt * w * sizeof(double), h->stream);
-            return hipMemcpyAsync(dst, src + (size_t)o * w, (size_t)cnt * w * sizeof(double), hipMemcpyHostToDevice, h->stream);
-        };
-        hipError_t e = up(dG, G, D.nnzG);
-        if (e == hipSuccess) e = up(dA, A, D.nnzA);
-        if (e == hipSuccess) e = up(dc, c, D.n);
-        if (e == hipSuccess && G) e = up(dh, hh, D.m);
-        if (e == hipSuccess && A) e = up(db, b, D.p);
-        if (e != hipSuccess) { rc = fail(EICOS_E_HIP, hipGetErrorString(e)); break; }
-        rc = eicos_batch_update_device(h, first + o, cnt, G ? dG : nullptr, A ? dA : nullptr, c ? dc : nullptr,
-                                       G ? dh : nullptr, A ? db : nullptr);
-        // the staging buffer is reused by the next chunk, and the caller may reuse its host arrays on return
-        if (rc == EICOS_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(EICOS_E_HIP, "stream sync failed in update");
+    CopyPool &pool = CopyPool::get();
+    int k = 0;
+    for (int o = 0; o < count && rc == EICOS_OK; o += chunk, k++) {
+        const int cnt = std::min(chunk, count - o), bi = k & 1;
+        if (h->pin_busy[bi]) { // the kernel that read this buffer two chunks ago (or an earlier call's) must have finished
+            if (hipEventSynchronize(h->pin_ev[bi]) != hipSuccess) { rc = fail(EICOS_E_HIP, "event sync failed in update"); break; }
+            h->pin_busy[bi] = false;
+        }
+        const double *dptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        double *at = h->pin[bi];
+        for (int q = 0; q < 5; q++) {
+            if (!arr[q].src) continue;
+            dptr[q] = at;
+            if (arr[q].w) pool.copy(at, arr[q].src + (size_t)o * arr[q].w, (size_t)cnt * arr[q].w * sizeof(double));
+            at += (size_t)cnt * arr[q].w + 8;
+        }
+        rc = eicos_batch_update_device(h, first + o, cnt, dptr[0], dptr[1], dptr[2], dptr[3], dptr[4]); // reads the pinned buffer in place
+        if (rc == EICOS_OK) {
+            if (hipEventRecord(h->pin_ev[bi], h->stream) != hipSuccess) rc = fail(EICOS_E_HIP, "event record failed in update");
+            else h->pin_busy[bi] = true;
+        }
     }
     h->in_chunked_update = false;
     if (rc == EICOS_OK) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
@@ -847,15 +1026,8 @@ int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    if (h->ldsres)
-        HIP_TRY(ldsres::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
-                                     h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
-    else if (h->w2)
-        HIP_TRY(w2::launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
-                                 h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
-    else
-        HIP_TRY(launch_solve(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds, h->dp.idx16,
-                             h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
+    HIP_TRY(solve_build(h->threads, h->ldsres, h->w2).launch(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds,
+                                                             h->dp.idx16, h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     h->last_ordered = h->batch > h->order_min;
@@ -869,11 +1041,40 @@ int eicos_batch_sync(eicos_batch *h) {
     return EICOS_OK;
 }
 
+// rows [off, off + width) of every instance slab -> dst[batch][width] on the host.  Pinned destination: one strided device-to-host copy
+// straight into it.  Pageable destination: chunks through the two pinned bounce buffers, the copy of chunk k + 1 in flight while the
+// host copies chunk k out (a strided hipMemcpy2D into pageable memory is staged by the runtime row by row).
 static int fetch_rows(eicos_batch *h, double *dst, int off, int width) {
     if (!dst || width == 0) return EICOS_OK;
-    HIP_TRY(hipMemcpy2D(dst, (size_t)width * sizeof(double), h->d_inst + off, h->dp.inst_stride * sizeof(double),
-                        (size_t)width * sizeof(double), (size_t)h->batch, hipMemcpyDeviceToHost));
-    return EICOS_OK;
+    const size_t wb = (size_t)width * sizeof(double), pitch = h->dp.inst_stride * sizeof(double);
+    if (is_pinned_host(dst) || (size_t)h->batch * wb < (256u << 10)) {
+        HIP_TRY(hipMemcpy2DAsync(dst, wb, h->d_inst + off, pitch, wb, (size_t)h->batch, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return EICOS_OK;
+    }
+    int chunk = (int)std::max<size_t>(16, PIN_CHUNK_BYTES / wb);
+    chunk = std::min(chunk, h->batch);
+    int rc = ensure_pin(h, (size_t)chunk * width);
+    if (rc != EICOS_OK) return rc;
+    chunk = (int)std::min<size_t>((size_t)h->batch, h->pin_doubles / (size_t)width); // (the buffers may be larger than asked for)
+    for (int i = 0; i < 2; i++) if (h->pin_busy[i]) { HIP_TRY(hipEventSynchronize(h->pin_ev[i])); h->pin_busy[i] = false; }
+    CopyPool &pool = CopyPool::get();
+    auto issue = [&](int o, int bi) -> int {
+        const int cnt = std::min(chunk, h->batch - o);
+        HIP_TRY(hipMemcpy2DAsync(h->pin[bi], wb, h->d_inst + (size_t)o * h->dp.inst_stride + off, pitch, wb, (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->pin_ev[bi], h->stream));
+        return EICOS_OK;
+    };
+    rc = issue(0, 0);
+    int k = 0;
+    for (int o = 0; o < h->batch && rc == EICOS_OK; o += chunk, k++) {
+        const int cnt = std::min(chunk, h->batch - o), bi = k & 1;
+        if (o + chunk < h->batch) rc = issue(o + chunk, bi ^ 1);
+        if (rc != EICOS_OK) break;
+        HIP_TRY(hipEventSynchronize(h->pin_ev[bi]));
+        pool.copy(dst + (size_t)o * width, h->pin[bi], (size_t)cnt * wb);
+    }
+    return rc;
 }
 
 int eicos_batch_info(eicos_batch *h, eicos_info *info) {

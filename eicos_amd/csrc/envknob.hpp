@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace eicos {
 inline bool experiments_enabled() {
@@ -15,6 +16,8 @@ inline bool experiments_enabled() {
 // A knob that is set but not honoured (no opt-in, or a value outside its range) is reported on stderr -- once per knob and process --
 // so that an A/B script cannot silently measure the default path.
 inline void knob_warn(const char *name, const char *why) {
+    static std::mutex mu; // (handles are created on parallel host threads: eicos_multi_create)
+    std::lock_guard<std::mutex> lk(mu);
     static char seen[32][40];
     static int nseen = 0;
     for (int i = 0; i < nseen; i++) if (std::strncmp(seen[i], name, 39) == 0) return;

@@ -49,7 +49,14 @@
 #ifndef EICOS_W2
 #define EICOS_W2 0
 #endif
-#define EICOS_MAIN_BUILD (!EICOS_LDSRES && !EICOS_W2)
+// Two more compilations split the default build by workgroup size, so that the five translation units compile side by side (a clean
+// build is bounded by the slowest one instead of by the sum of eighteen k_solve instantiations): EICOS_TSPLIT = 128 (kernels_t128.o,
+// namespace eicos::t128) and 512 (kernels_t512.o, namespace eicos::t512) hold the 128- / 512-thread solve kernels at their default
+// register budgets; kernels.o keeps the 256-thread one (168 VGPRs), updateData and the debug kernels.
+#ifndef EICOS_TSPLIT
+#define EICOS_TSPLIT 0
+#endif
+#define EICOS_MAIN_BUILD (!EICOS_LDSRES && !EICOS_W2 && !EICOS_TSPLIT)
 
 namespace eicos {
 #if EICOS_LDSRES
@@ -63,6 +70,12 @@ typedef double EICOS_DATA *gdbl_p;        // (shadow the global-memory typedefs 
 typedef const double EICOS_DATA *gcdbl_p;
 #elif EICOS_W2
 namespace w2 {
+#define EICOS_DATA EICOS_GLOBAL
+#elif EICOS_TSPLIT == 128
+namespace t128 {
+#define EICOS_DATA EICOS_GLOBAL
+#elif EICOS_TSPLIT == 512
+namespace t512 {
 #define EICOS_DATA EICOS_GLOBAL
 #else
 #define EICOS_DATA EICOS_GLOBAL
@@ -3087,12 +3100,10 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
         if (nlds == 1) return f((const void *)k_solve<T, 1, false>);
         return f((const void *)k_solve<T, 0, false>);
     };
-#if EICOS_W2
-    return byT(std::integral_constant<int, 256>{}); // (this build exists for 256 threads only)
+#if EICOS_TSPLIT
+    return byT(std::integral_constant<int, EICOS_TSPLIT>{}); // (this build exists for one workgroup size only)
 #else
-    if (threads == 512) return byT(std::integral_constant<int, 512>{});
-    if (threads == 128) return byT(std::integral_constant<int, 128>{});
-    return byT(std::integral_constant<int, 256>{});
+    return byT(std::integral_constant<int, 256>{}); // (kernels.o / kernels_w2.o: 256 threads; 128 and 512 live in kernels_t128.o / kernels_t512.o)
 #endif
 }
 #endif
@@ -3176,6 +3187,10 @@ hipError_t upload_pattern(int ps, const DevPat &P) {
 } // namespace ldsres
 #elif EICOS_W2
 } // namespace w2
+#elif EICOS_TSPLIT == 128
+} // namespace t128
+#elif EICOS_TSPLIT == 512
+} // namespace t512
 #else
 int max_patterns() { return MAX_PATTERNS; }
 #endif

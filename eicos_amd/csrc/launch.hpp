@@ -31,4 +31,35 @@ hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
 } // namespace w2
+// the 128- and 512-thread k_solve of the default build, in their own translation units (kernels_t128.hip / kernels_t512.hip = kernels.hip
+// compiled with EICOS_TSPLIT): the default namespace keeps the 256-thread one
+namespace t128 {
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
+hipError_t upload_pattern(int ps, const DevPat &P);
+} // namespace t128
+namespace t512 {
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
+hipError_t upload_pattern(int ps, const DevPat &P);
+} // namespace t512
+// one k_solve build = these four entry points
+struct SolveBuild {
+    decltype(&launch_solve) launch;
+    decltype(&solve_occupancy) occupancy;
+    decltype(&solve_set_max_lds) set_max_lds;
+    decltype(&upload_pattern) upload;
+};
+// the build a handle's solves run: LDS-resident (128 threads), two-waves-per-SIMD (256 threads), or the default one of its workgroup size
+inline SolveBuild solve_build(int threads, bool ldsres, bool w2) {
+    if (ldsres) return {ldsres::launch_solve, ldsres::solve_occupancy, ldsres::solve_set_max_lds, ldsres::upload_pattern};
+    if (w2) return {w2::launch_solve, w2::solve_occupancy, w2::solve_set_max_lds, w2::upload_pattern};
+    if (threads == 128) return {t128::launch_solve, t128::solve_occupancy, t128::solve_set_max_lds, t128::upload_pattern};
+    if (threads == 512) return {t512::launch_solve, t512::solve_occupancy, t512::solve_set_max_lds, t512::upload_pattern};
+    return {launch_solve, solve_occupancy, solve_set_max_lds, upload_pattern};
+}
 } // namespace eicos

@@ -8,8 +8,13 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,27 +23,59 @@ extern "C" int eicos_internal_update_staged(eicos_batch *h, int first, int count
                                             const double *c, const double *hh, const double *b, int src_dev);
 extern "C" int eicos_internal_device(const eicos_batch *h);
 
+namespace {
+// One persistent host thread per shard: blocking calls of the shards (symbolic analysis at creation, the chunked host-pointer
+// updateData, result copies) overlap across GPUs without a thread being created per call.  post() hands the worker one job, wait()
+// blocks until it has run.
+class Worker {
+  public:
+    Worker() : th_([this] { run(); }) {}
+    ~Worker() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); job_ = std::move(f); has_ = true; done_ = false; } cv_.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return done_; }); }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return stop_ || has_; }); if (!has_) return; f = std::move(job_); has_ = false; }
+            f();
+            { std::lock_guard<std::mutex> lk(mu_); done_ = true; }
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_;
+    std::function<void()> job_;
+    bool has_ = false, done_ = true, stop_ = false;
+    std::thread th_; // (last member: the thread starts after the state above is initialised)
+};
+} // namespace
+
 struct eicos_multi {
     int batch = 0, n = 0, m = 0, p = 0, nnzG = 0, nnzA = 0;
     std::vector<eicos_batch *> shard;
     std::vector<int> first, count, device;
+    std::vector<std::unique_ptr<Worker>> worker; // one per shard (none for a single shard: the caller's thread does the work)
+    std::mutex call_mu;                          // one fan-out at a time (the workers hold one job each)
 };
 
 namespace {
 thread_local std::string g_merr;
 int mfail(int code, const std::string &msg) { g_merr = msg; return code; }
-// run fn(s) for every shard on its own host thread (blocking calls such as the chunked host-pointer updateData overlap across
-// GPUs); returns the first failing shard's code and message
+// run fn(s) for every shard on the shard's host thread; returns the first failing shard's code and message
 template <class F> int for_shards(eicos_multi *mh, F &&fn) {
     const int ns = (int)mh->shard.size();
     std::vector<int> rc(ns, EICOS_OK);
     std::vector<std::string> msg(ns);
     auto body = [&](int s) { rc[s] = fn(s); if (rc[s] != EICOS_OK) msg[s] = eicos_last_error(); };
-    if (ns == 1) body(0);
+    if (ns == 1 || mh->worker.empty()) { for (int s = 0; s < ns; s++) body(s); }
     else {
-        std::vector<std::thread> th;
-        for (int s = 0; s < ns; s++) th.emplace_back(body, s);
-        for (auto &t : th) t.join();
+        std::lock_guard<std::mutex> lk(mh->call_mu);
+        for (int s = 0; s < ns; s++) mh->worker[s]->post([&body, s] { body(s); });
+        for (int s = 0; s < ns; s++) mh->worker[s]->wait();
     }
     for (int s = 0; s < ns; s++) if (rc[s] != EICOS_OK) return mfail(rc[s], "shard " + std::to_string(s) + " (device " + std::to_string(mh->device[s]) + "): " + msg[s]);
     return EICOS_OK;
@@ -69,17 +106,47 @@ int eicos_multi_create(int n, int m, int p, int l, int ncones, const int *q, con
     eicos_multi *mh = new eicos_multi();
     mh->batch = batch;
     mh->shard.assign(ndev, nullptr); mh->first.resize(ndev); mh->count.resize(ndev); mh->device.assign(device_ids, device_ids + ndev);
+    // a negative id means "the caller's current device": resolved HERE, on the calling thread (a worker thread's current device is 0)
+    {
+        int cur = 0, nvis = 0;
+        if (hipGetDeviceCount(&nvis) != hipSuccess || nvis == 0) {
+            const int d0 = mh->device[0];
+            delete mh;
+            return mfail(EICOS_E_NOGPU, "shard 0 (device " + std::to_string(d0) + "): no HIP device visible: the solver has no CPU fallback");
+        }
+        if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+        for (int &d : mh->device) { if (d < 0) d = cur; if (d >= nvis) { delete mh; return mfail(EICOS_E_INVALID, "device index out of range (" + std::to_string(nvis) + " visible)"); } }
+    }
+    if (ndev > 1) for (int s = 0; s < ndev; s++) mh->worker.emplace_back(new Worker());
     const int base = batch / ndev, rem = batch % ndev; // contiguous shards, the first `rem` one instance longer (= eicos_amd.generate.shard_range)
     for (int s = 0; s < ndev; s++) { mh->first[s] = s * base + std::min(s, rem); mh->count[s] = base + (s < rem ? 1 : 0); }
     // every shard analyses the pattern and sets up its device on its own host thread (the analysis is deterministic: identical plans)
     const int rc = for_shards(mh, [&](int s) {
-        return eicos_batch_create(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, mh->count[s], device_ids[s], &mh->shard[s]);
+        return eicos_batch_create(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, mh->count[s], mh->device[s], &mh->shard[s]);
     });
     if (rc != EICOS_OK) { const std::string keep = g_merr; eicos_multi_destroy(mh); g_merr = keep; return rc; }
     eicos_dims d;
     eicos_batch_dims(mh->shard[0], &d);
     mh->n = d.n; mh->m = d.m; mh->p = d.p; mh->nnzG = d.nnzG; mh->nnzA = d.nnzA;
-    for (int s = 0; s < ndev; s++) mh->device[s] = eicos_internal_device(mh->shard[s]); // (a negative id was resolved to the current device)
+    // Peer access between every pair of distinct devices of the list, both directions: eicos_multi_update_device then reads inputs that
+    // live on one GPU in place over xGMI.  A pair without it (or a failure to enable it) falls back to staged peer copies -- noted once.
+    int caller_dev = 0;
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = 0;
+    for (int a = 0; a < ndev; a++)
+        for (int b = 0; b < ndev; b++) {
+            const int da = mh->device[a], db = mh->device[b];
+            if (da == db) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+            hipError_t e = hipErrorUnknown;
+            if (can && hipSetDevice(da) == hipSuccess) e = hipDeviceEnablePeerAccess(db, 0);
+            (void)hipGetLastError();
+            if (!can || (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)) {
+                static bool noted = false;
+                if (!noted) { noted = true; std::fprintf(stderr, "[eicos_amd] no peer access from device %d to device %d: eicos_multi_update_device will stage peer copies\n", da, db); }
+            }
+        }
+    (void)hipSetDevice(caller_dev); // (enabling peer access switched devices: the caller's current device is restored)
     *out = mh;
     return EICOS_OK;
 }
@@ -113,10 +180,10 @@ int eicos_multi_update_device(eicos_multi *mh, int src_device, int first, int co
     if (src_device < 0) return mfail(EICOS_E_INVALID, "src_device must name the GPU that holds the inputs");
     return for_range(mh, first, count, [&](int s, int f, int cnt, size_t off) {
         const double *G = at(dGpr, off, mh->nnzG), *A = at(dApr, off, mh->nnzA), *cc = at(dc, off, mh->n), *hh = at(dh, off, mh->m), *bb = at(db, off, mh->p);
-        // (experiment knob, honoured like the others only under EICOS_EXPERIMENT=1: take the peer-copy path even on the source GPU, so
-        // that a single-GPU box exercises it -- hipMemcpyPeerAsync with equal devices is a device-to-device copy)
-        static const bool force_peer = [] { const char *e = std::getenv("EICOS_EXPERIMENT"), *k = std::getenv("EICOS_MULTI_FORCE_PEER");
-                                            return e && !std::strcmp(e, "1") && k && !std::strcmp(k, "1"); }();
+        // (experiment knob, honoured like the others only under EICOS_EXPERIMENT=1 and read on EVERY call: take the other-GPU path even on
+        // the source GPU, so that a single-GPU box exercises it; eicos_batch_last_update_path tells which path a shard took)
+        const char *e_ = std::getenv("EICOS_EXPERIMENT"), *k_ = std::getenv("EICOS_MULTI_FORCE_PEER");
+        const bool force_peer = e_ && !std::strcmp(e_, "1") && k_ && !std::strcmp(k_, "1");
         if (mh->device[s] == src_device && !force_peer) return eicos_batch_update_device(mh->shard[s], f, cnt, G, A, cc, hh, bb); // already in this GPU's HBM: no copy
         return eicos_internal_update_staged(mh->shard[s], f, cnt, G, A, cc, hh, bb, src_device);                  // peer copies (xGMI), then the same kernel
     });

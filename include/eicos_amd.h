@@ -96,6 +96,16 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
 int eicos_batch_update(eicos_batch *hd, int first, int count,
                        const double *Gpr, const double *Apr,
                        const double *c, const double *h, const double *b);
+/* How the host arrays travel (csrc/api.cpp: eicos_internal_update_staged).  PAGEABLE arrays (plain malloc / std::vector / numpy) go through
+ * two pinned bounce buffers in chunks of ~16 MB: the host copies chunk k + 1 in while the updateData kernel of chunk k reads its inputs
+ * straight out of the other buffer over PCIe; the call returns once the last chunk has been copied (the arrays are the caller's again),
+ * with the kernels still in flight on the handle's stream.  PINNED arrays (eicos_host_alloc below, hipHostMalloc, hipHostRegister) are
+ * read in place by ONE kernel launch; the call waits for it, so the arrays may be overwritten on return -- as with the reference's
+ * synchronous updateData.  eicos_batch_last_update_path tells which path the most recent call took (1 bounce, 2 pinned in place,
+ * 3 peer GPU in place, 4 staged peer copies). */
+void *eicos_host_alloc(size_t bytes); /* pinned host memory the GPU addresses directly; NULL on failure */
+int eicos_host_free(void *p);
+int eicos_batch_last_update_path(eicos_batch *hd);
 /* Same, DEVICE pointers (inputs already resident in HBM; no PCIe traffic). */
 int eicos_batch_update_device(eicos_batch *hd, int first, int count,
                               const double *dGpr, const double *dApr,
@@ -110,7 +120,8 @@ int eicos_batch_solve_async(eicos_batch *hd);
 int eicos_batch_sync(eicos_batch *hd);
 
 /* ---- results: replaces solution() (reference include/eicos.hpp:160) / getInfo() (:163).
- * x: [batch][n] host.  y,z,s are extras the reference keeps private; any may be NULL. */
+ * x: [batch][n] host.  y,z,s are extras the reference keeps private; any may be NULL.  A pinned destination receives one strided
+ * device-to-host copy; a pageable one is filled through the pinned bounce buffers (copy of chunk k + 1 in flight while chunk k is copied out). */
 int eicos_batch_solution(eicos_batch *hd, double *x);
 int eicos_batch_duals(eicos_batch *hd, double *y, double *z, double *s);
 int eicos_batch_info(eicos_batch *hd, eicos_info *info /* [batch] */);
@@ -176,11 +187,13 @@ typedef struct eicos_multi eicos_multi; /* opaque */
 int eicos_multi_create(int n, int m, int p, int l, int ncones, const int *q,
                        const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                        int batch, const int *device_ids, int ndev, eicos_multi **out);
-/* updateData from HOST arrays: every shard stages its rows over its own GPU's PCIe link, all shards in parallel (one host thread each) */
+/* updateData from HOST arrays: every shard moves its rows over its own GPU's PCIe link (eicos_batch_update's pinned bounce pipeline), all
+ * shards in parallel -- one persistent host thread per shard, started by eicos_multi_create */
 int eicos_multi_update(eicos_multi *mh, int first, int count, const double *Gpr, const double *Apr,
                        const double *c, const double *h, const double *b);
-/* updateData from arrays resident in the HBM of ONE GPU (src_device): shards on that GPU read them in place, the others pull their
- * rows with peer copies (hipMemcpyPeerAsync: xGMI) on their own streams -- the "batch scatter" of north_star without a collective */
+/* updateData from arrays resident in the HBM of ONE GPU (src_device): shards on that GPU read them in place; the others read their rows
+ * in place as well, over xGMI (peer access is enabled between the listed devices at creation), or -- without peer access -- pull them with
+ * staged hipMemcpyPeerAsync copies on their own streams: the "batch scatter" of north_star without a collective */
 int eicos_multi_update_device(eicos_multi *mh, int src_device, int first, int count, const double *dGpr, const double *dApr,
                               const double *dc, const double *dh, const double *db);
 /* solve: async = enqueue every shard's kernels on its stream and return; sync waits for all; eicos_multi_solve = both (+ exit codes, may be NULL) */
