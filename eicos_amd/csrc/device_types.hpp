@@ -68,6 +68,10 @@ static_assert(ELL_KMAX == 4, "the packed index entries hold four 16-bit indices 
 #ifndef EICOS_TRI_DEPTH_SOLO
 #define EICOS_TRI_DEPTH_SOLO 3
 #endif
+#ifndef EICOS_TRI_DEPTH_W2
+#define EICOS_TRI_DEPTH_W2 2
+#endif
+constexpr int TRI_DEPTH_W2 = EICOS_TRI_DEPTH_W2; // queue depth in GROUPS of two slices when a sweep step takes two slices of a level at once (DevPat::tri_w = 2)
 constexpr int TRI_DEPTH_SOLO = EICOS_TRI_DEPTH_SOLO; // queue depth (= slices per trip) of the single-wavefront part of the sweeps
 constexpr int TRI_DEPTH = EICOS_TRI_DEPTH; // ... this many slices ahead of their use (plans are padded to a multiple)
 #ifndef EICOS_TRI_TRIP
@@ -127,6 +131,7 @@ struct DevPat {
     const PackedSlice EICOS_GLOBAL *fsl; const PackedSlice EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;   // nfs / nbs = slices of the workgroup-wide part of the forward / backward plan
     int nfs_solo, nbs_solo;   // single-wavefront part (top of the tree): fsl = [wide | solo], bsl = [solo | wide]
+    int tri_w;                // slices per sweep step (kernels.hip: tri_sweep<..., W>): 2 = every level of both plans holds an even number of slices
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
     gint_p f_idx, b_idx;

@@ -610,7 +610,13 @@ __device__ __forceinline__ void lds_barrier() {
 // workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
 // VSH (dual right-hand sides of ONE instance): the vector ws is KI-interleaved, the factor (eval, invD) is a single one.
-template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class WS>
+// W (1 or 2): slices per step.  The slices of one level are independent, but a wavefront walks them one after the other -- LDS gathers,
+// multiply-adds, lane reduction, store -- and at two wavefronts per SIMD nobody hides that chain.  W = 2 (DevPat::tri_w; the host pads
+// every level of the plan to an even number of slices, so a group never straddles a level): the gathers of BOTH slices of a group are
+// issued before the first multiply, one dependent chain per group instead of per slice (MPC02, 256 threads: 52 groups instead of 77
+// slice steps per solve).  A row cut into sub-slices may continue inside a group: the continuation reads what its predecessor stored,
+// same lane, program order.
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, int W = 1, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
     // KI = 2 (with VSH): the two right-hand sides of a dual solve -- one factor, the sweep vector ws 2-interleaved, so every
@@ -618,12 +624,13 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
     // the narrow tree top (SOLO, one wavefront) runs short steps: the same lead time needs a deeper queue than the workgroup-wide levels
-    constexpr int DEPTH = SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH;
-    constexpr int TRIP = SOLO ? ((TRI_TRIP + TRI_DEPTH_SOLO - 1) / TRI_DEPTH_SOLO) * TRI_DEPTH_SOLO : TRI_TRIP; // (a multiple of the queue depth)
+    // (queue depth and trip length count GROUPS of W slices)
+    constexpr int DEPTH = W == 2 ? TRI_DEPTH_W2 : (SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH);
+    constexpr int TRIP = ((TRI_TRIP / W + DEPTH - 1) / DEPTH) * DEPTH; // (a multiple of the queue depth)
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
         int row0, lg, K, off, lanes, newlev, more, cont;
         int idx[ELL_KMAX]; double val[ELL_KMAX][KI]; double d[KI], own[KI];
-    } q[DEPTH];
+    } q[DEPTH][W];
     // every slice issues the same number of global loads per lane (inactive lanes / padding read the plan's dummy
     // slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
     auto load = [&](int s, Slot &o) {
@@ -655,57 +662,67 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
         } else ldK_g<KI, false>(invD, r, o.d);
         ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
-    // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
+    // ns is a multiple of W * DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) load(d < ns ? d : 0, q[d]);
-    // one slice step; `d` = the slice's slot of the register queue.  A trip of TRI_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
-    // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of TRI_DEPTH, so
-    // plans are padded to a multiple of TRI_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int w = 0; w < W; w++) load(d * W + w < ns ? d * W + w : 0, q[d][w]);
+    // one step = one group of W slices; `d` = the group's slot of the register queue, s = its first slice.  A trip of TRIP groups is unrolled (the
+    // compiler's s_waitcnt insertion is exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in
+    // trips of the queue depth, so plans are padded to a multiple of W * DEPTH only -- a padded slice costs a full step of the dependent chain
+    // on small patterns
     auto step = [&](const int d, const int s) __attribute__((always_inline)) {
-        const Slot c = q[d];
-        load(min(s + DEPTH, ns - 1), q[d]);
-        if (c.newlev) {
+        Slot c[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) c[w] = q[d][w];
+#pragma unroll
+        for (int w = 0; w < W; w++) load(min(s + DEPTH * W + w, ns - 1), q[d][w]);
+        if (c[0].newlev) { // (only the first slice of a group can open a level)
             if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
             else if (LDSBAR) lds_barrier();
             else __syncthreads();
         }
-        double xg[ELL_KMAX][KI]; // all gathers in flight before the first multiply (the scheduler would serialise them)
+        double xg[W][ELL_KMAX][KI]; // all gathers in flight before the first multiply (the scheduler would serialise them)
 #pragma unroll
-        for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, c.idx[kk], xg[kk]);
+        for (int w = 0; w < W; w++)
+#pragma unroll
+            for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, c[w].idx[kk], xg[w][kk]);
         __builtin_amdgcn_sched_barrier(0);
-        double acc[KI];
 #pragma unroll
-        for (int k = 0; k < KI; k++) {
-            double a = 0.;
-#pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) a = madd(a, c.val[kk][k], xg[kk][k]);
-            acc[k] = grp_reduce_to_lane0(a, c.lg);
-        }
-        if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
-            const int r = c.row0 + (t >> c.lg);
-            // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
-            // (same lane, program order), and only the last one applies the pivot
-            double cur[KI], out[KI];
-            if (c.cont) ldK<KI>(ws, r, cur);
+        for (int w = 0; w < W; w++) {
+            double acc[KI];
 #pragma unroll
             for (int k = 0; k < KI; k++) {
-                const double v = (c.cont ? cur[k] : c.own[k]) - acc[k];
-                out[k] = (FORWARD || c.more) ? v         // y_i = b_i - sum_k L[i,k] y_k
-                                             : v * c.d[k]; // x_j = (y_j - sum_i U[i,j] x_i) / D_j
+                double a = 0.;
+#pragma unroll
+                for (int kk = 0; kk < ELL_KMAX; kk++) a = madd(a, c[w].val[kk][k], xg[w][kk][k]);
+                acc[k] = grp_reduce_to_lane0(a, c[w].lg);
             }
-            stK<KI>(ws, r, out);
+            if (t < c[w].lanes && (t & ((1 << c[w].lg) - 1)) == 0) {
+                const int r = c[w].row0 + (t >> c[w].lg);
+                // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
+                // (same lane, program order), and only the last one applies the pivot
+                double cur[KI], out[KI];
+                if (c[w].cont) ldK<KI>(ws, r, cur);
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const double v = (c[w].cont ? cur[k] : c[w].own[k]) - acc[k];
+                    out[k] = (FORWARD || c[w].more) ? v              // y_i = b_i - sum_k L[i,k] y_k
+                                                    : v * c[w].d[k]; // x_j = (y_j - sum_i U[i,j] x_i) / D_j
+                }
+                stK<KI>(ws, r, out);
+            }
         }
-    
     };
     int s0 = 0;
-    for (; s0 + TRIP <= ns; s0 += TRIP) {
+    for (; s0 + TRIP * W <= ns; s0 += TRIP * W) {
 #pragma unroll
-        for (int u = 0; u < TRIP; u++) step(u % DEPTH, s0 + u);
+        for (int u = 0; u < TRIP; u++) step(u % DEPTH, s0 + u * W);
     }
-    for (; s0 < ns; s0 += DEPTH) { // remainder in trips of the queue depth (the host pads every section of a plan to a multiple of it)
+    for (; s0 < ns; s0 += DEPTH * W) { // remainder in trips of the queue depth (the host pads every section of a plan to a multiple of it)
 #pragma unroll
-        for (int u = 0; u < DEPTH; u++) step(u, s0 + u);
+        for (int u = 0; u < DEPTH; u++) step(u, s0 + u * W);
     }
     if (!SOLO) __syncthreads();
 }
@@ -2024,6 +2041,24 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         const bool wave0 = uni(tid >> 6) == 0;
         if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
             if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV);
+        } else if (KI == 1 && P.tri_w == 2) { // two slices of a level per step (plans padded per level by the host; pure scalar path, one right-hand side)
+            if constexpr (KI == 1 && NLDS >= 1) {
+                tri_sweep<T, true, true, false, I16, 1, false, 2>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                if (wave0) {
+                    tri_sweep<T, true, true, true, I16, 1, false, 2>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tri_sweep<T, false, true, true, I16, 1, false, 2>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                }
+                __syncthreads();
+                tri_sweep<T, false, true, false, I16, 1, false, 2>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            } else if constexpr (KI == 1) {
+                tri_sweep<T, true, false, false, I16, 1, false, 2>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                if (wave0) {
+                    tri_sweep<T, true, false, true, I16, 1, false, 2>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tri_sweep<T, false, false, true, I16, 1, false, 2>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                }
+                __syncthreads();
+                tri_sweep<T, false, false, false, I16, 1, false, 2>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            }
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
             tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
             if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down

@@ -258,8 +258,33 @@ def test_stage_functions_save_no_callee_saved_registers(tmp_path):
             m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
             if m and name and "k_solve" in name:
                 seen[name] = int(m.group(1))
-    assert len(seen) >= 20, seen  # three builds of kernels.hip
+    assert len(seen) >= 20, seen  # five builds of kernels.hip (per workgroup size, LDS-resident, two waves per SIMD)
     # measured with the saves: 816 (256-VGPR build of the 256-thread kernel), 528-560 (168-VGPR build), 912 (512 threads), 704 (LDS-resident)
     for name, size in seen.items():
         limit = 600 if ("w2" in name or "ldsres" in name or "ILi512E" in name) else 450
         assert size <= limit, (name, size)
+
+
+def test_bench_launch_mode_never_runs_fewer_gpus_than_asked():
+    """bench.py --gpus N: under torch.distributed.run it is one process per GPU; WITHOUT a launcher N > 1 takes the
+    product's own multi-GPU layer over devices 0..N-1 -- or exits non-zero; it never falls through to a 1-GPU run labelled N."""
+    import bench
+    lm = bench.launch_mode
+    assert lm(1, {}, None, lambda: 0) == ("single", None)
+    assert lm(1, {"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "29500"}, None, lambda: 0) == ("single", None)  # torchrun with one rank
+    assert lm(8, {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8", "MASTER_PORT": "29500"}, None, lambda: 8) == ("dist", None)
+    assert lm(8, {}, None, lambda: 8) == ("multi", list(range(8)))       # the driver's `python bench.py --gpus 8` on an 8-GPU node
+    assert lm(2, {}, None, lambda: 8) == ("multi", [0, 1])
+    assert lm(1, {}, "0,0,0", lambda: 1) == ("multi", [0, 0, 0])         # a device may be listed several times
+    for bad in ((8, {}, None, lambda: 1),                                # 8 asked, one visible: refuse, do not run one GPU as "8"
+                (4, {"RANK": "0", "WORLD_SIZE": "8", "MASTER_PORT": "1"}, None, lambda: 8),  # launcher world != --gpus
+                (1, {}, "0,1", lambda: 1),                               # --multi names a device that is not there
+                (2, {"RANK": "0", "WORLD_SIZE": "2", "MASTER_PORT": "1"}, "0,1", lambda: 2)):  # --multi under a launcher
+        with pytest.raises(SystemExit) as e:
+            lm(*bad)
+        assert e.value.code not in (0, None)
+    # without a GPU in this container the real entry point refuses --gpus 2 before importing torch.cuda or touching a device
+    if eicos_amd.device_count() == 0:
+        import subprocess, sys
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, cwd=ROOT)
+        assert out.returncode != 0 and "visible devices" in out.stderr and not out.stdout.strip()

@@ -1,8 +1,10 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
 inputs.  Tolerances (fp64): same exit code; iteration count within +-1;
-|pcost - pcost_ref| <= 1e-8 max(1,|pcost_ref|) for OPTIMAL instances; x to 1e-8 relative where
-the optimum is unique (checked on the strictly-feasible generated batches), otherwise objective
-+ residuals; pres/dres below the solver tolerance."""
+|pcost - pcost_ref| <= 1e-8 max(1,|pcost_ref|) for OPTIMAL instances; x to 1e-8 relative
+(||x - x_ref||_inf <= 1e-8 max(1, ||x_ref||_inf), north_star) on every instance of the full-size batches whose iteration count equals
+the oracle's (all of them on MPC02 / MPC-SOC / dense-front: _all_instances_against_the_oracle, measured maxima in its docstring);
+small random SOCPs with non-unique or ill-conditioned optima are held to 1e-6 / 1e-7 plus objective + residuals; pres/dres below the
+solver tolerance."""
 import numpy as np
 import pytest
 
@@ -118,7 +120,7 @@ def test_mpc_batch_soc():
     pat, sets = load_fixture("MPC02")
     spat = mpc_soc_variant(pat, sets[0])
     assert spat.ncones == 332 and spat.l == 3000
-    _check_batch(spat, feasible_batch(spat, sets[0], 0, 48), 48, 4, x_rtol=1e-7)
+    _check_batch(spat, feasible_batch(spat, sets[0], 0, 48), 48, 4, x_rtol=1e-8)
 
 
 def test_big_cone_wavefront_path():
@@ -519,10 +521,18 @@ def test_full_size_batch_properties():
     assert np.array_equal(g.solution(), x1)
     g.close()
     # ... and ALL 1024 instances against the oracle (1-2 s of CPU): exit code, iteration count +-1, pcost, x
-    _all_instances_against_the_oracle(pat, d, codes, ia, x)
+    _all_instances_against_the_oracle(pat, d, codes, ia, x, tag="MPC02 b1024")
 
 
-def _all_instances_against_the_oracle(pat, d, codes, ia, x, x_rtol=1e-6):
+def _all_instances_against_the_oracle(pat, d, codes, ia, x, x_rtol=1e-8, tag=None):
+    """Every instance against the oracle: exit code, iteration count +-1, pcost to 1e-8, and x to north_star's "within 1e-8 relative"
+    (||x - x_ref||_inf <= 1e-8 max(1, ||x_ref||_inf)) on the instances whose iteration counts agree.  Measured on the GPU box, round 5
+    (tools/dev/r5_xerr.py -> profiles/r05_log_xerr.log; iteration counts equal on every instance of all four workloads): MPC02 batch
+    1024 1.5e-12, batch 4096 4.6e-12, MPC-SOC batch 1024 7.9e-9, dense-front batch 512 3.8e-9.  An instance that stops one pass
+    earlier or later sits at a different point of the central path -- an IPM stopped at 1e-8 residuals pins x to about the gap tolerance
+    there -- so that group (empty on these workloads) is held to 1e-6 and must stay below 10 % of the batch.  The measured maxima are
+    printed (pytest -s) and appended to gpurun_out/parity_xerr.jsonl."""
+    import json
     import os
     from oracle import oracle as orc
     r = orc.batch_solve(pat, d["Gpr"], d["Apr"], d["c"], d["h"], d["b"], len(os.sched_getaffinity(0)), want_x=True)
@@ -530,10 +540,19 @@ def _all_instances_against_the_oracle(pat, d, codes, ia, x, x_rtol=1e-6):
     it_o, it_g = r["iters"].astype(int), ia["iter"].astype(int)
     assert np.all(np.abs(it_o - it_g) <= 1), np.flatnonzero(np.abs(it_o - it_g) > 1)
     assert np.all(np.abs(ia["pcost"] - r["pcost"]) <= PCOST_RTOL * np.maximum(1.0, np.abs(r["pcost"])))
-    same = it_o == it_g  # (one pass more or less ends at a different point of the central path: x then agrees to the gap tolerance only)
+    same = it_o == it_g
     assert same.sum() >= 0.9 * len(codes)
-    xs = np.maximum(1.0, np.abs(r["x"]).max(axis=1))
-    assert np.all(np.abs(x - r["x"]).max(axis=1)[same] <= x_rtol * xs[same])
+    err = np.abs(x - r["x"]).max(axis=1) / np.maximum(1.0, np.abs(r["x"]).max(axis=1))
+    rec = {"workload": tag or f"n={pat.n} m={pat.m} cones={pat.ncones} batch={len(codes)}", "iters_equal": int(same.sum()), "iters_pm1": int((~same).sum()),
+           "xerr_equal_max": float(err[same].max()), "xerr_pm1_max": float(err[~same].max()) if (~same).any() else None,
+           "pcost_rel_max": float((np.abs(ia["pcost"] - r["pcost"]) / np.maximum(1.0, np.abs(r["pcost"]))).max())}
+    print("x parity:", json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_xerr.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    assert np.all(err[same] <= x_rtol), (rec, np.flatnonzero(same & (err > x_rtol))[:8])
+    assert np.all(err[~same] <= 1e-6), rec
 
 
 def test_config4_dense_front_full_size():
@@ -560,7 +579,7 @@ def test_config4_dense_front_full_size():
     x1 = x.copy(); g.solve()
     assert np.array_equal(g.solution(), x1)                                        # idempotent re-solve, same bits
     # oracle parity on ALL 512 instances (~3 s on 16 cores): exit code, iteration count +-1, pcost to 1e-8, x
-    _all_instances_against_the_oracle(pat, d, codes, ia, x)
+    _all_instances_against_the_oracle(pat, d, codes, ia, x, tag="dense-front b512")
     g.close()
 
 
@@ -832,17 +851,88 @@ def test_multi_gpu_layer_two_shards_on_one_device_bit_identical(monkeypatch):
     m = eicos_amd.MultiBatchSolver(pat, B, [0, 0])
     m.update_device(0, ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"))  # inputs resident on GPU 0: read in place by both shards
     check(m)
+    assert m.shard_last_update(1)[0] == "none"  # (read in place on the source GPU: the other-GPU code was not involved)
     m.close()
+    # the other-GPU paths, forced on this one-GPU box and WITNESSED (the knob is read on every call, and
+    # eicos_batch_last_update_path says which path a shard really took): (a) the kernel reads the source GPU's HBM in place (peer
+    # access), (b) staged hipMemcpyPeerAsync copies in chunks of 256 through the device staging buffer -- ragged shards 334 + 333 + 333
     monkeypatch.setenv("EICOS_EXPERIMENT", "1"); monkeypatch.setenv("EICOS_MULTI_FORCE_PEER", "1")
-    m = eicos_amd.MultiBatchSolver(pat, 1000, [0, 0, 0])  # ragged shards: 334 + 333 + 333, the staged (peer-copy) path with chunks of 256
-    assert m.shards() == [(0, 334, 0), (334, 333, 0), (667, 333, 0)]
-    m.update_device(0, ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"), count=1000)
-    codes = m.solve()
-    assert np.array_equal(codes, codes1[:1000]) and np.array_equal(m.solution(), x1[:1000]) and np.array_equal(m.info_arrays()["iter"], ia1["iter"][:1000])
-    m.close()
+    for staged, path in (("0", "peer GPU in place"), ("1", "staged peer copies")):
+        monkeypatch.setenv("EICOS_PEER_STAGED", staged)
+        m = eicos_amd.MultiBatchSolver(pat, 1000, [0, 0, 0])
+        assert m.shards() == [(0, 334, 0), (334, 333, 0), (667, 333, 0)]
+        m.update_device(0, ptr("Gpr"), ptr("Apr"), ptr("c"), ptr("h"), ptr("b"), count=1000)
+        assert [m.shard_last_update(s_)[0] for s_ in range(3)] == [path] * 3
+        codes = m.solve()
+        assert np.array_equal(codes, codes1[:1000]) and np.array_equal(m.solution(), x1[:1000]) and np.array_equal(m.info_arrays()["iter"], ia1["iter"][:1000])
+        m.close()
+    monkeypatch.delenv("EICOS_MULTI_FORCE_PEER"); monkeypatch.delenv("EICOS_PEER_STAGED")
     for pbuf in dev.values():
         if pbuf:
             hip.hipFree(ctypes.c_void_p(pbuf))
+
+
+def test_host_pointer_update_and_result_paths_are_bit_identical():
+    # the reference's real signature is updateData(double *...) / solution() on HOST memory
+    # (/root/reference include/eicos.hpp:155-160).  Pageable arrays travel through the pinned double-buffer bounce (the kernel reads the
+    # bounce buffer in place over PCIe), pinned arrays (eicos_host_alloc) are read / written in place; both must give the bits of the
+    # device-resident path, on the full range, on a sub-range with kept groups, and for results copied into pageable and pinned memory
+    import ctypes
+    from eicos_amd.binding import _lib
+    pat, sets = load_fixture("MPC02")
+    B = 600  # 600 x 124 KB = 74 MB: five bounce chunks of 128 instances (the last one short)
+    d = feasible_batch(pat, sets[0], 0, B)
+    keys = ("Gpr", "Apr", "c", "h", "b")
+    hip = _lib()
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    dev = {}
+    for k in keys:
+        pbuf = ctypes.c_void_p()
+        v = np.ascontiguousarray(d[k])
+        assert hip.hipMalloc(ctypes.byref(pbuf), max(v.nbytes, 8)) == 0 and hip.hipMemcpy(pbuf, v.ctypes.data, v.nbytes, 1) == 0
+        dev[k] = pbuf.value
+    g = eicos_amd.BatchSolver(pat, B, device=0)
+    g.update_device(*[dev[k] for k in keys])
+    codes0 = g.solve(); x0 = g.solution(); ia0 = g.info_arrays()
+    assert np.all(codes0 == 0) and g.last_update_path() == "none"
+    # pageable host arrays: the bounce pipeline
+    g.update(*[d[k] for k in keys])
+    assert g.last_update_path() == "pinned bounce" and g.last_update_ms() > 0
+    codes = g.solve()
+    assert np.array_equal(codes, codes0) and np.array_equal(g.solution(), x0) and np.array_equal(g.info_arrays()["iter"], ia0["iter"])
+    # the caller's arrays are free again on return: scribbling over a copy that was passed must not change anything
+    scratch = {k: d[k].copy() for k in keys}
+    g.update(*[scratch[k] for k in keys])
+    for k in keys:
+        scratch[k][...] = np.nan
+    assert np.array_equal(g.solve(), codes0) and np.array_equal(g.solution(), x0)
+    # pinned host arrays: read in place, x written in place
+    pins = {k: eicos_amd.PinnedArray(d[k].shape) for k in keys}
+    for k in keys:
+        pins[k].a[...] = d[k]
+    px = eicos_amd.PinnedArray((B, pat.n))
+    g.update(*[pins[k].a for k in keys])
+    assert g.last_update_path() == "pinned source in place"
+    for k in keys:
+        pins[k].a[...] = 0.0  # (the call has waited for the kernel: overwriting the arrays now is allowed, as with the reference)
+    assert np.array_equal(g.solve(), codes0) and np.array_equal(g.solution_into(px.a), x0)
+    y, z, s_ = g.duals()
+    # a sub-range with kept groups through the bounce (c of instances 100..355 only: two chunks would need > 16 MB -- one here) and a
+    # short range below one chunk: same bits as the same calls with device pointers
+    g.update(None, None, d["c"][100:356], None, None, first=100, count=256)
+    g.solve(); xk = g.solution()
+    g.update_device(*[dev[k] for k in keys]); g.solve()
+    assert np.array_equal(g.solution(), x0)
+    g.update_device(0, 0, dev["c"] + 100 * pat.n * 8, 0, 0, first=100, count=256)
+    g.solve()
+    assert np.array_equal(g.solution(), xk) and not np.array_equal(xk[100:356], x0[100:356])
+    g.close()
+    for pa in list(pins.values()) + [px]:
+        pa.close()
+    for v in dev.values():
+        hip.hipFree(ctypes.c_void_p(v))
 
 
 def test_cpp_batch_solver_over_a_device_list(tmp_path):
@@ -1009,6 +1099,51 @@ def test_bench_multi_flag_drives_the_product_multi_gpu_layer():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["config"]["total_instances"] == 128 and d["config"]["optimal"] == 128
     assert "eicos_multi" in d["config"]["io"] and "(0, 64, 0), (64, 64, 0)" in d["config"]["io"] and d["value"] > 0
+
+
+def test_bench_eight_shards_keep_the_roofline_below_one():
+    # the N > 1 measurement path, dry-run on this one-GPU box -- eight handles / streams / host threads
+    # (device list {0 x 8}, 512 instances each = the per-GPU share of configs[2]); every instance optimal, the roofline fraction of the
+    # multi-device line stays <= 1 (peak = distinct devices x 8 TB/s), the shard witnesses are in the line
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--multi", "0,0,0,0,0,0,0,0", "--total", "4096",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    c, r = d["config"], d["roofline"]
+    assert d["n_gpus"] == 1 and c["total_instances"] == 4096 and c["optimal"] == 4096 and c["devices"] == [0] * 8 and "eicos_multi" in c["launch"]
+    assert 0 < r["frac"] <= 1 and 0 < r["frac_dual"] <= 1 and r["peak"] == 8000.0 and r["devices"] == 1
+    assert len(r["per_shard"]) == 8 and all(p_["instances"] == 512 and p_["kernel_ms"] > 0 for p_ in r["per_shard"])
+    assert sum(p_["frac_of_one_gpu"] for p_ in r["per_shard"]) <= 1.0  # (eight shards share ONE device's bandwidth)
+    assert abs(d["value"] - c["mean_iter"] * 4096 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+
+
+def test_mpc_soc_batch_1024_all_instances_against_the_oracle():
+    # the metric says "SOCP" -- the MPC-SOC variant (332 cones of dimension 3) at the headline's batch, every
+    # instance against the oracle: exit code, iterations +-1, pcost 1e-8, x
+    pat, sets = load_fixture("MPC02")
+    spat = mpc_soc_variant(pat, sets[0])
+    B = 1024
+    d = feasible_batch(spat, sets[0], 0, B)
+    g = eicos_amd.BatchSolver(spat, B)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve(); ia = g.info_arrays(); x = g.solution(); g.close()
+    assert np.all(codes == 0)
+    _all_instances_against_the_oracle(spat, d, codes, ia, x, tag="MPC02-SOC b1024")
+
+
+def test_mpc_batch_4096_all_instances_against_the_oracle():
+    # north_star's ">= 10x the host at batch 4096" configuration (three workgroups per CU, the 168-VGPR build, the instance queue):
+    # all 4096 instances against the oracle (~2 s of 16-core CPU time)
+    pat, sets = load_fixture("MPC02")
+    B = 4096
+    d = feasible_batch(pat, sets[0], 0, B)
+    g = eicos_amd.BatchSolver(pat, B)
+    g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+    codes = g.solve(); ia = g.info_arrays(); x = g.solution(); g.close()
+    assert np.all(codes == 0)
+    _all_instances_against_the_oracle(pat, d, codes, ia, x, tag="MPC02 b4096")
 
 
 def test_dynamic_regularisation_extension_matches_oracle():
