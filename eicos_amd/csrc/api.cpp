@@ -328,21 +328,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     // (tile mode: the sweeps and the factorisation run over the tile plan instead; the scalar plans stay empty)
     TriPlan planF, planB;
-    {   // Two slices of a level per sweep step (kernels.hip: tri_sweep<..., W = 2>): the pure scalar path in the throughput regime (more
-        // instances than CUs: no dual right-hand-side solves, whose doubled registers leave no room for a second slice)
-        int n_cu = 256;
-        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device < 0 ? 0 : device) == hipSuccess) n_cu = pr.multiProcessorCount; }
-        const bool dual_forced = env_int("EICOS_DUAL", 0, 0, 1) == 1;
-        D.tri_w = (S.tile == 0 && batch > n_cu && !dual_forced) ? env_int("EICOS_TRI_W", 2, 1, 2) : 1;
-    }
-    if (!tile1) { planF = build_tri_plan(S, h->threads, true, true, D.tri_w); planB = build_tri_plan(S, h->threads, false, true, D.tri_w); }
+    if (!tile1) { planF = build_tri_plan(S, h->threads, true); planB = build_tri_plan(S, h->threads, false); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
     // every section of a sweep plan is a whole number of queue-depth trips (tri_sweep's remainder loop executes full trips)
-    const int dep_wide = D.tri_w == 2 ? 2 * TRI_DEPTH_W2 : TRI_DEPTH, dep_solo = D.tri_w == 2 ? 2 * TRI_DEPTH_W2 : TRI_DEPTH_SOLO;
-    bool groups_ok = true; // W = 2: a level opens on the first slice of a group only
-    if (D.tri_w == 2) for (const TriPlan *pl : {&planF, &planB}) for (size_t i = 1; i < pl->sl.size(); i += 2) if (pl->sl[i].newlev & 1) groups_ok = false;
-    if (!groups_ok || D.nfs % dep_wide || D.nbs % dep_wide || D.nfs_ext % dep_wide || D.nfs_solo % dep_solo || D.nbs_solo % dep_solo) {
+    if (D.nfs % TRI_DEPTH || D.nbs % TRI_DEPTH || D.nfs_ext % TRI_DEPTH || D.nfs_solo % TRI_DEPTH_SOLO || D.nbs_solo % TRI_DEPTH_SOLO) {
         delete h; return fail(EICOS_E_INVALID, "internal: a section of a sweep plan is not padded to its queue depth");
     }
     D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
@@ -379,6 +369,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         D.w_DL = Wl.add((size_t)TP.nb * 256);
     }
     D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
+    D.n0 = (!tile && S.nlev >= 1) ? S.lev_ptr[1] : 0;                                          // leaf rows of the elimination order (level 0)
+    D.w_dual_xl = Wl.add(2 * ((size_t)D.n0 + 16));                                               // compact dual solve: x of the leaf rows
     D.work_stride = Wl.size;
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
     std::vector<int> col_of(S.nnzL);
@@ -612,11 +604,19 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // Scalar / hybrid programs: when the batch fits one workgroup per CU -- the sweeps are then a dependent chain of level
         // steps, and a step for two right-hand sides costs far less than two steps
         int dual = (fit == 2 && (tile1 || batch <= prop.multiProcessorCount)) ? 1 : 0;
-        dual = env_int("EICOS_DUAL", dual, 0, 1);
-        if (fit < 2 || D.tri_w == 2) dual = 0; // (plans laid out for two slices per step are walked by the single right-hand-side sweeps only)
+        // Beyond one workgroup per CU two full vectors cost the second workgroup (MPC02: 2 x 48 KB).  The COMPACT pair (dual = 2; kernels.hip:
+        // kkt_solve<..., CPT>) keeps only the rows of levels >= 1 in LDS -- the n0 leaf rows of the elimination tree are pure inputs of the
+        // forward sweep and pure outputs of the backward one and stay in the workspace slab -- and fits the LDS of ONE vector when
+        // 2 (Npad - n0) <= Npad: the launch shape of the single-vector kernel is kept and every pass makes 2 dual + 1 single solve
+        // instead of 3 single ones.  Pure scalar path without second-order cones (the cone part of the refinement operator reads
+        // the iterate at arbitrary rows).
+        const bool compact_ok = !tile && S.nc == 0 && fit >= 1 && want == 1 && h->nlds == 1 && D.n0 > 0 && 2 * ((size_t)D.Npad - (size_t)D.n0) <= (size_t)D.Npad;
+        dual = env_int("EICOS_DUAL", (!dual && compact_ok) ? 2 : dual, 0, 2);
+        if (dual == 2 && !compact_ok) dual = 0;
+        if (dual == 1 && fit < 2) dual = 0;
         if (dual) h->nlds = 1;
         D.dual = dual;
-        const int nvec = dual ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS
+        const int nvec = dual == 1 ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS (the compact pair lives in ONE)
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
         // deferred-L factorisation (device_types.hpp: fac_defer): needs the idle LDS solve vector for the mirror of 1/D
         // It trades one LDS read per pair for a write + read of every L entry and one barrier per level: measured +1.5..3.3 % on MPC02 and
@@ -681,7 +681,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
     // scattered stores and the read-back stay on chip.  Verified against the runtime's occupancy for the enlarged allocation.
     D.e_lds = 0; D.e_off = 0;
-    if (!h->ldsres && h->nlds == 1 && !D.dual && S.tile != 1) {
+    if (!h->ldsres && h->nlds == 1 && D.dual != 1 && S.tile != 1) { // (dual = 2: the single right-hand-side solves of a pass still use it)
         const size_t base = (h->dyn_lds + 15) & ~(size_t)15, room = (160 * 1024) / (size_t)bpc;
         size_t xs = room > base + 4096 + 1024 ? std::min<size_t>((size_t)NV, (room - base - 4096 - 1024) / sizeof(double)) & ~(size_t)15 : 0;
         while (xs > 0) {
@@ -1340,17 +1340,12 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
         for (int i = 0; i < N; i++) rhs[i] = rnd() - 0.5;
         // the two sweeps exactly as the kernel walks its sliced-ELL plans (lane by lane)
         double plan_err = 0;
-        for (int TW : {128, 256, 512, 1128, 1256, 1512}) { // (+ 1000: the same plans laid out for two slices per sweep step)
-            const int T = TW % 1000, W = TW > 1000 ? 2 : 1;
-            TriPlan pf = build_tri_plan(S, T, true, true, W), pb = build_tri_plan(S, T, false, true, W);
-            if (W == 2) for (const TriPlan *pl : {&pf, &pb}) {
-                for (size_t i = 1; i < pl->sl.size(); i += 2) if (pl->sl[i].newlev & 1) throw std::logic_error("a level opens inside a group of two slices");
-                if (pl->n_wide % (2 * TRI_DEPTH_W2) || pl->n_solo % (2 * TRI_DEPTH_W2)) throw std::logic_error("section not padded to the group queue");
-            }
+        for (int T : {128, 256, 512}) {
+            TriPlan pf = build_tri_plan(S, T, true), pb = build_tri_plan(S, T, false);
             std::vector<double> UF(pf.slots + 1, 0.0), UB(pb.slots + 1, 0.0), ws(N + 1, 0.0);
             { // numeric factorisation through the sliced-ELL factor plan, lane by lane as the kernel does it
                 FactorPlan px = build_factor_plan(S, T, pb.pos, pb.slots, pf.pos, pf.slots);
-                if (getenv("EICOS_PLAN_STATS") && W == 1) { // developer aid: shape of the three programs for this workgroup size
+                if (getenv("EICOS_PLAN_STATS")) { // developer aid: shape of the three programs for this workgroup size
                     auto stat = [&](const char *nm, const std::vector<SliceMeta> &sl, int slots) {
                         int lev = 0, kmax = 0; long lanes = 0, kl = 0;
                         for (const SliceMeta &m : sl) { lev += m.newlev & 1; kmax = std::max(kmax, m.K); lanes += (long)m.cnt << m.lg; kl += (long)m.K; }
@@ -1421,7 +1416,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
             sweep(pf, UF, true); sweep(pb, UB, false);
             std::vector<double> xt(N);
             for (int j = 0; j < N; j++) xt[S.perm[j]] = ws[j];
-            if (TW == 128) x = xt;
+            if (T == 128) x = xt;
             for (int j = 0; j < N; j++) plan_err = std::max(plan_err, std::fabs(xt[j] - x[j]));
         }
         if (plan_err > 1e-9) return -3.0;

@@ -68,10 +68,6 @@ static_assert(ELL_KMAX == 4, "the packed index entries hold four 16-bit indices 
 #ifndef EICOS_TRI_DEPTH_SOLO
 #define EICOS_TRI_DEPTH_SOLO 3
 #endif
-#ifndef EICOS_TRI_DEPTH_W2
-#define EICOS_TRI_DEPTH_W2 2
-#endif
-constexpr int TRI_DEPTH_W2 = EICOS_TRI_DEPTH_W2; // queue depth in GROUPS of two slices when a sweep step takes two slices of a level at once (DevPat::tri_w = 2)
 constexpr int TRI_DEPTH_SOLO = EICOS_TRI_DEPTH_SOLO; // queue depth (= slices per trip) of the single-wavefront part of the sweeps
 constexpr int TRI_DEPTH = EICOS_TRI_DEPTH; // ... this many slices ahead of their use (plans are padded to a multiple)
 #ifndef EICOS_TRI_TRIP
@@ -131,7 +127,6 @@ struct DevPat {
     const PackedSlice EICOS_GLOBAL *fsl; const PackedSlice EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;   // nfs / nbs = slices of the workgroup-wide part of the forward / backward plan
     int nfs_solo, nbs_solo;   // single-wavefront part (top of the tree): fsl = [wide | solo], bsl = [solo | wide]
-    int tri_w;                // slices per sweep step (kernels.hip: tri_sweep<..., W>): 2 = every level of both plans holds an even number of slices
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
     gint_p f_idx, b_idx;
@@ -175,7 +170,8 @@ struct DevPat {
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
     int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_UF, w_UB, w_D, w_invD, w_trace;
     int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)
-    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves: flag + the two 2-interleaved vectors in the workspace
+    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves: flag (2 = the compact pair: kernels.hip, kkt_solve<..., CPT>) + the two 2-interleaved vectors in the workspace
+    int n0, w_dual_xl;               // compact dual solve: number of level-0 (leaf) rows of the elimination order; their x, 2-interleaved (workspace)
     int lr_inst, lr_work;            // LDS-resident variant: offsets (doubles) of the instance slab and the workspace slab in the dynamic LDS
     // G in dense 16 x 16 tiles (api.cpp): gt_nrb row blocks of 16 rows, tiles [gt_rbptr[rb], gt_rbptr[rb+1]) of row block rb,
     // 16 columns per tile (gt_col: variable index or -1, gt_colk: elimination-order slot), gt_zslot: slot of z_i per row,

@@ -21,7 +21,7 @@ static void push_subslices(std::vector<SliceMeta> &sl, SliceMeta m) {
     }
 }
 
-TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo, int W) {
+TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) {
     TriPlan pl;
     pl.pos.assign(S.nnzL, 0);
     const std::vector<int> &ptr = forward ? S.Rp : S.Lp;
@@ -53,7 +53,6 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo, 
         return n;
     };
     auto emit_level = [&](int v, int Tw) { // v = nlev (hybrid, forward): the rows of the top block
-        const size_t lev0 = pl.sl.size();
         int r = S.lev_ptr[v];
         const int end = (hyb && v == nlev) ? S.N : S.lev_ptr[v + 1];
         bool first = true;
@@ -76,16 +75,14 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo, 
             r += cnt;
             first = false;
         }
-        // W slices per step: a group must not straddle a level (only the first slice of a group may open one)
-        while ((pl.sl.size() - lev0) % (size_t)W) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0});
     };
     // empty slices: no loop tail in the kernel's software pipeline (trips of TRI_TRIP slices, remainder in trips of the queue depth).  Every
     // SECTION of a plan (wide / solo / ext: each is walked by its own tri_sweep call) is padded to a multiple of ITS queue depth, counted
     // from the section's first slice -- the two depths need not divide each other
     size_t sec0 = 0;
     auto pad_to = [&](int depth) { while ((pl.sl.size() - sec0) % depth) pl.sl.push_back(SliceMeta{0, 0, 0, 0, pl.slots, 0, 0, 0}); sec0 = pl.sl.size(); };
-    auto pad = [&]() { pad_to(W == 2 ? 2 * TRI_DEPTH_W2 : TRI_DEPTH); };
-    auto pad_solo = [&]() { pad_to(W == 2 ? 2 * TRI_DEPTH_W2 : TRI_DEPTH_SOLO); };
+    auto pad = [&]() { pad_to(TRI_DEPTH); };
+    auto pad_solo = [&]() { pad_to(TRI_DEPTH_SOLO); };
     // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
     const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
     int vs = nlev;

@@ -21,9 +21,8 @@ struct TriPlan {
     int slots = 0;
 };
 
-// T = workgroup size the plan is laid out for.  W = slices per sweep step (DevPat::tri_w): every level is padded to a multiple of W
-// slices with empty ones, every section to a multiple of W x the queue depth of that step width.
-TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo = true, int W = 1);
+// T = workgroup size the plan is laid out for.
+TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo = true);
 
 // Sliced-ELL plan of a plain row-wise sparse product (no levels): rows [0,nrows) of a CSR-like
 // pattern `ptr`, consecutive rows per slice.  src[slot] = CSR entry stored in that slot, -1 = padding.
