@@ -369,8 +369,6 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         D.w_DL = Wl.add((size_t)TP.nb * 256);
     }
     D.w_dual_xk = Wl.add(2 * ((size_t)NV + 16)); D.w_dual_ek = Wl.add(2 * ((size_t)NV + 16)); // dual right-hand-side solves
-    D.n0 = (!tile && S.nlev >= 1) ? S.lev_ptr[1] : 0;                                          // leaf rows of the elimination order (level 0)
-    D.w_dual_xl = Wl.add(2 * ((size_t)D.n0 + 16));                                               // compact dual solve: x of the leaf rows
     D.work_stride = Wl.size;
     std::vector<int> fac_src(planX.target.size()), fac_dst(planX.target.size()), fac_dstF(planX.target.size()), fac_col(planX.target.size(), 0);
     std::vector<int> col_of(S.nnzL);
@@ -604,19 +602,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // Scalar / hybrid programs: when the batch fits one workgroup per CU -- the sweeps are then a dependent chain of level
         // steps, and a step for two right-hand sides costs far less than two steps
         int dual = (fit == 2 && (tile1 || batch <= prop.multiProcessorCount)) ? 1 : 0;
-        // Beyond one workgroup per CU two full vectors cost the second workgroup (MPC02: 2 x 48 KB).  The COMPACT pair (dual = 2; kernels.hip:
-        // kkt_solve<..., CPT>) keeps only the rows of levels >= 1 in LDS -- the n0 leaf rows of the elimination tree are pure inputs of the
-        // forward sweep and pure outputs of the backward one and stay in the workspace slab -- and fits the LDS of ONE vector when
-        // 2 (Npad - n0) <= Npad: the launch shape of the single-vector kernel is kept and every pass makes 2 dual + 1 single solve
-        // instead of 3 single ones.  Pure scalar path without second-order cones (the cone part of the refinement operator reads
-        // the iterate at arbitrary rows).
-        const bool compact_ok = !tile && S.nc == 0 && fit >= 1 && want == 1 && h->nlds == 1 && D.n0 > 0 && 2 * ((size_t)D.Npad - (size_t)D.n0) <= (size_t)D.Npad;
-        dual = env_int("EICOS_DUAL", (!dual && compact_ok) ? 2 : dual, 0, 2);
-        if (dual == 2 && !compact_ok) dual = 0;
-        if (dual == 1 && fit < 2) dual = 0;
+        dual = env_int("EICOS_DUAL", dual, 0, 1);
+        if (fit < 2) dual = 0;
         if (dual) h->nlds = 1;
         D.dual = dual;
-        const int nvec = dual == 1 ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS (the compact pair lives in ONE)
+        const int nvec = dual ? 2 : h->nlds; // vectors of Npad doubles at the start of the dynamic LDS
         D.meta_lds = h->nlds >= 1 ? 1 : 0;
         // deferred-L factorisation (device_types.hpp: fac_defer): needs the idle LDS solve vector for the mirror of 1/D
         // It trades one LDS read per pair for a write + read of every L entry and one barrier per level: measured +1.5..3.3 % on MPC02 and
@@ -681,7 +671,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
     // scattered stores and the read-back stay on chip.  Verified against the runtime's occupancy for the enlarged allocation.
     D.e_lds = 0; D.e_off = 0;
-    if (!h->ldsres && h->nlds == 1 && D.dual != 1 && S.tile != 1) { // (dual = 2: the single right-hand-side solves of a pass still use it)
+    if (!h->ldsres && h->nlds == 1 && !D.dual && S.tile != 1) {
         const size_t base = (h->dyn_lds + 15) & ~(size_t)15, room = (160 * 1024) / (size_t)bpc;
         size_t xs = room > base + 4096 + 1024 ? std::min<size_t>((size_t)NV, (room - base - 4096 - 1024) / sizeof(double)) & ~(size_t)15 : 0;
         while (xs > 0) {

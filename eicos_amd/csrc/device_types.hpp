@@ -170,8 +170,7 @@ struct DevPat {
     int w_dx1, w_dy1, w_dz1, w_dx2, w_dy2, w_dz2, w_dsw, w_wdz, w_dsa, w_t1, w_t2;
     int w_lpw, w_lpv, w_csc, w_qv, w_xk, w_ek, w_dxr, w_UF, w_UB, w_D, w_invD, w_trace;
     int lds_tab;                     // dynamic LDS: offset (doubles) of the slice tables behind the KKT-space vector(s)
-    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves: flag (2 = the compact pair: kernels.hip, kkt_solve<..., CPT>) + the two 2-interleaved vectors in the workspace
-    int n0, w_dual_xl;               // compact dual solve: number of level-0 (leaf) rows of the elimination order; their x, 2-interleaved (workspace)
+    int dual, w_dual_xk, w_dual_ek;  // dual right-hand-side solves: flag + the two 2-interleaved vectors in the workspace
     int lr_inst, lr_work;            // LDS-resident variant: offsets (doubles) of the instance slab and the workspace slab in the dynamic LDS
     // G in dense 16 x 16 tiles (api.cpp): gt_nrb row blocks of 16 rows, tiles [gt_rbptr[rb], gt_rbptr[rb+1]) of row block rb,
     // 16 columns per tile (gt_col: variable index or -1, gt_colk: elimination-order slot), gt_zslot: slot of z_i per row,

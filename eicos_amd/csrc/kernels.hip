@@ -235,32 +235,6 @@ __device__ __forceinline__ double grp_reduce_to_lane0(double v, int lg) { // lg 
     return dpp_shl_add<0x101>(v);           // row_shl:1
 }
 
-// ---- range-checked loads of the LEAF rows of a KI-interleaved KKT-space vector (compact dual solve): a raw buffer load through a
-// descriptor that covers rows [0, n0) -- a lane whose row index is >= n0 (its value lives in LDS instead) is OUT OF RANGE: the hardware
-// returns 0 for it and makes no memory access, so the loop issues the same load instruction for every entry without a clamped
-// duplicate fetch and without a branch around the load (a load under a branch costs the software pipeline its exact s_waitcnt).
-typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-#if !EICOS_LDSRES
-struct LeafBuf { __amdgpu_buffer_rsrc_t r; };
-template <int KI> __device__ __forceinline__ LeafBuf leaf_buf(gcdbl_p base, int n0) {
-    return LeafBuf{__builtin_amdgcn_make_buffer_rsrc((void *)(unsigned long long)base, 0, n0 * KI * 8, 0x00020000)};
-}
-template <int KI> __device__ __forceinline__ void ldK_leaf(const LeafBuf &b, int row, double (&o)[KI]) {
-    if constexpr (KI == 2) { const d2_t v = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(b.r, row * 16, 0, 0)); o[0] = v.x; o[1] = v.y; }
-    else { static_assert(KI == 1, "KI"); o[0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.r, row * 8, 0, 0)); }
-}
-// one element (row, k)
-template <int KI> __device__ __forceinline__ double ld1_leaf(const LeafBuf &b, int row, int k) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.r, (row * KI + k) * 8, 0, 0));
-}
-#else // (the LDS-resident build never runs the compact dual solve: stubs keep its instantiation well-formed)
-struct LeafBuf { gcdbl_p p; int n0; };
-template <int KI> __device__ __forceinline__ LeafBuf leaf_buf(gcdbl_p base, int n0) { return LeafBuf{base, n0}; }
-template <int KI> __device__ __forceinline__ void ldK_leaf(const LeafBuf &b, int row, double (&o)[KI]) { for (int k = 0; k < KI; k++) o[k] = row < b.n0 ? (double)b.p[row * KI + k] : 0.; }
-template <int KI> __device__ __forceinline__ double ld1_leaf(const LeafBuf &b, int row, int k) { return row < b.n0 ? (double)b.p[row * KI + k] : 0.; }
-#endif
-
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
 struct OpMin { __device__ static double f(double a, double b) { return fmin(a, b); } };
@@ -615,97 +589,6 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
     }
 }
 
-// ell_dots_k for the COMPACT dual solve (DevPat::dual = 2, see tri_sweep): the gathered vector has its rows of levels >= 1 in LDS (`x`,
-// row r at r - n0, KI-interleaved) and its leaf rows in global memory (`xl`).  Leaf values are prefetched like the matrix values, which
-// needs their indices one stage earlier -- three stages: A (two queue depths ahead) gather indices + `pre0(row)` = the row's own
-// elimination position; B (one depth ahead) matrix values, the leaf values the indices name, `pre(k, row, o)` (right-hand side entry,
-// the row's own x when it is a leaf, ...); C the LDS gathers and the arithmetic.  The stage-A results ride in the queue slot that
-// will hold their slice.
-// GLG = false: no gather of this plan names a leaf row (host flag per plan): the leaf loads are not issued at all.
-template <int T, bool I16, int KI, bool SHARED, bool GLG, class SM, class X, class Pre0, class Pre, class Epi>
-__device__ __forceinline__ void ell_dots_k3(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, const gcdbl_p (&eval)[KI], X x, const LeafBuf &xl, int n0,
-                                            int dummy_slot, Pre0 &&pre0, Pre &&pre, Epi &&epi) {
-    if (ns == 0) return; // no rows
-    const int t = threadIdx.x;
-    using R = decltype(pre(0, 0, 0));
-    struct Q { int i[ELL_KMAX], ni[ELL_KMAX], no; double v[ELL_KMAX][KI], g[GLG ? ELL_KMAX : 1][KI]; R r[KI]; } q[ELL_DEPTH];
-    auto meta = [&](int s) { return slice_at(sm, s); };
-    double carry[KI]; // partial sum of rows cut into sub-slices (SliceMeta::more / cont)
-#pragma unroll
-    for (int k = 0; k < KI; k++) carry[k] = 0.;
-    auto loadA = [&](int s, Q &o) {
-        const Sl nm = meta(s);
-        const int lanes = nm.cnt << nm.lg;
-        const bool act = t < lanes;
-        load_indices<I16>(o.ni, eidx, eidx16, act, nm.K, nm.off, lanes, t, dummy_slot, nm.off16, d16);
-        o.no = pre0(act ? nm.row0 + (t >> nm.lg) : 0);
-    };
-    auto loadB = [&](int s, Q &o) {
-        const Sl nm = meta(s);
-        const int lanes = nm.cnt << nm.lg;
-        const bool act = t < lanes;
-#pragma unroll
-        for (int kk = 0; kk < ELL_KMAX; kk++) {
-            o.i[kk] = o.ni[kk];
-            const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
-            o.v[kk][0] = ld_u32_nt(eval[0], slot);
-#pragma unroll
-            for (int k = 1; k < KI; k++) o.v[kk][k] = SHARED ? o.v[kk][0] : ld_u32_nt(eval[k], slot);
-            if constexpr (GLG) ldK_leaf<KI>(xl, o.i[kk], o.g[kk]); // (out of range -- 0, no memory access -- for an index that names no leaf)
-        }
-        const int oo = o.no;
-#pragma unroll
-        for (int k = 0; k < KI; k++) o.r[k] = pre(k, act ? nm.row0 + (t >> nm.lg) : 0, oo);
-    };
-#pragma unroll
-    for (int d = 0; d < ELL_DEPTH; d++) loadA(d < ns ? d : 0, q[d]);
-#pragma unroll
-    for (int d = 0; d < ELL_DEPTH; d++) { loadB(d < ns ? d : 0, q[d]); loadA(min(d + ELL_DEPTH, ns - 1), q[d]); }
-    auto step = [&](const int d, const int s) __attribute__((always_inline)) {
-        const Sl m = meta(s);
-        int ci[ELL_KMAX]; double cv[ELL_KMAX][KI], cg[GLG ? ELL_KMAX : 1][KI]; R cr[KI];
-#pragma unroll
-        for (int k = 0; k < KI; k++) cr[k] = q[d].r[k];
-#pragma unroll
-        for (int kk = 0; kk < ELL_KMAX; kk++) {
-            ci[kk] = q[d].i[kk];
-#pragma unroll
-            for (int k = 0; k < KI; k++) { cv[kk][k] = q[d].v[kk][k]; if constexpr (GLG) cg[kk][k] = q[d].g[kk][k]; }
-        }
-        loadB(min(s + ELL_DEPTH, ns - 1), q[d]);
-        loadA(min(s + 2 * ELL_DEPTH, ns - 1), q[d]);
-        const int lanes = m.cnt << m.lg;
-        const bool act = t < lanes;
-        double xg[ELL_KMAX][KI];
-#pragma unroll
-        for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(x, max(ci[kk] - n0, 0), xg[kk]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < KI; k++) {
-            double acc = 0.;
-#pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) {
-                double xv = xg[kk][k];
-                if constexpr (GLG) xv = ci[kk] < n0 ? cg[kk][k] : xv;
-                acc = madd(acc, cv[kk][k], xv);
-            }
-            acc = grp_reduce_to_lane0(acc, m.lg);
-            if (m.cont) acc += carry[k];
-            if (m.more) carry[k] = acc;
-            else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(k, m.row0 + (t >> m.lg), acc, cr[k]);
-        }
-    };
-    int s0 = 0;
-    for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
-#pragma unroll
-        for (int u = 0; u < ELL_TRIP; u++) step(u % ELL_DEPTH, s0 + u);
-    }
-    for (; s0 < ns; s0 += ELL_DEPTH) {
-#pragma unroll
-        for (int u = 0; u < ELL_DEPTH; u++) step(u, s0 + u);
-    }
-}
-
 // Workgroup barrier that orders LDS traffic only.  On gfx9-family parts loads and stores share
 // the vmcnt counter, so __syncthreads() (release fence) drains every outstanding global LOAD as
 // well -- which would serialise the software prefetch below behind each level barrier.  The
@@ -727,39 +610,20 @@ __device__ __forceinline__ void lds_barrier() {
 // workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
 // VSH (dual right-hand sides of ONE instance): the vector ws is KI-interleaved, the factor (eval, invD) is a single one.
-// CPT ("compact" dual solve, DevPat::dual = 2): the KI-interleaved sweep vector `ws` (LDS) holds only the rows of levels >= 1, row r at
-// r - n0 (n0 = number of level-0 rows = leaves of the elimination tree: they are pure inputs of the forward sweep and pure outputs of
-// the backward one); the leaf rows live in global memory: the forward sweep reads y_leaf from `cp.yl` (the right-hand side / residual
-// in elimination order), the backward sweep reads it as the own value of its level-0 slices and writes x_leaf to `cp.xl`.  Two 16-byte
-// vectors of all N rows would cost the second workgroup of a CU on MPC02 (2 x 48 KB); the compact pair takes 2 x 16 KB.  Leaf values
-// are gathered from global memory, so they are PREFETCHED like the matrix values: three stages -- gather indices two queue depths
-// ahead (they ride in the slot that will hold their slice: Slot::nidx), values + leaf gathers one depth ahead, LDS gathers at the step.
-struct CptArgs { gcdbl_p yl; gdbl_p xl; int n0; };
-template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, bool CPT = false, class SM, class WS>
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class WS>
 __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
-                                          int dummy_slot, CptArgs cp = CptArgs{nullptr, nullptr, 0}) {
+                                          int dummy_slot) {
     // KI = 2 (with VSH): the two right-hand sides of a dual solve -- one factor, the sweep vector ws 2-interleaved, so every
     // gather / store of the pair is one 16-byte LDS access
     if (ns == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
-    const int n0 = CPT ? cp.n0 : 0;
-    const LeafBuf yl = leaf_buf<KI>(cp.yl, n0); // (range-checked: rows >= n0 read 0 without a memory access)
-    constexpr bool GL = CPT && FORWARD; // gathers may name leaf rows (backward gathers never do: a column's entries sit in rows of higher levels)
     // the narrow tree top (SOLO, one wavefront) runs short steps: the same lead time needs a deeper queue than the workgroup-wide levels
     constexpr int DEPTH = SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH;
     constexpr int TRIP = SOLO ? ((TRI_TRIP + TRI_DEPTH_SOLO - 1) / TRI_DEPTH_SOLO) * TRI_DEPTH_SOLO : TRI_TRIP; // (a multiple of the queue depth)
     struct Slot { // one prefetched slice: descriptor (SGPRs), ELL_KMAX (index, value) pairs, 1/D and old value of the own row
         int row0, lg, K, off, lanes, newlev, more, cont;
         int idx[ELL_KMAX]; double val[ELL_KMAX][KI]; double d[KI], own[KI];
-        int nidx[GL ? ELL_KMAX : 1];          // GL: gather indices of the slice that takes this slot next (stage A)
-        double gl[GL ? ELL_KMAX : 1][KI];     // GL: the leaf values of this slice's gathers (stage B; 0 for entries that name no leaf)
     } q[DEPTH];
-    // stage A: the gather indices of slice s
-    auto load_idx = [&](int s, int (&ni)[ELL_KMAX]) {
-        const Sl nm = slice_at(sm, s);
-        const int lanes = nm.cnt << nm.lg;
-        load_indices<I16>(ni, eidx, eidx16, t < lanes, nm.K, nm.off, lanes, t, dummy_slot, nm.off16, d16);
-    };
     // every slice issues the same number of global loads per lane (inactive lanes / padding read the plan's dummy
     // slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
     auto load = [&](int s, Slot &o) {
@@ -768,10 +632,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
         o.more = nm.more; o.cont = nm.cont;
         o.lanes = nm.cnt << o.lg;
         const bool act = t < o.lanes;
-        if constexpr (GL) { // the indices arrived one queue depth ago; the leaf values they name are fetched with the matrix values
-#pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) { o.idx[kk] = o.nidx[kk]; ldK_leaf<KI>(yl, o.idx[kk], o.gl[kk]); }
-        } else load_indices<I16>(o.idx, eidx, eidx16, act, o.K, o.off, o.lanes, t, dummy_slot, nm.off16, d16);
+        load_indices<I16>(o.idx, eidx, eidx16, act, o.K, o.off, o.lanes, t, dummy_slot, nm.off16, d16);
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < o.K) ? o.off + kk * o.lanes + t : dummy_slot;
@@ -782,7 +643,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
                 for (int k = 0; k < KI; k++) o.val[kk][k] = v1[0];
             } else ldK_g<KI, true>(eval, slot, o.val[kk]); // streamed once per sweep: do not displace the index arrays in L2
         }
-        const int r = act ? o.row0 + (t >> o.lg) : (CPT ? n0 : 0);
+        const int r = act ? o.row0 + (t >> o.lg) : 0;
         if constexpr (FORWARD) { // forward is L y = b with unit-lower L: no pivot needed
 #pragma unroll
             for (int k = 0; k < KI; k++) o.d[k] = 0.;
@@ -792,31 +653,18 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 #pragma unroll
             for (int k = 0; k < KI; k++) o.d[k] = d1[0];
         } else ldK_g<KI, false>(invD, r, o.d);
-        // rows of later slices are not written before their own slice runs
-        if constexpr (CPT && !FORWARD) { // the slices of level 0 (row0 < n0, workgroup-uniform) take y_leaf from global memory; both loads are
-            double gy[KI], ly[KI];       // issued on every slice, so the load count per slice stays fixed (the global one is out of range for rows >= n0)
-            const bool leaf = o.row0 < n0;
-            ldK_leaf<KI>(yl, (leaf && act) ? r : n0, gy);
-            ldK<KI>(ws, (!leaf && act) ? r - n0 : 0, ly);
-#pragma unroll
-            for (int k = 0; k < KI; k++) o.own[k] = leaf ? gy[k] : ly[k];
-        } else ldK<KI>(ws, r - n0, o.own);
+        ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
-    if constexpr (GL) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) load_idx(d < ns ? d : 0, q[d].nidx);
-    }
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) { load(d < ns ? d : 0, q[d]); if constexpr (GL) load_idx(min(d + DEPTH, ns - 1), q[d].nidx); }
+    for (int d = 0; d < DEPTH; d++) load(d < ns ? d : 0, q[d]);
     // one slice step; `d` = the slice's slot of the register queue.  A trip of TRI_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
     // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of TRI_DEPTH, so
     // plans are padded to a multiple of TRI_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
     auto step = [&](const int d, const int s) __attribute__((always_inline)) {
         const Slot c = q[d];
         load(min(s + DEPTH, ns - 1), q[d]);
-        if constexpr (GL) load_idx(min(s + 2 * DEPTH, ns - 1), q[d].nidx);
         if (c.newlev) {
             if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
             else if (LDSBAR) lds_barrier();
@@ -824,34 +672,29 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
         }
         double xg[ELL_KMAX][KI]; // all gathers in flight before the first multiply (the scheduler would serialise them)
 #pragma unroll
-        for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, CPT ? max(c.idx[kk] - n0, 0) : c.idx[kk], xg[kk]);
+        for (int kk = 0; kk < ELL_KMAX; kk++) ldK<KI>(ws, c.idx[kk], xg[kk]);
         __builtin_amdgcn_sched_barrier(0);
         double acc[KI];
 #pragma unroll
         for (int k = 0; k < KI; k++) {
             double a = 0.;
 #pragma unroll
-            for (int kk = 0; kk < ELL_KMAX; kk++) {
-                double xv = xg[kk][k];
-                if constexpr (GL) xv = c.idx[kk] < n0 ? c.gl[kk][k] : xv;
-                a = madd(a, c.val[kk][k], xv);
-            }
+            for (int kk = 0; kk < ELL_KMAX; kk++) a = madd(a, c.val[kk][k], xg[kk][k]);
             acc[k] = grp_reduce_to_lane0(a, c.lg);
         }
         if (t < c.lanes && (t & ((1 << c.lg) - 1)) == 0) {
             const int r = c.row0 + (t >> c.lg);
-            const bool leaf = CPT && !FORWARD && c.row0 < n0; // (workgroup-uniform: a slice belongs to one level)
             // rows cut into sub-slices: a continuation works on what the previous sub-slice left in ws[r]
             // (same lane, program order), and only the last one applies the pivot
             double cur[KI], out[KI];
-            if (c.cont) { if (leaf) ldK<KI>(cp.xl, r, cur); else ldK<KI>(ws, r - n0, cur); }
+            if (c.cont) ldK<KI>(ws, r, cur);
 #pragma unroll
             for (int k = 0; k < KI; k++) {
                 const double v = (c.cont ? cur[k] : c.own[k]) - acc[k];
                 out[k] = (FORWARD || c.more) ? v         // y_i = b_i - sum_k L[i,k] y_k
                                              : v * c.d[k]; // x_j = (y_j - sum_i U[i,j] x_i) / D_j
             }
-            if (leaf) stK<KI>(cp.xl, r, out); else stK<KI>(ws, r - n0, out);
+            stK<KI>(ws, r, out);
         }
     
     };
@@ -2090,11 +1933,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) int stage_resid(
 // right-hand side k at 2 i + k); every right-hand side keeps its own refinement state (step count, previous error, done
 // flag): the loop runs until both have stopped, one that has stopped keeps its iterate while the other takes further
 // steps (its lanes still compute, the result is discarded).  amask: bit k set = right-hand side k takes part.
-// CPT (with DUAL; DevPat::dual = 2): the COMPACT dual solve -- the two interleaved KKT-space vectors keep only the rows of levels >= 1 in
-// LDS (row r at r - n0), the n0 leaf rows of the elimination tree live in the workspace slab: the sweep's y_leaf in E (where the
-// right-hand side / the residual is anyway), x_leaf in XL (see tri_sweep).  Same plans, same factor, same arithmetic per row as the
-// full-vector dual solve: results are bit-identical to it; what changes is that the pair fits the LDS of one single-vector workgroup.
-template <int T, int NLDS, bool I16, int KI, bool DUAL = false, bool CPT = false>
+template <int T, int NLDS, bool I16, int KI, bool DUAL = false>
 static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(int ps, gdbl_p I0, gdbl_p I1, gdbl_p Wg, int stage, int amask) {
     ps = uni(ps); I0 = uni_ptr(I0); I1 = uni_ptr(I1); Wg = uni_ptr(Wg); stage = uni(stage); amask = uni(amask);
     const DevPat &P = c_pat[ps];
@@ -2103,9 +1942,6 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
     int phase = 0;
     static_assert(DUAL == (KI == 2), "KI = 2 is the dual right-hand-side solve");
     static_assert(KI == 1 || NLDS == 1, "a dual solve keeps its two sweep vectors in LDS");
-    static_assert(!CPT || DUAL, "the compact layout exists for the dual solve");
-    const int n0 = CPT ? P.n0 : 0;                       // leaf rows [0, n0) of the elimination order: in global memory
-    gdbl_p XL = Wg + P.w_dual_xl;                        // CPT: x of the leaf rows, KI-interleaved
     gdbl_p Ik[KI_MAX] = {I0, I1};
     const bool init = (stage == ST_KKT_INIT1 || stage == ST_KKT_INIT2);
     const bool first = (stage == ST_KKT_INIT1 || stage == ST_KKT1);
@@ -2133,8 +1969,6 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
     auto X = [&] { if constexpr (NLDS >= 2) return g_dyn + P.Npad; else if constexpr (NLDS == 1) return g_dyn; else return Wg + P.w_xk; }();
     auto E = [&] { if constexpr (DUAL) return Wg + P.w_dual_ek; else if constexpr (NLDS == 1) return Wg + P.w_ek; else return SV; }();
     gdbl_p Xg = DUAL ? Wg + P.w_dual_xk : Wg + P.w_xk; // NLDS = 1: the iterate while the LDS vector serves the triangular sweeps
-    // CPT: element (position o, right-hand side k) of the iterate X -- leaf rows from XL, the others from the compact LDS vector
-    auto ldX = [&](int o, int k) -> double { if constexpr (CPT) return o < n0 ? (double)XL[o * KI + k] : X[(o - n0) * KI + k]; else return X[o * KI + k]; };
     // NLDS = 1, one right-hand side: the first e_lds elimination positions of E live in the LDS the launch shape leaves free
     // behind the tables (api.cpp) -- E is written by scattered 8-byte stores (partial lines in HBM) and read back once
     constexpr bool ESPLIT = (NLDS == 1 && !DUAL);
@@ -2165,8 +1999,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
             double z[KI];
 #pragma unroll
             for (int k = 0; k < KI; k++) z[k] = 0.;
-            if constexpr (CPT) { FOR_T(q_, P.nzpos) { const int o = P.zpos[q_]; if (o < n0) stK<KI>(E, o, z); else stK<KI>(SV, o - n0, z); } } // (the host checked KI (Npad - n0) <= Npad)
-            else FOR_T(q_, P.nzpos) stK<KI>(SV, P.zpos[q_], z); // (host list: every slot of [0, Npad) that no entry of ipk names)
+            FOR_T(q_, P.nzpos) stK<KI>(SV, P.zpos[q_], z); // (host list: every slot of [0, Npad) that no entry of ipk names)
         }
         for_t_pre<T, 6>(np + m, [&](int j) {
             IVK<KI> r;
@@ -2177,8 +2010,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         }, [&](int, const IVK<KI> &r) {
 #pragma unroll
             for (int k = 0; k < KI; k++) nr[k] = fmax(nr[k], fabs(r.v[k]));
-            if constexpr (CPT) { if (r.o < n0) stK<KI>(E, r.o, r.v); else stK<KI>(SV, r.o - n0, r.v); } // (leaf rows: y_leaf is read from E by both sweeps)
-            else stK<KI>(SV, r.o, r.v);
+            stK<KI>(SV, r.o, r.v);
         });
         blk_reduce<OpMax, T, KI>(phase, nr);
 #pragma unroll
@@ -2192,15 +2024,6 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         const bool wave0 = uni(tid >> 6) == 0;
         if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
             if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV);
-        } else if constexpr (CPT) { // compact dual solve (pure scalar path): leaf rows in global memory
-            const CptArgs ca{E, XL, n0};
-            tri_sweep<T, true, true, false, I16, KI, true, true>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF, ca);
-            if (wave0) {
-                tri_sweep<T, true, true, true, I16, KI, true, true>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF, ca);
-                tri_sweep<T, false, true, true, I16, KI, true, true>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB, ca);
-            }
-            __syncthreads();
-            tri_sweep<T, false, true, false, I16, KI, true, true>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB, ca);
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
             tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
             if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down
@@ -2241,16 +2064,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
             tri_sweep<T, false, false, false, I16, KI, DUAL>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
         }
         // x = first solve / x += dx_ref (ref :1602); an instance that has stopped keeps its iterate
-        if constexpr (CPT) { // X = previous iterate (Xg) + increment: the compact LDS vector for the rows of levels >= 1, XL for the leaf rows
-            struct XU { double g[KI], l[KI]; };
-            if (pass > 0) for_t_pre<T, 6>(N, [&](int i) { XU r; ldK<KI>(Xg, i, r.g); ldK<KI>(XL, min(i, n0 - 1), r.l); return r; }, [&](int i, const XU &r) {
-                double c[KI], o[KI];
-                if (i < n0) { for (int k = 0; k < KI; k++) c[k] = r.l[k]; } else ldK<KI>(SV, i - n0, c);
-#pragma unroll
-                for (int k = 0; k < KI; k++) o[k] = rdone[k] ? r.g[k] : r.g[k] + c[k];
-                if (i < n0) stK<KI>(XL, i, o); else stK<KI>(SV, i - n0, o);
-            });
-        } else if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
+        if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
             if (pass > 0) for_t_pre<T, 6>(N, [&](int i) { VKI<KI> r; ldK<KI>(Xg, i, r.v); return r; }, [&](int i, const VKI<KI> &r) {
                 double c[KI], o[KI];
                 ldK<KI>(SV, i, c);
@@ -2278,40 +2092,6 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         struct PreK { double b, w; int o, sg; double g; }; // rhs entry, LP scaling, elimination-order slot, sign of the regularisation, G-tile term
         const bool gt = P.gt_on != 0; // G in tiles: one pass gives G dx and G' dz for all KI right-hand sides
         gdbl_p gxv = Wg + P.w_gx, gzv = Wg + P.w_gz;
-        if constexpr (CPT) { // the three products with the iterate split between LDS and XL: three-stage loops (ell_dots_k3)
-            struct PreC { double b, w, xo; int o, sg; }; // rhs entry, LP scaling, the row's own x when it is a leaf row, its elimination position, sign of the regularisation
-            const LeafBuf xlb = leaf_buf<KI>(XL, n0);
-            auto own = [&](int k, int o) -> double { return ld1_leaf<KI>(xlb, o, k); }; // (0 without a memory access for a row that is no leaf)
-            // (the three instantiations per plan -- with / without leaf gathers -- are chosen by the host's per-plan flags)
-            ell_dots_k3<T, I16, KI, true, true>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, xlb, n0, P.cag_slots,
-                        [&](int j) { return ld_u32(P.ipx, j); },
-                        [&](int k, int j, int o) { return PreC{ld_u32(bx[k], j), 0., own(k, o), o, 0}; },
-                        [&](int k, int j, double s_, const PreC &pr) {
-                const int o = pr.o;
-                const double xo = o < n0 ? pr.xo : X[(o - n0) * KI + k];
-                const double e = pr.b - s_ - DELTASTAT * xo; // ex = bx - G'dz - A'dy - delta dx
-                stE(o, k, e); nex[k] = fmax(nex[k], fabs(e));
-            });
-            ell_dots_k3<T, I16, KI, true, true>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, xlb, n0, P.rA_slots,
-                        [&](int r) { return ld_u32(P.ipy, r); },
-                        [&](int k, int r, int o) { return PreC{ld_u32(by[k], r), 0., own(k, o), o, 0}; },
-                        [&](int k, int r, double s_, const PreC &pr) {
-                const int o = pr.o;
-                const double xo = o < n0 ? pr.xo : X[(o - n0) * KI + k];
-                const double e = pr.b - s_ + DELTASTAT * xo; // ey = by - A dx + delta dy
-                stE(o, k, e); ney[k] = fmax(ney[k], fabs(e));
-            });
-            ell_dots_k3<T, I16, KI, true, true>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, xlb, n0, P.rG_slots,
-                        [&](int i) { return ld_u32(P.ipz, i); },
-                        [&](int k, int i, int o) { return PreC{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), own(k, o), o, ld_u32(P.zdsign, i)}; },
-                        [&](int k, int i, double s_, const PreC &pr) {
-                const int o = pr.o;
-                const double xo = o < n0 ? pr.xo : X[(o - n0) * KI + k];
-                double v = pr.b - s_ + (double)pr.sg * DELTASTAT * xo; // ez = bz - G dx +/- delta dz ...
-                if (i < l) { v += init ? xo : pr.w * xo; nez[k] = fmax(nez[k], fabs(v)); } // ... + V dz (LP part; the compact solve has no cone rows)
-                stE(o, k, v);
-            });
-        } else {
         if (gt) g_tile_products<T, KI>(P, I0 + P.i_Gt, P.gt_colk, [&](int c, int k) { return X[c * KI + k]; },
                                        [&](int i, int k) { return X[P.gt_zslot[i] * KI + k]; }, Wg + P.w_gpart, gxv, gzv);
         ell_dots_k<T, I16, KI, DUAL>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
@@ -2337,8 +2117,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
             if (i < l) { v += init ? xo : pr.w * xo; nez[k] = fmax(nez[k], fabs(v)); } // ... + V dz (LP part)
             stE(o, k, v);
         });
-        }
-        if (!CPT && P.nc > 0) {
+        if (P.nc > 0) {
             __syncthreads();
             // cone blocks (expanded): ez += dz_true (init) or scale2add (ref :1629-1662)
 #pragma unroll
@@ -2463,19 +2242,11 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
 #pragma unroll
         for (int k = 0; k < KI; k++) {
             if (!undo[k]) continue;
-            if constexpr (CPT) { FOR_T(i, N) { const double v = Xg[i * KI + k]; if (i < n0) XL[i * KI + k] = v; else X[(i - n0) * KI + k] = v; } }
-            else if constexpr (NLDS == 1) { FOR_T(i, N) X[i * KI + k] = Xg[i * KI + k]; } // Xg still holds the previous iterate
+            if constexpr (NLDS == 1) { FOR_T(i, N) X[i * KI + k] = Xg[i * KI + k]; } // Xg still holds the previous iterate
             else { FOR_T(i, N) X[i] -= dxr[i]; }
         }
         if (all_done) break;
-        if constexpr (CPT) { // another step: park the iterate (leaf rows: XL -> Xg), residual of the rows of levels >= 1 -> sweep vector (the leaf rows' stays in E)
-            __syncthreads();
-            struct PK { double e[KI], l[KI]; };
-            for_t_pre<T, 6>(N, [&](int i) { PK r; ldK<KI>(E, i, r.e); ldK<KI>(XL, min(i, n0 - 1), r.l); return r; }, [&](int i, const PK &r) {
-                if (i < n0) stK<KI>(Xg, i, r.l);
-                else { double c[KI]; ldK<KI>(X, i - n0, c); stK<KI>(Xg, i, c); stK<KI>(SV, i - n0, r.e); }
-            });
-        } else if constexpr (NLDS == 1) { // another step: park the iterate in the slab, residual -> sweep vector (unit stride)
+        if constexpr (NLDS == 1) { // another step: park the iterate in the slab, residual -> sweep vector (unit stride)
             __syncthreads();
             for_t_pre<T, 6>(N, [&](int i) {
                 VKI<KI> r;
@@ -2495,7 +2266,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         if ((amask >> k) & 1) {
         gcdbl_p cv = Ik[k] + P.i_c;
         for_t_pre3<T, 8>(n, p, m, [&](int, int j) { // (j: index in [x | y | z]; c, b, h and dx, dy, dz are laid out in that order)
-            return V2{ldX(ld_u32(P.ipk, j), k), init ? 0. : ld_u32(cv, j)};
+            return V2{X[ld_u32(P.ipk, j) * KI + k], init ? 0. : ld_u32(cv, j)};
         }, [&](int rg, int j, const V2 &r) {
             dx[k][j] = r.a;
             const double t = r.b * r.a;
@@ -2952,8 +2723,7 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
             // the two right-hand sides of this point of the algorithm do not depend on each other: one dual solve
             if constexpr (NLDS == 1) {
                 if (stage == ST_KKT1) kkt_post_any<T>(ps, I, W, ST_KKT1); // RHSaffine (ref :1176) needs the residuals only
-                if (P.dual == 2) kkt_solve<T, 1, I16, 2, true, true>(ps, I, I, W, stage, 3); // compact pair: fits beside a second workgroup
-                else kkt_solve<T, 1, I16, 2, true>(ps, I, I, W, stage, 3);
+                kkt_solve<T, 1, I16, 2, true>(ps, I, I, W, stage, 3);
                 const int second = (stage == ST_KKT1) ? ST_KKT_AFF : ST_KKT_INIT2;
                 if (stage == ST_KKT_INIT1) kkt_post_any<T>(ps, I, W, ST_KKT_INIT1);
                 __syncthreads();

@@ -215,41 +215,6 @@ def test_deferred_l_factorisation_is_bit_identical_to_the_stored_l_one(name, mon
         assert np.array_equal(a_, b_)
 
 
-@pytest.mark.parametrize("name,B", [("MPC02", 600), ("MPC02", 64), ("lp_afiro", 300), ("lp_adlittle", 300), ("lp_bandm", 300), ("lp_agg", 300)])
-def test_compact_dual_solve_is_bit_identical_to_single_and_full_dual_solves(name, B, monkeypatch):
-    # Round 5: the COMPACT dual right-hand-side solve (eicos_dims.dual_rhs = 2: only the rows of levels >= 1 of the two
-    # interleaved KKT-space vectors in LDS, the leaf rows of the elimination tree in the workspace slab) performs the arithmetic of the
-    # single solves row by row in the same order -- x, y, z, s, every counter and every Information field must be bit-identical to the
-    # single right-hand-side path (EICOS_DUAL=0) and, where two full vectors fit LDS, to the full dual solve (EICOS_DUAL=1).
-    pat, sets = load_fixture(name)
-    d = (feasible_batch if name == "MPC02" else perturbed_batch)(pat, sets[0], 0, B)
-    monkeypatch.setenv("EICOS_TILES", "0")  # (the compact pair exists on the pure scalar path)
-    res = {}
-    for mode in ("2", "0", "1"):
-        monkeypatch.setenv("EICOS_DUAL", mode)
-        g = eicos_amd.BatchSolver(pat, B)
-        dm = g.dims()
-        if mode == "2" and dm["dual_rhs"] != 2:
-            g.close()
-            pytest.skip(f"{name}: fewer than half of the elimination order are leaves (or the pattern has cones): no compact pair")
-        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
-        codes = g.solve(); ia = g.info_arrays(); x = g.solution(); y, z, s_ = g.duals()
-        res[mode] = (dm["dual_rhs"], codes, ia, x, y, z, s_)
-        g.close()
-    assert res["2"][0] == 2 and res["0"][0] == 0
-    ref = res["2"]
-    assert np.sum(ref[1] == 0) >= 0.6 * B
-    for mode in ("0", "1"):
-        r = res[mode]
-        assert np.array_equal(r[1], ref[1]), mode
-        for k in ("iter", "pcost", "dcost", "pres", "dres", "gap", "mu", "step", "sigma", "tau", "kap", "n_factor", "n_ldlsolve", "nitref1", "nitref2", "nitref3"):
-            assert np.array_equal(r[2][k], ref[2][k]), (mode, k)
-        for a, b in zip(r[3:], ref[3:]):
-            assert np.array_equal(a, b), mode
-    # ... and it does what it is for: one pass over L for the two independent systems
-    assert ref[2]["n_sweep"].sum() < ref[2]["n_ldlsolve"].sum() and np.array_equal(res["0"][2]["n_sweep"], res["0"][2]["n_ldlsolve"])
-
-
 def test_kernel_build_reported_for_the_handle(monkeypatch):
     # which compilation of k_solve a handle launches is part of its description: 256-thread workgroups at <= 2 per CU take the
     # 256-VGPR build ("w2"), small patterns the LDS-resident one, everything else the default one; EICOS_W2=0 forbids the first
