@@ -1141,6 +1141,16 @@ int eicos_batch_kernel_build(eicos_batch *h) {
 }
 
 int eicos_internal_device(const eicos_batch *h) { return h ? h->device : -1; }
+// ms from the start of `from`'s most recent solve to the end of `to`'s (two handles on ONE device: the span of a device that holds
+// several shards of an eicos_multi); both solves must have completed
+int eicos_internal_solve_span_ms(eicos_batch *from, eicos_batch *to, float *ms) {
+    if (!from || !to || !ms || from->device != to->device || !from->solve_timed || !to->solve_timed) return fail(EICOS_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(from->device));
+    HIP_TRY(hipEventSynchronize(from->ev_s1));
+    HIP_TRY(hipEventSynchronize(to->ev_s1));
+    HIP_TRY(hipEventElapsedTime(ms, from->ev_s0, to->ev_s1));
+    return EICOS_OK;
+}
 
 int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     if (!h || !o) return fail(EICOS_E_INVALID, "NULL argument");

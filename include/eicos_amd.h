@@ -209,7 +209,8 @@ int eicos_multi_set_dynamic_regularization(eicos_multi *mh, double delta, double
 /* the shards: their number, and shard s's single-GPU handle (every eicos_batch_* call works on it), instance range and device */
 int eicos_multi_num_shards(eicos_multi *mh);
 int eicos_multi_shard(eicos_multi *mh, int s, eicos_batch **handle, int *first, int *count, int *device);
-/* HIP-event duration of the most recent solve of every shard (ms): the maximum, and optionally each ([num_shards]) */
+/* HIP-event duration of the most recent solve (ms): per_shard ([num_shards], optional) = every shard's own launch; ms_max = the slowest
+ * DEVICE -- for a device that holds several shards, from the start of its first launch to the end of its last one */
 int eicos_multi_last_solve_ms(eicos_multi *mh, float *ms_max, float *per_shard);
 int eicos_multi_destroy(eicos_multi *mh);
 const char *eicos_multi_last_error(void);

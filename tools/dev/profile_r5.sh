@@ -1,8 +1,8 @@
-# round 4: rocprofv3 summaries for profiles/ -- kernel stats of the bench command + PMC passes (separate runs, kernel-trace only)
+# round 5: rocprofv3 summaries for profiles/ -- kernel stats of the bench command + PMC passes (separate runs, kernel-trace only)
 # for EVERY workload of the default bench line (headline, its SOC leg, and the configs).  Every pass is bounded.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/prof_r4
+out=gpurun_out/prof_r5
 rm -rf $out; mkdir -p $out
 python3 bench.py --steps 10 --warmup 2 > $out/bench_plain.json 2> $out/bench_plain.err
 tail -1 $out/bench_plain.json | cut -c1-200

@@ -1,6 +1,6 @@
-# profiles/<tag>_* from gpurun_out/prof_r4 (tools/dev/profile_r4.sh): usage tools/dev/summarize_r4.sh r04_v1
+# profiles/<tag>_* from gpurun_out/prof_r5 (tools/dev/profile_r5.sh): usage tools/dev/summarize_r4.sh r05_v1
 set -e
-t=$1; s=gpurun_out/prof_r4
+t=$1; s=gpurun_out/prof_r5
 python tools/summarize_profile.py $s profiles/$t "MPC02 batch=1024" "" > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_soc "MPC02-SOC batch=1024" soc_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_tile "dense-front batch=512" tile_ > /dev/null
