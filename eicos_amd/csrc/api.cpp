@@ -28,6 +28,7 @@
 #include "envknob.hpp"
 
 using namespace eicos;
+static constexpr int KI_MAX_HOST = 2; // right-hand sides of a dual solve (kernels.hip: KI_MAX)
 
 static thread_local std::string g_err;
 static std::mutex g_slot_mu;
@@ -529,6 +530,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     TileSweeps TSW;
     if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_STRIP);
     put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
+    put(D.tl_fsplit, TSW.fsplit); put(D.tl_bsplit, TSW.bsplit);
     TileFactorOps TFO;
     if (tile) {
         // pure tile mode: tiles of the K image no KKT entry lands in (targets that exist through fill only) start from zero without
@@ -577,7 +579,8 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const size_t avail = 160 * 1024 - 4096, vec = (size_t)std::max(D.Npad, 16) * sizeof(double);
         const size_t lds_static = 4096; // struct Sh + the per-instance states of kernels.hip (reductions + scalar state), rounded up
         // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
-        const size_t scratch = tile ? (size_t)(h->threads / 64) * TILE_SCR * sizeof(double) : 0;
+        // ... and the partial-sum slots of split blocks in the tile sweeps (TILE_PARTS x 16 rows x two right-hand sides)
+        const size_t scratch = tile ? ((size_t)(h->threads / 64) * TILE_SCR + (size_t)TILE_PARTS * 16 * KI_MAX_HOST) * sizeof(double) : 0;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
         const int wgs_by_regs = (h->threads == 256 ? 3 : (h->threads == 512 ? 2 : 4)) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
@@ -617,6 +620,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         h->dyn_lds = h->nlds >= 1 ? (size_t)nvec * vec + meta : scratch;
         D.lds_tab = h->nlds >= 1 ? nvec * D.Npad : 0;
         D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
+        D.tl_part = D.tl_scratch + (h->threads / 64) * TILE_SCR;
         // LDS-resident variant (small patterns, kernels_ldsres.hip): when the instance slab and the workspace slab fit LDS
         // beside the vectors and tables, k_solve works on LDS copies of both, so the elementwise stages and the products wait
         // for LDS instead of L2 (+12 % on lp_afiro at batch 256; the level-by-level sweeps are issue-bound and do not change:

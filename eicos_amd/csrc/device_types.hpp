@@ -158,7 +158,9 @@ struct DevPat {
     int tl_nimg, tl_scratch;       // entries of the K image scatter; offset (doubles) of the per-wave LDS scratch
     gint_p tl_blev, tl_tgt_lev, tl_tgt, tl_tp, tl_pa, tl_pb, tl_pk, tl_fin_lev, tl_fin; // levels, factor targets / pairs, finalise lists
     gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view
-    gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op
+    gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op; ptr: [(level * 2 + phase) * NW + wave]
+    gint_p tl_fsplit, tl_bsplit;               // per level (sweep order): 1 = the level has split blocks, i.e. a second phase behind a barrier
+    int tl_part;                               // offset (doubles) of the TILE_PARTS partial-sum slots (16 x KI_MAX doubles each) in the dynamic LDS
     gint_p tl_facops, tl_facptr;               // per-wavefront flat schedule of the factorisation's accumulation phase (TileFactorOps)
     gint_p tl_ident;               // per block: 1 = the diagonal tile of L is the identity (skipped by the sweeps)
     gint_p tl_img_dst, tl_img_src, tl_psign; // K image scatter (slab offset -> image index); quasi-definite pivot sign per slot
@@ -189,6 +191,11 @@ struct DevPat {
 constexpr int tile_op(int r, int k) { return (((k & 3) * 16 + r) << 2) + (k >> 2); }
 constexpr int tile_res(int r, int c) { return (((r & 3) * 16 + c) << 2) + (r >> 2); }
 constexpr int TOP_DIAG = 1, TOP_IDENT = 2; // tile sweep op flags: closes its block (diagonal tile) / that diagonal tile is the identity (no load)
+// A block whose row (forward) / column (backward) of tiles is much longer than a wavefront's share of its level is SPLIT over several
+// wavefronts (tiles.hpp: build_tile_sweeps): every part ends with a TOP_PART operation that writes the wavefront's partial sum to an LDS
+// slot (op.z), and the block is closed in a second phase of the level, after a barrier, by a TOP_DIAG operation that adds its
+// TOP_NPART (flags >> TOP_NPART_SHIFT) partial sums, slots op.z ..., in slot order.  TILE_PARTS = slots per level.
+constexpr int TOP_PART = 4, TOP_NPART_SHIFT = 8, TILE_PARTS = 32;
 constexpr int TILE_PF = 6;          // tile loads in flight per wavefront in the tile sweeps (op lists are padded to a multiple)
 #ifndef EICOS_TILE_FPF
 #define EICOS_TILE_FPF 3

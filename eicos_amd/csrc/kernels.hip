@@ -1381,17 +1381,23 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
     gcdbl_p LC = W + P.w_LC, LR = W + P.w_LR, DL = W + P.w_DL, invD = W + P.w_invD + P.tl_base;
     const int lane = threadIdx.x & 63, wave = uni((int)threadIdx.x >> 6), kq = lane >> 4, lc = lane & 15;
     double *scr = g_dyn + P.tl_scratch + wave * TILE_SCR; // wave-private 16 x 17 tile in LDS: L_JJ of the block being closed
+    double *part = g_dyn + P.tl_part;                     // partial sums of split blocks: slot q at (q * 16 + row) * NR
     auto bar = [&] { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); };
     auto fold = [](double v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
     // One sweep: per level every wavefront walks ITS flat list of tile operations (host: build_tile_sweeps) -- the tiles
     // of its blocks, each block closed by its diagonal operation -- with the tile loads of the next TILE_PF operations in
     // flight across block boundaries (they do not depend on ws).
-    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gcdbl_p val, gcdbl_p dia, auto bwd) {
+    // A level has a second phase when it holds SPLIT blocks (device_types.hpp: TOP_PART): phase 0 = tiles, whole blocks and the parts of
+    // split blocks (partial sums -> LDS slots), barrier, phase 1 = the split blocks' diagonal operations (partial sums added in slot order).
+    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gint_p split_g, gcdbl_p val, gcdbl_p dia, auto bwd) {
         constexpr bool scale = decltype(bwd)::value; // backward: x_J = L_JJ^-T (y_J / D_J - ...), forward: y_J = L_JJ^-1 (b_J - ...)
         cint4_p ops = (cint4_p)(unsigned long long)ops_i;
-        cint_p ptr = as_const(ptr_g);
+        cint_p ptr = as_const(ptr_g), split = as_const(split_g);
         for (int v = 0; v < P.nblev; v++) {
-            const int o0 = ptr[v * NW + wave], o1 = ptr[v * NW + wave + 1]; // (o1 - o0) is a multiple of TILE_STRIP
+          const int nph = split[v] ? 2 : 1; // (workgroup-uniform: a scalar load)
+          for (int ph = 0; ph < nph; ph++) {
+            if (ph) bar(); // the partial sums of phase 0 are in LDS
+            const int o0 = ptr[(v * 2 + ph) * NW + wave], o1 = ptr[(v * 2 + ph) * NW + wave + 1]; // (o1 - o0) is a multiple of TILE_STRIP
             d4_t qv[TILE_PF];
             // unconditional: a conditional load would force s_waitcnt vmcnt(0) at every join and serialise the queue
             auto load = [&](int o, d4_t &x) {
@@ -1413,7 +1419,14 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                     const d4_t cv = qv[u];
                     load(o + uu + TILE_PF, qv[u]);
                     const int fl = op.w, vb = op.y;
-                    if (!(fl & TOP_DIAG)) {
+                    if (fl & TOP_PART) { // a part of a split block ends: the partial sum goes to its LDS slot
+#pragma unroll
+                        for (int k = 0; k < NR; k++) {
+                            const double pv = fold(acc[k]); // (every 16-lane row holds the whole block vector)
+                            if (lane < 16) part[(op.z * 16 + lane) * NR + k] = pv;
+                            acc[k] = 0.;
+                        }
+                    } else if (!(fl & TOP_DIAG)) {
 #pragma unroll
                         for (int st = 0; st < 4; st++) {
                             double y[NR];
@@ -1425,9 +1438,12 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                         double own[NR], res[NR];
                         ldK<NR>(ws, vb * 16 + lc, own);
                         const double idv = scale ? invD[vb * 16 + lc] : 1.;
+                        const int np = fl >> TOP_NPART_SHIFT; // split block: its partial sums, added in slot order (0 for a whole block)
 #pragma unroll
                         for (int k = 0; k < NR; k++) {
-                            res[k] = (scale ? own[k] * idv : own[k]) - fold(acc[k]); // (every 16-lane row holds the whole block vector)
+                            double sum = fold(acc[k]); // (every 16-lane row holds the whole block vector)
+                            for (int q = 0; q < np; q++) sum += part[((op.z + q) * 16 + lc) * NR + k];
+                            res[k] = (scale ? own[k] * idv : own[k]) - sum;
                             acc[k] = 0.;
                         }
                         if (!(fl & TOP_IDENT)) {
@@ -1455,11 +1471,12 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                     }
                 }
             }
-            bar();
+          }
+          bar();
         }
     };
-    sweep(P.tl_fops, P.tl_fptr, LC, DL, std::false_type{}); // forward: block rows, levels up
-    sweep(P.tl_bops, P.tl_bptr, LR, DL, std::true_type{});  // backward: block columns, levels down
+    sweep(P.tl_fops, P.tl_fptr, P.tl_fsplit, LC, DL, std::false_type{}); // forward: block rows, levels up
+    sweep(P.tl_bops, P.tl_bptr, P.tl_bsplit, LR, DL, std::true_type{});  // backward: block columns, levels down
 }
 
 // ---------------- G in dense tiles: G x and G' z in ONE pass over the values (DevPat::gt_on, host: api.cpp) ----------------

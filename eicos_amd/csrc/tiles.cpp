@@ -1,6 +1,8 @@
 // Host-side construction of the tile plan (see tiles.hpp).  Plain C++17, no GPU code.
 #include "tiles.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -138,48 +140,108 @@ TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf, const std
 TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
     TileSweeps W;
     W.NW = NW;
-    auto build = [&](bool fwd, std::vector<int> &ops, std::vector<int> &ptr) {
+    const bool allow_split = !(getenv("EICOS_EXPERIMENT") && getenv("EICOS_TILE_SPLIT") && !strcmp(getenv("EICOS_EXPERIMENT"), "1") && !strcmp(getenv("EICOS_TILE_SPLIT"), "0"));
+    auto build = [&](bool fwd, std::vector<int> &ops, std::vector<int> &ptr, std::vector<int> &split) {
         ptr.assign(1, 0);
+        split.assign(T.nblev, 0);
         for (int step = 0; step < T.nblev; step++) {
             const int v = fwd ? step : T.nblev - 1 - step;
             const int b0 = T.blev_ptr[v], b1 = T.blev_ptr[v + 1];
             auto ntiles = [&](int B) { return fwd ? T.tr_ptr[B + 1] - T.tr_ptr[B] : T.tc_ptr[B + 1] - T.tc_ptr[B]; };
-            std::vector<int> order(b1 - b0);
-            std::iota(order.begin(), order.end(), b0);
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ntiles(a) > ntiles(b); });
+            // work items: whole blocks, or parts of a split block (tile range [e0, e1) of the block's list, partial-sum slot)
+            struct Item { int B, e0, e1, slot; };
+            std::vector<Item> items;
+            struct Closing { int B, slot0, np; };
+            std::vector<Closing> closing; // diagonal operations of the split blocks (phase 1)
+            long total = 0;
+            for (int B = b0; B < b1; B++) total += ntiles(B) + 2;
+            const long share = std::max<long>(2L * pf, (total + NW - 1) / NW); // a wavefront's share of the level (never below two trips of the queue)
+            int slots = 0;
+            for (int B = b0; B < b1; B++) {
+                const int n = ntiles(B);
+                int parts = 1;
+                if (allow_split && NW > 1 && n > share + share / 4) parts = (int)std::min<long>(NW, (n + share - 1) / share);
+                if (slots + parts > TILE_PARTS) parts = 1;
+                if (parts == 1) { items.push_back({B, 0, n, -1}); continue; }
+                closing.push_back({B, slots, parts});
+                for (int q = 0; q < parts; q++) items.push_back({B, (int)((long)n * q / parts), (int)((long)n * (q + 1) / parts), slots++});
+            }
+            auto weight = [&](const Item &it) { return (long)(it.e1 - it.e0) + (it.slot < 0 ? 2 : 1); };
+            std::vector<int> order(items.size());
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight(items[a]) > weight(items[b]); });
             std::vector<std::vector<int>> mine(NW);
             std::vector<long> load(NW, 0);
-            for (int B : order) { // longest first onto the least loaded wavefront
+            for (int i : order) { // longest first onto the least loaded wavefront
                 const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-                mine[w].push_back(B); load[w] += ntiles(B) + 2;
+                mine[w].push_back(i); load[w] += weight(items[i]);
             }
-            for (int w = 0; w < NW; w++) {
-                for (int B : mine[w]) {
-                    if (fwd) for (int e = T.tr_ptr[B]; e < T.tr_ptr[B + 1]; e++) { const int t = T.tr_tile[e]; ops.insert(ops.end(), {t, T.t_col[t], B, 0}); }
-                    else for (int t = T.tc_ptr[B]; t < T.tc_ptr[B + 1]; t++) ops.insert(ops.end(), {t, T.t_row[t], B, 0});
+            // pad to a multiple of `pf` operations with products against the all-zero vector block nb: the kernel's software
+            // pipeline then has no conditional around its loads (a conditional load defeats the s_waitcnt counting)
+            auto close_segment = [&]() { while (((int)ops.size() / 4 - ptr.back()) % pf) ops.insert(ops.end(), {0, T.nb, 0, 0}); ptr.push_back((int)ops.size() / 4); };
+            for (int w = 0; w < NW; w++) { // phase 0
+                for (int i : mine[w]) {
+                    const Item &it = items[i];
+                    const int B = it.B;
+                    if (fwd) for (int e = T.tr_ptr[B] + it.e0; e < T.tr_ptr[B] + it.e1; e++) { const int t = T.tr_tile[e]; ops.insert(ops.end(), {t, T.t_col[t], B, 0}); }
+                    else for (int t = T.tc_ptr[B] + it.e0; t < T.tc_ptr[B] + it.e1; t++) ops.insert(ops.end(), {t, T.t_row[t], B, 0});
+                    if (it.slot >= 0) ops.insert(ops.end(), {0, T.nb, it.slot, TOP_PART}); // partial sum -> LDS slot (its unconditional load: tile 0)
                     // identity diagonal tile: nothing to multiply; its (unconditional) load is pointed at diagonal tile 0, which stays cached
-                    ops.insert(ops.end(), {T.ident[B] ? 0 : B, B, B, TOP_DIAG | (T.ident[B] ? TOP_IDENT : 0)});
+                    else ops.insert(ops.end(), {T.ident[B] ? 0 : B, B, 0, TOP_DIAG | (T.ident[B] ? TOP_IDENT : 0)});
                 }
-                // pad to a multiple of `pf` operations with products against the all-zero vector block nb: the kernel's software
-                // pipeline then has no conditional around its loads (a conditional load defeats the s_waitcnt counting)
-                while (((int)ops.size() / 4 - ptr.back()) % pf) ops.insert(ops.end(), {0, T.nb, 0, 0});
-                ptr.push_back((int)ops.size() / 4);
+                close_segment();
             }
+            for (int w = 0; w < NW; w++) { // phase 1: the split blocks are closed, dealt round-robin
+                for (size_t c = (size_t)w; c < closing.size(); c += (size_t)NW) {
+                    const Closing &cl = closing[c];
+                    ops.insert(ops.end(), {T.ident[cl.B] ? 0 : cl.B, cl.B, cl.slot0, TOP_DIAG | (T.ident[cl.B] ? TOP_IDENT : 0) | (cl.np << TOP_NPART_SHIFT)});
+                }
+                close_segment();
+            }
+            split[step] = closing.empty() ? 0 : 1;
         }
     };
-    build(true, W.fops, W.fptr);
-    build(false, W.bops, W.bptr);
-    if (getenv("EICOS_PLAN_STATS")) { // developer aid: per level, blocks and the op count of the busiest / the average wavefront
+    build(true, W.fops, W.fptr, W.fsplit);
+    build(false, W.bops, W.bptr, W.bsplit);
+    // every tile exactly once, every block closed exactly once, partial slots written before they are read (by construction; checked)
+    for (int pass = 0; pass < 2; pass++) {
+        const std::vector<int> &ops = pass ? W.bops : W.fops, &ptr = pass ? W.bptr : W.fptr;
+        std::vector<int> seen_tile(T.nt, 0), closed(T.nb, 0);
+        for (int st = 0; st < T.nblev; st++) {
+            std::vector<int> written(TILE_PARTS, 0);
+            for (int ph = 0; ph < 2; ph++)
+                for (int w = 0; w < NW; w++)
+                    for (int o = ptr[(st * 2 + ph) * NW + w]; o < ptr[(st * 2 + ph) * NW + w + 1]; o++) {
+                        const int x = ops[4 * o], y = ops[4 * o + 1], z = ops[4 * o + 2], fl = ops[4 * o + 3];
+                        if (fl & TOP_PART) { if (ph != 0 || z < 0 || z >= TILE_PARTS || written[z]++) throw std::logic_error("tile sweeps: bad partial slot"); }
+                        else if (fl & TOP_DIAG) {
+                            closed[y]++;
+                            const int np = fl >> TOP_NPART_SHIFT;
+                            if ((np > 0) != (ph == 1)) throw std::logic_error("tile sweeps: split block closed in the wrong phase");
+                            for (int q = 0; q < np; q++) if (!written[z + q]) throw std::logic_error("tile sweeps: partial sum read before it is written");
+                        } else if (y != T.nb) seen_tile[x]++;
+                    }
+        }
+        for (int t = 0; t < T.nt; t++) if (seen_tile[t] != 1) throw std::logic_error("tile sweeps: a tile is not swept exactly once");
+        for (int b = 0; b < T.nb; b++) if (closed[b] != 1) throw std::logic_error("tile sweeps: a block is not closed exactly once");
+    }
+    if (getenv("EICOS_PLAN_STATS")) { // developer aid: per level, blocks and the op count of the busiest / the average wavefront (phase 0 + phase 1)
         for (int pass = 0; pass < 2; pass++) {
             const std::vector<int> &ptr = pass ? W.bptr : W.fptr;
             fprintf(stderr, "[tile sweeps NW=%d] %s:", NW, pass ? "backward" : "forward");
+            long crit = 0, totall = 0;
             for (int st = 0; st < T.nblev; st++) {
-                int mx = 0, tot = 0;
-                for (int w = 0; w < NW; w++) { const int c = ptr[st * NW + w + 1] - ptr[st * NW + w]; mx = std::max(mx, c); tot += c; }
                 const int v = pass ? T.nblev - 1 - st : st;
-                fprintf(stderr, " L%d[%d blk: max %d / avg %.1f]", v, T.blev_ptr[v + 1] - T.blev_ptr[v], mx, (double)tot / NW);
+                fprintf(stderr, " L%d[%d blk:", v, T.blev_ptr[v + 1] - T.blev_ptr[v]);
+                for (int ph = 0; ph < 2; ph++) {
+                    int mx = 0, tot = 0;
+                    for (int w = 0; w < NW; w++) { const int c = ptr[(st * 2 + ph) * NW + w + 1] - ptr[(st * 2 + ph) * NW + w]; mx = std::max(mx, c); tot += c; }
+                    if (ph == 0 || tot) fprintf(stderr, " max %d / avg %.1f%s", mx, (double)tot / NW, ph ? " (closing)" : "");
+                    crit += mx; totall += tot;
+                }
+                fprintf(stderr, "]");
             }
-            fprintf(stderr, "\n");
+            fprintf(stderr, "  critical path %ld ops, %.1f per wavefront\n", crit, (double)totall / NW);
         }
     }
     return W;

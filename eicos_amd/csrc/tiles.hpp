@@ -49,10 +49,16 @@ struct TilePlan {
 // its blocks, each block closed by its diagonal operation -- so that its loads can run ahead across block boundaries.
 // op = {tile id (diagonal op: the block), vector block the tile multiplies, block being accumulated, flags}
 // flags TOP_DIAG / TOP_IDENT: device_types.hpp
+// A block whose tile list is much longer than a wavefront's share of the level (the top of the block tree: one or two blocks per level, up
+// to 48 tiles each on the dense-front config while seven wavefronts wait) is SPLIT into parts dealt like blocks; a part ends with a
+// TOP_PART operation (partial sum -> LDS slot) and the block's diagonal operation moves to a second phase of the level that adds the
+// partial sums in slot order (device_types.hpp).  ptr has two segments per (level, wave): phase 0 (tiles, parts, whole blocks), phase 1
+// (the split blocks' diagonal operations); split[level] = 1 when phase 1 is not empty.
 struct TileSweeps {
     int NW = 0;
     std::vector<int> fops, bops;       // 4 ints per op
-    std::vector<int> fptr, bptr;       // [nblev * NW + 1]: op range of (level, wave), levels in sweep order (forward: up, backward: down)
+    std::vector<int> fptr, bptr;       // [nblev * 2 * NW + 1]: op range of (level, phase, wave), levels in sweep order (forward: up, backward: down)
+    std::vector<int> fsplit, bsplit;   // [nblev]
 };
 TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf /* list lengths are padded to a multiple of pf */);
 
