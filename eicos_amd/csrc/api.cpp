@@ -4,6 +4,7 @@
 #include "../../include/eicos_amd.h"
 
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>
@@ -840,9 +841,23 @@ class CopyPool {
         done_cv.wait(lk, [&] { return left.load() == 0; });
     }
   private:
+    // cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container's hardware_concurrency() is the host's)
+    static int usable_cores() {
+        int n = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0}; long period = 0;
+            if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) n = std::max(1, std::min(n, (int)(std::atol(q) / period)));
+            std::fclose(f);
+        }
+        return n;
+    }
     CopyPool() {
-        const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-        nthreads_ = (int)std::min(6u, hc > 2 ? hc / 2 - 1 : 0u);
+        // the bounce copy of a host-pointer updateData must keep up with the PCIe link (~50 GB/s; one core copies ~10 GB/s): up to ten
+        // helper threads, two cores left to the caller and the runtime; EICOS_COPY_THREADS overrides (experiments)
+        const int cores = usable_cores();
+        nthreads_ = env_knob("EICOS_COPY_THREADS", std::max(0, std::min(10, cores - 2)), 0, 64);
         for (int i = 0; i < nthreads_; i++) th_.emplace_back([this] { run(); });
     }
     ~CopyPool() {
