@@ -158,6 +158,17 @@ namespace EiCOS
             if (n_ > 0) mcheck(eicos_multi_solution(h_, x.data()), "eicos_multi_solution");
             return x;
         }
+        // x into caller-owned storage [batch][n] (pinned memory from hostAlloc: one strided copy per shard, no bounce)
+        void solution(double *x) const { if (n_ > 0) mcheck(eicos_multi_solution(h_, x), "eicos_multi_solution"); }
+        // Pinned host arrays (eicos_host_alloc): updateData reads them in place over PCIe instead of through the bounce buffers -- for the
+        // arrays a closed loop rewrites every sample.  Not in the reference (which computes on the host).
+        static double *hostAlloc(size_t doubles)
+        {
+            void *ptr = eicos_host_alloc(doubles * sizeof(double));
+            if (!ptr) throw std::runtime_error(std::string("eicos_host_alloc: ") + eicos_last_error());
+            return static_cast<double *>(ptr);
+        }
+        static void hostFree(double *ptr) { eicos_host_free(ptr); }
         std::vector<Information> getInfo() const
         {
             std::vector<eicos_info> raw(batch_);
