@@ -35,7 +35,8 @@
 #include "device_types.hpp"
 #include "launch.hpp"
 
-// This file is compiled three times.  EICOS_LDSRES = 0 (kernels.o): the slabs of an instance live in HBM.  EICOS_LDSRES = 1
+// This file is ONE source compiled FIVE times (kernels.hip, kernels_t128.hip, kernels_t512.hip, kernels_ldsres.hip, kernels_w2.hip: translation
+// units that build side by side; launch.hpp: solve_build() picks a handle's).  EICOS_LDSRES = 0: the slabs of an instance live in HBM.  EICOS_LDSRES = 1
 // (kernels_ldsres.o, namespace eicos::ldsres): the LDS-RESIDENT variant for small patterns -- k_solve copies the
 // instance slab and the workspace slab into LDS, solves there and copies both back, so every "slab" pointer below is an
 // LDS pointer (address space 3, ds_read / ds_write) and a dependent step of the sparse programs costs an LDS round trip

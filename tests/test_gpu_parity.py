@@ -928,6 +928,14 @@ def test_host_pointer_update_and_result_paths_are_bit_identical():
     g.update_device(0, 0, dev["c"] + 100 * pat.n * 8, 0, 0, first=100, count=256)
     g.solve()
     assert np.array_equal(g.solution(), xk) and not np.array_equal(xk[100:356], x0[100:356])
+    # ... and the same sub-range from a PINNED slice (read in place, NULL groups kept)
+    g.update_device(*[dev[k] for k in keys]); g.solve()
+    pc = eicos_amd.PinnedArray((256, pat.n)); pc.a[...] = d["c"][100:356]
+    g.update(None, None, pc.a, None, None, first=100, count=256)
+    assert g.last_update_path() == "pinned source in place"
+    g.solve()
+    assert np.array_equal(g.solution(), xk)
+    pc.close()
     g.close()
     for pa in list(pins.values()) + [px]:
         pa.close()
