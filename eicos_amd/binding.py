@@ -93,6 +93,10 @@ def _lib():
         L.eicos_host_alloc.restype = vp
         L.eicos_host_free.argtypes = [vp]
         L.eicos_host_free.restype = C.c_int
+        L.eicos_host_register.argtypes = [vp, C.c_size_t]
+        L.eicos_host_register.restype = C.c_int
+        L.eicos_host_unregister.argtypes = [vp]
+        L.eicos_host_unregister.restype = C.c_int
         L.eicos_debug_factor.argtypes = [vp, C.c_int, dp, dp]
         L.eicos_debug_pattern.argtypes = [vp, ip, ip, ip]
         L.eicos_debug_trace.argtypes = [vp, C.c_int, dp]
@@ -170,6 +174,18 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
+
+
+def host_register(a):
+    """Pin a C-contiguous float64 numpy array IN PLACE (eicos_host_register): updateData then reads it over PCIe without a bounce copy.
+    Keep the array alive and call host_unregister(a) before it is freed."""
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    _chk(_lib().eicos_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+    return a
+
+
+def host_unregister(a):
+    _chk(_lib().eicos_host_unregister(C.c_void_p(a.ctypes.data)))
 
 
 UPDATE_PATHS = {0: "none", 1: "pinned bounce", 2: "pinned source in place", 3: "peer GPU in place", 4: "staged peer copies"}

@@ -918,6 +918,23 @@ int eicos_host_free(void *p) {
     HIP_TRY(hipHostFree(p));
     return EICOS_OK;
 }
+// Pin arrays the caller already owns (std::vector storage, numpy arrays, ...) IN PLACE: hipHostRegister.  From then on updateData / solution
+// treat them like eicos_host_alloc memory (no bounce copy).  Registering costs about as much as a few bounce copies of the same
+// bytes, so it pays for arrays that are reused across calls -- the sample-by-sample rewrite of an MPC loop; the caller unregisters
+// before freeing them.
+int eicos_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) return fail(EICOS_E_INVALID, "bad argument");
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return EICOS_OK; }
+    if (e != hipSuccess) return fail(EICOS_E_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    return EICOS_OK;
+}
+int eicos_host_unregister(void *p) {
+    if (!p) return EICOS_OK;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(EICOS_E_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
+    return EICOS_OK;
+}
 int eicos_batch_last_update_path(eicos_batch *h) { return h ? h->last_update_path : fail(EICOS_E_INVALID, "NULL handle"); }
 
 // updateData from buffers that are not in the handle's HBM: host memory (src_dev < 0) or the HBM of another GPU (src_dev = that device,
@@ -1071,11 +1088,11 @@ static int fetch_rows(eicos_batch *h, double *dst, int off, int width) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         return EICOS_OK;
     }
-    int chunk = (int)std::max<size_t>(16, PIN_CHUNK_BYTES / wb);
+    // (chunks of ~4 MB: small enough that the device-to-host copy of one chunk and the host copy of the previous one overlap on a result of a few MB)
+    int chunk = (int)std::max<size_t>(16, (PIN_CHUNK_BYTES / 4) / wb);
     chunk = std::min(chunk, h->batch);
     int rc = ensure_pin(h, (size_t)chunk * width);
     if (rc != EICOS_OK) return rc;
-    chunk = (int)std::min<size_t>((size_t)h->batch, h->pin_doubles / (size_t)width); // (the buffers may be larger than asked for)
     for (int i = 0; i < 2; i++) if (h->pin_busy[i]) { HIP_TRY(hipEventSynchronize(h->pin_ev[i])); h->pin_busy[i] = false; }
     CopyPool &pool = CopyPool::get();
     auto issue = [&](int o, int bi) -> int {

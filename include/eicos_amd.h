@@ -105,6 +105,10 @@ int eicos_batch_update(eicos_batch *hd, int first, int count,
  * 3 peer GPU in place, 4 staged peer copies). */
 void *eicos_host_alloc(size_t bytes); /* pinned host memory the GPU addresses directly; NULL on failure */
 int eicos_host_free(void *p);
+/* ... or pin arrays the caller already owns IN PLACE (hipHostRegister): they then take the pinned path as well.  Registering costs about
+ * as much as a few bounce copies of the same bytes -- worth it for arrays reused across calls; unregister before freeing them. */
+int eicos_host_register(void *p, size_t bytes);
+int eicos_host_unregister(void *p);
 int eicos_batch_last_update_path(eicos_batch *hd);
 /* Same, DEVICE pointers (inputs already resident in HBM; no PCIe traffic). */
 int eicos_batch_update_device(eicos_batch *hd, int first, int count,

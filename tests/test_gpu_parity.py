@@ -928,6 +928,17 @@ def test_host_pointer_update_and_result_paths_are_bit_identical():
     g.update_device(0, 0, dev["c"] + 100 * pat.n * 8, 0, 0, first=100, count=256)
     g.solve()
     assert np.array_equal(g.solution(), xk) and not np.array_equal(xk[100:356], x0[100:356])
+    # the caller's own arrays pinned IN PLACE (eicos_host_register): the in-place path without an allocation by the library
+    own = {k: np.ascontiguousarray(d[k]).copy() for k in keys}
+    for k in keys:
+        eicos_amd.host_register(own[k])
+    g.update(*[own[k] for k in keys])
+    assert g.last_update_path() == "pinned source in place"
+    assert np.array_equal(g.solve(), codes0) and np.array_equal(g.solution(), x0)
+    for k in keys:
+        eicos_amd.host_unregister(own[k])
+    g.update(*[own[k] for k in keys])  # unregistered again: back on the bounce
+    assert g.last_update_path() == "pinned bounce"
     # ... and the same sub-range from a PINNED slice (read in place, NULL groups kept)
     g.update_device(*[dev[k] for k in keys]); g.solve()
     pc = eicos_amd.PinnedArray((256, pat.n)); pc.a[...] = d["c"][100:356]
