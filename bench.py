@@ -57,7 +57,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "eicos_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile":  # (the build flags are part of the identity)
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
