@@ -827,18 +827,21 @@ class CopyPool {
         const int parts = (int)std::min<size_t>((size_t)nthreads_ + 1, (bytes + piece - 1) / piece);
         if (parts <= 1) { std::memcpy(dst, src, bytes); return; }
         const size_t per = ((bytes + parts - 1) / parts + 63) & ~(size_t)63;
-        std::atomic<int> left{parts - 1};
+        // completion state on the caller's stack: the count is changed and the caller notified INSIDE the lock, so a helper's last access to
+        // these objects is its unlock, which the caller's wait cannot overtake
+        int left = parts - 1;
         std::mutex done_mu; std::condition_variable done_cv;
         for (int k = 1; k < parts; k++) {
             const size_t a = std::min(bytes, (size_t)k * per), b = std::min(bytes, a + per);
             push([=, &left, &done_mu, &done_cv] {
                 if (b > a) std::memcpy((char *)dst + a, (const char *)src + a, b - a);
-                if (left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(done_mu); done_cv.notify_one(); }
+                std::lock_guard<std::mutex> lk(done_mu);
+                if (--left == 0) done_cv.notify_one();
             });
         }
         std::memcpy(dst, src, std::min(bytes, per));
         std::unique_lock<std::mutex> lk(done_mu);
-        done_cv.wait(lk, [&] { return left.load() == 0; });
+        done_cv.wait(lk, [&] { return left == 0; });
     }
   private:
     // cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container's hardware_concurrency() is the host's)
@@ -886,12 +889,16 @@ class CopyPool {
 
 // Is `p` host memory the GPU can address directly (hipHostMalloc / hipHostRegister / eicos_host_alloc)?  Then kernels read or write it
 // in place over PCIe and no bounce copy is needed.
-bool is_pinned_host(const void *p) {
-    if (!p) return false;
+// 0 = pageable host memory, 1 = pinned / registered host memory, 2 = device (or managed) memory
+int pointer_kind(const void *p) {
+    if (!p) return 0;
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // (plain malloc memory: "invalid value")
-    return a.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; } // (plain malloc memory: "invalid value")
+    if (a.type == hipMemoryTypeHost) return 1;
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray) return 2;
+    return 0;
 }
+bool is_pinned_host(const void *p) { return pointer_kind(p) == 1; }
 // the handle's two pinned bounce buffers hold at least `doubles` each
 int ensure_pin(eicos_batch *h, size_t doubles) {
     if (doubles <= h->pin_doubles) return EICOS_OK;
@@ -1009,8 +1016,10 @@ int eicos_internal_update_staged(eicos_batch *h, int first, int count, const dou
         return rc;
     }
     // ---- host pointers ----
-    bool all_pinned = true;
-    for (const Arr &a : arr) if (a.src && a.w && !is_pinned_host(a.src)) all_pinned = false;
+    bool all_pinned = true, any_device = false;
+    for (const Arr &a : arr) if (a.src && a.w) { const int kind = pointer_kind(a.src); if (kind != 1) all_pinned = false; if (kind == 2) any_device = true; }
+    // a device pointer handed to the HOST-pointer entry point must not reach the bounce copy (a host memcpy from it would fault)
+    if (any_device) return fail(EICOS_E_INVALID, "eicos_batch_update takes host pointers: an array lives in device memory (use eicos_batch_update_device)");
     if (all_pinned && !env_knob("EICOS_HOST_BOUNCE", 0, 0, 1)) {
         const int rc = whole_range(2);
         if (rc != EICOS_OK) return rc;

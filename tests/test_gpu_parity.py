@@ -897,6 +897,9 @@ def test_host_pointer_update_and_result_paths_are_bit_identical():
     g.update_device(*[dev[k] for k in keys])
     codes0 = g.solve(); x0 = g.solution(); ia0 = g.info_arrays()
     assert np.all(codes0 == 0) and g.last_update_path() == "none"
+    # a DEVICE pointer handed to the host-pointer entry point is refused (the bounce copy would fault on it), nothing is changed
+    rc = hip.eicos_batch_update(g._h, 0, B, ctypes.cast(dev["Gpr"], ctypes.POINTER(ctypes.c_double)), None, None, ctypes.cast(dev["h"], ctypes.POINTER(ctypes.c_double)), None)
+    assert rc == -1 and b"device memory" in hip.eicos_last_error()
     # pageable host arrays: the bounce pipeline
     g.update(*[d[k] for k in keys])
     assert g.last_update_path() == "pinned bounce" and g.last_update_ms() > 0
