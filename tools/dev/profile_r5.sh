@@ -6,6 +6,8 @@ out=gpurun_out/prof_r5
 rm -rf $out; mkdir -p $out
 python3 bench.py --steps 10 --warmup 2 > $out/bench_plain.json 2> $out/bench_plain.err
 tail -1 $out/bench_plain.json | cut -c1-200
+# rehearsal of the N > 1 measurement path on this one GPU: eight shards of 512 through eicos_multi_* 
+python3 bench.py --multi 0,0,0,0,0,0,0,0 --total 4096 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_multi8.json 2> $out/bench_multi8.err
 run() { # prefix, full-counters?, bench args...
   pre=$1; full=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${pre}stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-soc --no-configs "$@" > $out/${pre}stats.log 2>&1

@@ -10,4 +10,5 @@ python tools/summarize_profile.py $s profiles/${t}_afiro "lp_afiro batch=256" af
 python tools/summarize_profile.py $s profiles/${t}_bandm "lp_bandm batch=256" bandm_ > /dev/null
 python tools/summarize_profile.py $s profiles/${t}_25fv47 "lp_25fv47 batch=256" fv47_ > /dev/null
 tail -1 $s/bench_plain.json > profiles/${t}_bench.json
+[ -s $s/bench_multi8.json ] && tail -1 $s/bench_multi8.json > profiles/${t}_bench_multi8.json
 ls profiles/${t}_*
