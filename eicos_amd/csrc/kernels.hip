@@ -109,6 +109,7 @@ template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : (T == 512 
 // in round 2: +0.2 ... +0.7 % on every config -- the loops wait for their operands, not for issue slots.)
 __device__ __forceinline__ double madd(double acc, double a, double b) { return acc + a * b; }
 constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values per reduction
+constexpr bool ELL_DQ = EICOS_W2 != 0; // product loops keep decoded slice descriptors in their queue (ell_dots, ell_dots_k)
 
 // scalar slots in LDS (written by thread 0 only)
 enum { SV_RESX0 = 0, SV_RESY0, SV_RESZ0, SV_PRESPREV, SV_RT, SV_DTAUDEN, SV_DTAUAFF, SV_DKAPAFF, SV_BKAP,
@@ -433,6 +434,11 @@ __device__ __forceinline__ void for_t_pre3(int n0, int n1, int n2, L &&ld, F &&f
 // cut into sub-slices whose partial sums are carried in a register).  `sm` may live in LDS (staged by k_solve) or in global memory.
 // Decoded slice descriptor; every field is workgroup-uniform (SGPRs).
 struct Sl { int row0, off, off16, cnt, lg, K, newlev, last, more, cont; };
+__device__ __forceinline__ Sl slice_decode(const PackedSlice &w) {
+    const int b = uni(w.bits);
+    return Sl{uni(w.row0), uni(w.off), uni(w.off16), b & ((1 << PS_LG) - 1), (b >> PS_LG) & 7, (b >> PS_K) & 7,
+              (b >> PS_NEWLEV) & 1, (b >> PS_LAST) & 1, (b >> PS_MORE) & 1, (b >> PS_CONT) & 1};
+}
 template <class Tab> __device__ __forceinline__ Sl slice_at(const Tab *tab, int s) {
     const PackedSlice w = tab[s]; // 16 bytes: one ds_read_b128 (LDS copy) or one global/scalar load
     const int b = uni(w.bits);
@@ -460,11 +466,10 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
     if (ns == 0) return; // no rows
     const int t = threadIdx.x;
     using R = decltype(pre(0));
-    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX]; R qr[ELL_DEPTH];
-    auto meta = [&](int s) { return slice_at(sm, s); };
+    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX]; R qr[ELL_DEPTH]; Sl qm[ELL_DEPTH]; // (qm: the slice's decoded descriptor, SGPRs)
     double carry = 0.; // partial sum of rows cut into sub-slices (SliceMeta::more / cont)
-    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX], R &nr) {
-        const Sl nm = meta(s);
+    auto load = [&](const Sl &nm, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX], R &nr, Sl &om) {
+        if constexpr (ELL_DQ) om = nm;
         const int lanes = nm.cnt << nm.lg;
         const bool act = t < lanes;
         load_indices<I16>(ni, eidx, eidx16, act, nm.K, nm.off, lanes, t, dummy_slot, nm.off16, d16);
@@ -476,17 +481,21 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
         nr = pre(act ? nm.row0 + (t >> nm.lg) : 0);
     };
 #pragma unroll
-    for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
+    for (int d = 0; d < ELL_DEPTH; d++) load(slice_at(sm, d < ns ? d : 0), qi[d], qv[d], qr[d], qm[d]);
+    // (ELL_DQ, the 256-VGPR build only: the queue keeps the decoded descriptors and the next one is read a step before it is decoded, see tri_sweep --
+    // round 5: headline +2 ... 3 %; in the register-tight builds the extra live scalars cost more than the round trip: batch 4096 and dense-front -2.5 %)
+    PackedSlice raw = sm[min(ELL_DEPTH, ns - 1)];
     // one slice step; `d` = the slice's slot of the register queue.  A trip of ELL_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
     // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of ELL_DEPTH, so
     // plans are padded to a multiple of ELL_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
     auto step = [&](const int d, const int s) __attribute__((always_inline)) {
-        const Sl m = meta(s);
+        const Sl m = ELL_DQ ? qm[d] : slice_at(sm, s);
         int ci[ELL_KMAX]; double cv[ELL_KMAX];
         const R cr = qr[d];
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) { ci[kk] = qi[d][kk]; cv[kk] = qv[d][kk]; }
-        load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
+        if constexpr (ELL_DQ) { load(slice_decode(raw), qi[d], qv[d], qr[d], qm[d]); raw = sm[min(s + ELL_DEPTH + 1, ns - 1)]; }
+        else load(slice_at(sm, min(s + ELL_DEPTH, ns - 1)), qi[d], qv[d], qr[d], qm[d]);
         const int lanes = m.cnt << m.lg;
         const bool act = t < lanes;
         double xg[ELL_KMAX];
@@ -500,7 +509,6 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
         if (m.cont) acc += carry;
         if (m.more) carry = acc;
         else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc, cr);
-    
     };
     int s0 = 0;
     for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
@@ -522,13 +530,12 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
     if (ns == 0) return; // no rows
     const int t = threadIdx.x;
     using R = decltype(pre(0, 0));
-    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX][KI]; R qr[ELL_DEPTH][KI];
-    auto meta = [&](int s) { return slice_at(sm, s); };
+    int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX][KI]; R qr[ELL_DEPTH][KI]; Sl qm[ELL_DEPTH]; // (qm: the slice's decoded descriptor, SGPRs)
     double carry[KI]; // partial sum of rows cut into sub-slices (SliceMeta::more / cont)
 #pragma unroll
     for (int k = 0; k < KI; k++) carry[k] = 0.;
-    auto load = [&](int s, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX][KI], R (&nr)[KI]) {
-        const Sl nm = meta(s);
+    auto load = [&](const Sl &nm, int (&ni)[ELL_KMAX], double (&nv)[ELL_KMAX][KI], R (&nr)[KI], Sl &om) {
+        if constexpr (ELL_DQ) om = nm;
         const int lanes = nm.cnt << nm.lg;
         const bool act = t < lanes;
         load_indices<I16>(ni, eidx, eidx16, act, nm.K, nm.off, lanes, t, dummy_slot, nm.off16, d16);
@@ -545,12 +552,15 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
         for (int k = 0; k < KI; k++) nr[k] = pre(k, act ? nm.row0 + (t >> nm.lg) : 0);
     };
 #pragma unroll
-    for (int d = 0; d < ELL_DEPTH; d++) load(d < ns ? d : 0, qi[d], qv[d], qr[d]);
+    for (int d = 0; d < ELL_DEPTH; d++) load(slice_at(sm, d < ns ? d : 0), qi[d], qv[d], qr[d], qm[d]);
+    // (ELL_DQ, the 256-VGPR build only: the queue keeps the decoded descriptors and the next one is read a step before it is decoded, see tri_sweep --
+    // round 5: headline +2 ... 3 %; in the register-tight builds the extra live scalars cost more than the round trip: batch 4096 and dense-front -2.5 %)
+    PackedSlice raw = sm[min(ELL_DEPTH, ns - 1)];
     // one slice step; `d` = the slice's slot of the register queue.  A trip of ELL_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
     // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of ELL_DEPTH, so
     // plans are padded to a multiple of ELL_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
     auto step = [&](const int d, const int s) __attribute__((always_inline)) {
-        const Sl m = meta(s);
+        const Sl m = ELL_DQ ? qm[d] : slice_at(sm, s);
         int ci[ELL_KMAX]; double cv[ELL_KMAX][KI]; R cr[KI];
 #pragma unroll
         for (int k = 0; k < KI; k++) cr[k] = qr[d][k];
@@ -560,7 +570,8 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
 #pragma unroll
             for (int k = 0; k < KI; k++) cv[kk][k] = qv[d][kk][k];
         }
-        load(min(s + ELL_DEPTH, ns - 1), qi[d], qv[d], qr[d]);
+        if constexpr (ELL_DQ) { load(slice_decode(raw), qi[d], qv[d], qr[d], qm[d]); raw = sm[min(s + ELL_DEPTH + 1, ns - 1)]; }
+        else load(slice_at(sm, min(s + ELL_DEPTH, ns - 1)), qi[d], qv[d], qr[d], qm[d]);
         const int lanes = m.cnt << m.lg;
         const bool act = t < lanes;
         double xg[ELL_KMAX][KI];
@@ -577,7 +588,6 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
             if (m.more) carry[k] = acc;
             else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(k, m.row0 + (t >> m.lg), acc, cr[k]);
         }
-    
     };
     int s0 = 0;
     for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
@@ -627,8 +637,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     } q[DEPTH];
     // every slice issues the same number of global loads per lane (inactive lanes / padding read the plan's dummy
     // slot: index N, value 0) so the compiler can count them in s_waitcnt vmcnt(n)
-    auto load = [&](int s, Slot &o) {
-        const Sl nm = slice_at(sm, s);
+    auto load_m = [&](const Sl &nm, Slot &o) {
         o.row0 = nm.row0; o.lg = nm.lg; o.K = nm.K; o.off = nm.off; o.newlev = nm.newlev;
         o.more = nm.more; o.cont = nm.cont;
         o.lanes = nm.cnt << o.lg;
@@ -656,6 +665,7 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
         } else ldK_g<KI, false>(invD, r, o.d);
         ldK<KI>(ws, r, o.own); // rows of later slices are not written before their own slice runs
     };
+    auto load = [&](int s, Slot &o) { load_m(slice_at(sm, s), o); };
     // ns is a multiple of TRI_DEPTH (the host pads plans with empty slices) and refills past the end
     // re-read the last slice, so the steady-state loop has no data-dependent branch around its loads
 #pragma unroll
@@ -663,9 +673,13 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     // one slice step; `d` = the slice's slot of the register queue.  A trip of TRI_TRIP slices is unrolled (the compiler's s_waitcnt insertion is
     // exact inside a trip and drains the load queue at every loop head: DESIGN.md 4.2); the remainder runs in trips of TRI_DEPTH, so
     // plans are padded to a multiple of TRI_DEPTH only -- a padded slice costs a full step of the dependent chain on small patterns
+    // The descriptor of the next slice to be prefetched is READ one step before it is decoded (readfirstlane needs the data: a descriptor
+    // read at the point of use is an LDS round trip on the dependent chain of every step; round 5: sweeps 44.8 -> 42.9 us per MPC02 solve).
+    PackedSlice raw = sm[min(DEPTH, ns - 1)];
     auto step = [&](const int d, const int s) __attribute__((always_inline)) {
         const Slot c = q[d];
-        load(min(s + DEPTH, ns - 1), q[d]);
+        load_m(slice_decode(raw), q[d]);
+        raw = sm[min(s + DEPTH + 1, ns - 1)];
         if (c.newlev) {
             if (SOLO) { if (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // slab vector: drain the level's stores
             else if (LDSBAR) lds_barrier();
