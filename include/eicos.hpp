@@ -169,6 +169,12 @@ namespace EiCOS
             return static_cast<double *>(ptr);
         }
         static void hostFree(double *ptr) { eicos_host_free(ptr); }
+        // ... or pin storage the caller already owns (a std::vector's data()) in place; unregister before it is freed or reallocated
+        static void hostRegister(double *ptr, size_t doubles)
+        {
+            if (eicos_host_register(ptr, doubles * sizeof(double)) != EICOS_OK) throw std::runtime_error(std::string("eicos_host_register: ") + eicos_last_error());
+        }
+        static void hostUnregister(double *ptr) { eicos_host_unregister(ptr); }
         std::vector<Information> getInfo() const
         {
             std::vector<eicos_info> raw(batch_);
