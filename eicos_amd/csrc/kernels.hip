@@ -30,6 +30,7 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "device_types.hpp"
@@ -2832,7 +2833,11 @@ __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
 }
 // Longest-processing-time-first order for k_solve's queue: instances keyed by the number of LDL solves of their
 // previous solve (DevInfo::n_ldlsolve; 0 before the first solve), counting sort, descending.  One workgroup.
-__global__ __launch_bounds__(1024) void k_order(int ps, const double *inst, int B, int *order) {
+// snake (one-round launches: B <= resident workgroups, several per CU): workgroup g lands on CU g mod ncu, so the instances are laid out
+// boustrophedon over rows of ncu -- row 0 the ncu longest in descending order, row 1 the next ncu ASCENDING, ... -- which pairs the longest
+// instance of a CU with the shortest of the next row instead of with the ncu-th longest: the pair sums are balanced, and a launch ends
+// when its slowest CU does.
+__global__ __launch_bounds__(1024) void k_order(int ps, const double *inst, int B, int *order, int snake, int ncu) {
     const DevPat &P = c_pat[ps];
     constexpr int NB = 1024;
     __shared__ int cnt[NB];
@@ -2846,7 +2851,14 @@ __global__ __launch_bounds__(1024) void k_order(int ps, const double *inst, int 
     __syncthreads();
     if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < NB; k++) { const int c = cnt[k]; cnt[k] = run; run += c; } }
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += blockDim.x) order[atomicAdd(&cnt[key(i)], 1)] = i;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        int pos = atomicAdd(&cnt[key(i)], 1); // rank in descending work (ties in arrival order)
+        if (snake && pos < snake) { // (snake = number of leading positions laid out boustrophedon: the first round of the launch)
+            const int row = pos / ncu, col = pos % ncu, len = min(ncu, snake - row * ncu);
+            if (row & 1) pos = row * ncu + (len - 1 - col);
+        }
+        order[pos] = i;
+    }
 }
 
 // ============================================================================================
@@ -3149,7 +3161,10 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
     // with a short one on each CU, which then finishes the long one alone (+7 % at batch 512 on 256 CUs).
     if (B <= order_min) order = nullptr; // at most one instance per CU: identity
     else {
-        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order);
+        // (EICOS_SNAKE=0 under EICOS_EXPERIMENT=1: plain descending order, for A/B runs.  Laying out the first round of a MULTI-round launch the
+        // same way measured +-0: profiles/r05_log_snake_order.log)
+        static const int snake_on = [] { const char *e = getenv("EICOS_EXPERIMENT"), *k = getenv("EICOS_SNAKE"); return !(e && k && !strcmp(e, "1") && !strcmp(k, "0")); }();
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, ps, inst, B, order, (snake_on && B <= grid) ? B : 0, order_min);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
