@@ -957,6 +957,36 @@ def test_host_pointer_update_and_result_paths_are_bit_identical():
         hip.hipFree(ctypes.c_void_p(v))
 
 
+def test_handles_on_concurrent_host_threads_share_the_copy_pool():
+    # the host-pointer pipeline is shared state (one copy pool per process, one creation lock per device): four handles created, updated from
+    # pageable arrays, solved and read back on four host threads at once must give the bits of the same calls made one after the other
+    import threading
+    pat, sets = load_fixture("MPC02")
+    B = 160  # 160 x 124 KB = 20 MB per update: two bounce chunks each
+    datas = [feasible_batch(pat, sets[0], 1000 * t, B) for t in range(4)]
+
+    def run(t, out):
+        g = eicos_amd.BatchSolver(pat, B, device=0)
+        d = datas[t]
+        for _ in range(2):
+            g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+            codes = g.solve()
+        out[t] = (codes, g.solution(), g.info_arrays()["iter"], g.last_update_path())
+        g.close()
+
+    seq, par = {}, {}
+    for t in range(4):
+        run(t, seq)
+    th = [threading.Thread(target=run, args=(t, par)) for t in range(4)]
+    for x_ in th:
+        x_.start()
+    for x_ in th:
+        x_.join()
+    for t in range(4):
+        assert par[t][3] == "pinned bounce" and np.all(par[t][0] == 0)
+        assert np.array_equal(par[t][0], seq[t][0]) and np.array_equal(par[t][1], seq[t][1]) and np.array_equal(par[t][2], seq[t][2])
+
+
 def test_cpp_batch_solver_over_a_device_list(tmp_path):
     # examples/multi_gpu_demo.cpp: EiCOS::BatchSolver(device_ids) from host C++ (no torch), device list {0, 0} on this box;
     # the program itself compares the sharded run with a single-device run bit for bit
