@@ -320,35 +320,45 @@ def host_e2e(pat, sets, B, local_rank, device_value, steps=5, warmup=1):
     try:
         registered = []
         for variant in ("pageable", "registered", "pinned"):
-            if variant == "registered":  # the caller's own (numpy) arrays pinned in place once: eicos_host_register
-                arrs = {k: np.ascontiguousarray(data[k]).copy() for k in keys}
-                x = np.zeros((B, pat.n))
-                for a in list(arrs.values()) + [x]:
-                    if a.size:
-                        eicos_amd.host_register(a); registered.append(a)
-            elif variant == "pinned":
-                arrs = {}
-                for k in keys:
-                    pa = eicos_amd.PinnedArray(data[k].shape); pa.a[...] = data[k]; pinned.append(pa); arrs[k] = pa.a
-                px = eicos_amd.PinnedArray((B, pat.n)); pinned.append(px); x = px.a
-            else:
-                arrs, x = {k: data[k] for k in keys}, np.zeros((B, pat.n))
+            try:
+                if variant == "registered":  # the caller's own (numpy) arrays pinned in place once: eicos_host_register
+                    arrs = {k: np.ascontiguousarray(data[k]).copy() for k in keys}
+                    x = np.zeros((B, pat.n))
+                    for a in list(arrs.values()) + [x]:
+                        if a.size:
+                            eicos_amd.host_register(a)
+                            registered.append(a)
+                elif variant == "pinned":
+                    arrs = {}
+                    for k in keys:
+                        pa = eicos_amd.PinnedArray(data[k].shape)
+                        pa.a[...] = data[k]
+                        pinned.append(pa)
+                        arrs[k] = pa.a
+                    px = eicos_amd.PinnedArray((B, pat.n))
+                    pinned.append(px)
+                    x = px.a
+                else:
+                    arrs, x = {k: data[k] for k in keys}, np.zeros((B, pat.n))
 
-            def step():
-                solver.update(arrs["Gpr"], arrs["Apr"], arrs["c"], arrs["h"], arrs["b"])
-                solver.solve_async(); solver.sync()
-                solver.solution_into(x)
-            for _ in range(warmup):
-                step()
-            upd, t0 = [], time.perf_counter()
-            for _ in range(steps):
-                step()
-                upd.append(solver.last_update_ms())
-            dt = time.perf_counter() - t0
-            ia = solver.info_arrays()
-            out[variant] = {"value": float(ia["iter"].sum() * steps / dt), "ms_per_step": dt / steps * 1e3, "optimal": int((ia["exitcode"] == 0).sum()),
-                            "update_ms": float(np.mean(upd)), "update_path": solver.last_update_path(), "kernel_ms": solver.last_solve_ms(),
-                            "vs_device_resident": float(ia["iter"].sum() * steps / dt / device_value)}
+                def step():
+                    solver.update(arrs["Gpr"], arrs["Apr"], arrs["c"], arrs["h"], arrs["b"])
+                    solver.solve_async()
+                    solver.sync()
+                    solver.solution_into(x)
+                for _ in range(warmup):
+                    step()
+                upd, t0 = [], time.perf_counter()
+                for _ in range(steps):
+                    step()
+                    upd.append(solver.last_update_ms())
+                dt = time.perf_counter() - t0
+                ia = solver.info_arrays()
+                out[variant] = {"value": float(ia["iter"].sum() * steps / dt), "ms_per_step": dt / steps * 1e3, "optimal": int((ia["exitcode"] == 0).sum()),
+                                "update_ms": float(np.mean(upd)), "update_path": solver.last_update_path(), "kernel_ms": solver.last_solve_ms(),
+                                "vs_device_resident": float(ia["iter"].sum() * steps / dt / device_value)}
+            except RuntimeError as e:  # (pinning refused on this box -- locked-memory limit: the variant is skipped, the others still run)
+                out[variant + "_error"] = str(e)[:200]
     finally:
         solver.close()
         for a in registered:
@@ -571,12 +581,15 @@ def main():
             for k, v in cfg.items():
                 details[k] = v
                 summary[k] = summarise(v)
-            he = host_e2e(pat, sets, B, local_rank, value)
-            details["host_e2e"] = he
-            r3 = lambda v: float(f"{v:.4g}")
-            summary["host_e2e"] = {"batch": B, "in_MB": r3(he["bytes_in_per_step"] / 1e6), "out_MB": r3(he["bytes_out_per_step"] / 1e6),
-                                   **{v: {"value": r3(he[v]["value"]), "x_device_resident": r3(he[v]["vs_device_resident"]), "update_ms": r3(he[v]["update_ms"]),
-                                          "path": he[v]["update_path"]} for v in ("pageable", "registered", "pinned")}}
+            try:  # (an auxiliary leg: a box that cannot pin memory -- locked-memory limit -- must not cost the headline line)
+                he = host_e2e(pat, sets, B, local_rank, value)
+                details["host_e2e"] = he
+                r3 = lambda v: float(f"{v:.4g}")
+                summary["host_e2e"] = {"batch": B, "in_MB": r3(he["bytes_in_per_step"] / 1e6), "out_MB": r3(he["bytes_out_per_step"] / 1e6),
+                                       **{v: {"value": r3(he[v]["value"]), "x_device_resident": r3(he[v]["vs_device_resident"]), "update_ms": r3(he[v]["update_ms"]),
+                                              "path": he[v]["update_path"]} for v in ("pageable", "registered", "pinned") if v in he}}
+            except Exception as e:  # noqa: BLE001
+                summary["host_e2e"] = {"error": str(e)[:200]}
         out = {
             "metric": "ipm_iterations_per_sec", "value": value, "unit": unit,
             "n_gpus": (len(set(multi_ids)) if multi_ids else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
