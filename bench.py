@@ -572,15 +572,17 @@ def main():
             # every other BASELINE.json config, driver-run: configs[4] dense-front (MFMA path), configs[3] LPnetlib (three of the
             # ten patterns: the smallest, a mid-size hybrid one, the deepest), the per-GPU share of configs[2] and north_star's
             # ">= 10x the host at batch 4096 on one GPU" configuration
-            cfg = {}
-            cfg["dense_front_b512"] = run_config(args, "dense_front", "dense-front", 512, local_rank, steps=2, warmup=1, cpu_s=8.0)
-            for nm in ("lp_afiro", "lp_bandm", "lp_25fv47"):
-                cfg[f"{nm}_b256"] = run_config(args, nm, nm, 256, local_rank, perturb=True, steps=5, warmup=1, cpu_s=4.0)
-            cfg["mpc_b512"] = run_config(args, "mpc_b512", "MPC02", 512, local_rank, steps=5, warmup=1, cpu_s=6.0)
-            cfg["mpc_b4096"] = run_config(args, "mpc_b4096", "MPC02", 4096, local_rank, steps=3, warmup=1, cpu_s=6.0)
-            for k, v in cfg.items():
-                details[k] = v
-                summary[k] = summarise(v)
+            legs = [("dense_front_b512", dict(name="dense_front", pattern="dense-front", batch=512, steps=2, warmup=1, cpu_s=8.0))]
+            legs += [(f"{nm}_b256", dict(name=nm, pattern=nm, batch=256, perturb=True, steps=5, warmup=1, cpu_s=4.0)) for nm in ("lp_afiro", "lp_bandm", "lp_25fv47")]
+            legs += [("mpc_b512", dict(name="mpc_b512", pattern="MPC02", batch=512, steps=5, warmup=1, cpu_s=6.0)),
+                     ("mpc_b4096", dict(name="mpc_b4096", pattern="MPC02", batch=4096, steps=3, warmup=1, cpu_s=6.0))]
+            for k, kw in legs:
+                try:  # (an auxiliary leg must not cost the headline line: its failure is reported in its own entry)
+                    v = run_config(args, kw.pop("name"), kw.pop("pattern"), kw.pop("batch"), local_rank, **kw)
+                    details[k] = v
+                    summary[k] = summarise(v)
+                except Exception as e:  # noqa: BLE001
+                    summary[k] = {"error": str(e)[:200]}
             try:  # (an auxiliary leg: a box that cannot pin memory -- locked-memory limit -- must not cost the headline line)
                 he = host_e2e(pat, sets, B, local_rank, value)
                 details["host_e2e"] = he
