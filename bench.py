@@ -185,7 +185,7 @@ class Job:
         fence()
         dt = time.perf_counter() - t0
         ia = self.solver.info_arrays()
-        dev = self.devs[0]["c"].device
+        dev = getattr(self, "ctl_device", None) or self.devs[0]["c"].device
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         cnt = torch.tensor([int(ia["iter"].sum()), int((ia["exitcode"] == 0).sum()), self.B, 1], dtype=torch.float64, device=dev)  # ([3]: ranks that took part)
         km = float(np.mean(kernel_ms))
@@ -221,7 +221,7 @@ class Job:
             "value": r["iters"] * steps / r["dt"], "unit": "iter/s", "ms_per_step": r["dt"] / steps * 1e3,
             "solves_per_sec": r["instances"] * steps / r["dt"], "optimal": r["ok"], "instances": r["instances"],
             "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"], "levels": dims["nlevels"], "cones": dims["ncones"],
-            "mean_iter": float(ia["iter"].mean()),
+            "mean_iter": r["iters"] / max(1, r["instances"]),  # (over ALL ranks / shards, like `value`)
             "mean_ldl_solves_per_iter": float(ia["n_ldlsolve"].sum() / max(1, ia["iter"].sum())),
             "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"],
             "factor_path": ("scalar", "tile", "hybrid")[dims.get("factor_path", 0)], "lds_resident": bool(dims.get("lds_resident", 0)),
@@ -465,6 +465,8 @@ def main():
                     "before the timed region, results are gathered back after it (times reported in config)")
     args = ap.parse_args()
 
+    # (the host driver of this pool supports dmabuf IPC only: RCCL / peer mappings across processes need it; already exported on the GPU boxes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # (first: torch brings its own HIP runtime; counting devices does not initialise a context on this image)
     import eicos_amd
     mode, multi_ids = launch_mode(args.gpus, os.environ, args.multi, torch.cuda.device_count)
@@ -475,12 +477,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # REHEARSAL of the one-process-per-GPU launch on a box with fewer GPUs than ranks (EICOS_BENCH_REHEARSAL=1, never the default): the
+    # ranks share the visible devices (local_rank mod their number) and the control-plane reductions go over gloo (RCCL refuses two ranks
+    # on one device).  It exercises the launcher path end to end -- shard arithmetic, one handle per rank, the fences, the reductions, the
+    # line rank 0 prints -- and labels the line as what it is: `n_gpus` = the DISTINCT devices used, `config.launch` says REHEARSAL.
+    rehearsal = os.environ.get("EICOS_BENCH_REHEARSAL", "0") == "1" and mode == "dist"
+    device_of_rank = local_rank % max(1, torch.cuda.device_count()) if rehearsal else local_rank
+    torch.cuda.set_device(device_of_rank)
     dist = None
+    ctl_device = None  # device of the control-plane tensors (None: the rank's GPU, reduced over RCCL)
     if mode == "dist" or (mode == "single" and "RANK" in os.environ and "MASTER_PORT" in os.environ):  # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ctl_device = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    local_rank = device_of_rank
+    rank_devices = [r % max(1, torch.cuda.device_count()) for r in range(world)] if rehearsal else list(range(world))  # (one node: local rank = rank)
 
     if args.pattern == "dense-front":
         from eicos_amd.generate import dense_front_pattern
@@ -506,7 +521,10 @@ def main():
     default_workload = args.pattern == "MPC02" and not args.perturb and args.resolve == 0
 
     job = Job(args, pat, sets, first, B, local_rank, soc=args.soc, multi_ids=multi_ids)
+    job.ctl_device = ctl_device
     io_ms = {}
+    if args.io == "root" and rehearsal:
+        raise SystemExit("--io root moves the shards over RCCL: not available in a rehearsal (two ranks on one device)")
     if args.io == "root" and dist is not None and world > 1:
         # the batch originates on rank 0's GPU: scatter the shards (outside the timed region: inputs are resident in
         # HBM when timing starts), results gathered back after it; equal shards only
@@ -543,6 +561,7 @@ def main():
         cpu = job.cpu_baseline(job.ia_first) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
         job.solver.close()
         sjob = Job(args, pat, sets, first, B, local_rank, soc=True)
+        sjob.ctl_device = ctl_device
         sres = sjob.run(dist, args.steps, args.warmup)
         if rank == 0:
             soc_rep = sjob.report(sres, args.steps, f"MPC02-SOC batch={B}")
@@ -594,7 +613,7 @@ def main():
                 summary["host_e2e"] = {"error": str(e)[:200]}
         out = {
             "metric": "ipm_iterations_per_sec", "value": value, "unit": unit,
-            "n_gpus": (len(set(multi_ids)) if multi_ids else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": (len(set(multi_ids)) if multi_ids else len(set(rank_devices))), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"{total} instances total in {len(multi_ids)} shard(s) over devices {sorted(set(multi_ids))} from one process ({scaling}), " if multi_ids else
                                     f"{total} instances total = {B}/GPU x {world} GPU ({scaling}), ") + f"{args.pattern}{'-SOC' if args.soc else ''} pattern "
@@ -606,9 +625,10 @@ def main():
                        "threads_per_block": dims["threads_per_block"], "resident_blocks": dims["resident_blocks"], "kernel_build": dims["kernel_build"],
                        "kernel_ms_min_over_ranks": main_rep["kernel_ms_min_over_ranks"], "kernel_ms_max_over_ranks": main_rep["kernel_ms_max_over_ranks"],
                        # how the GPUs were reached, and the witnesses: ranks that reduced into the counters (RCCL world) / the shard device list
-                       "launch": {"single": "one process, one GPU", "dist": "torch.distributed, one process per GPU (RCCL for counters only)",
-                                  "multi": "one process, eicos_multi_* (no collective)"}[mode],
-                       "ranks_seen": res["ranks_seen"], "devices": (multi_ids if multi_ids else list(range(world))),
+                       "launch": (f"REHEARSAL: {world} ranks of torch.distributed share {len(set(rank_devices))} device(s), counters over gloo (EICOS_BENCH_REHEARSAL=1)" if rehearsal else
+                                  {"single": "one process, one GPU", "dist": "torch.distributed, one process per GPU (RCCL for counters only)",
+                                   "multi": "one process, eicos_multi_* (no collective)"}[mode]),
+                       "ranks_seen": res["ranks_seen"], "devices": (multi_ids if multi_ids else rank_devices),
                        "io": (f"one process, eicos_multi_* over devices {multi_ids} (shards {job.shards}), inputs resident per shard" if multi_ids else
                               "root scatter/gather over RCCL" if io_ms else "per-rank generation, no collective"), **io_ms,
                        **({"resolve_eps": args.resolve, "warm_shift": args.warm} if args.resolve > 0 else {}),

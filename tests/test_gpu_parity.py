@@ -1171,6 +1171,38 @@ def test_bench_eight_shards_keep_the_roofline_below_one():
     assert abs(d["value"] - c["mean_iter"] * 4096 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
 
 
+def test_bench_launcher_path_rehearsed_with_two_ranks_on_this_gpu():
+    # the one-process-per-GPU launch (the driver's N > 1 command line) end to end on the one leased GPU: EICOS_BENCH_REHEARSAL=1 lets the two
+    # ranks of torch.distributed.run share device 0 and reduce their counters over gloo (RCCL refuses two ranks on one device); the line must
+    # say what it is -- n_gpus = the distinct devices, launch = REHEARSAL -- and hold the contract: both ranks seen, the fixed total split
+    # into contiguous shards, every instance optimal, value = iterations of ALL ranks over the slowest rank's time
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    env = dict(os.environ, EICOS_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total", "1024", "--no-soc"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0]); c = d["config"]
+    assert d["n_gpus"] == 1 and c["launch"].startswith("REHEARSAL: 2 ranks") and c["ranks_seen"] == 2 and c["devices"] == [0, 0]
+    assert c["total_instances"] == 1024 and c["batch_per_gpu"] == 512 and c["optimal"] == 1024 and d["scaling"] == "strong"
+    assert 0 < d["roofline"]["frac"] <= 1 and "cpu_baseline" not in d  # (the CPU leg belongs to the N = 1 line)
+    assert abs(d["value"] - c["mean_iter"] * 1024 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    # without the rehearsal switch the same command line must fail loudly on this box (LOCAL_RANK 1 has no device), never print a line
+    env.pop("EICOS_BENCH_REHEARSAL")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          "--max-restarts", "0", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--total", "64", "--no-soc"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    if eicos_amd.device_count() < 2:
+        assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
 def test_mpc_soc_batch_1024_all_instances_against_the_oracle():
     # the metric says "SOCP" -- the MPC-SOC variant (332 cones of dimension 3) at the headline's batch, every
     # instance against the oracle: exit code, iterations +-1, pcost 1e-8, x
