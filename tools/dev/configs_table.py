@@ -1,18 +1,11 @@
-"""Dev: markdown table of DESIGN.md section 5.1 from a configs jsonl (tools/dev/configs_r3.sh) + the default bench line."""
+"""Dev: markdown table from a configs jsonl (tools/dev/r5_configs.sh: one bench.py line per pattern); reads `config.summary.headline`."""
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip().startswith("{")]
-head = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]) if len(sys.argv) > 2 else None
-def line(name, o, cfg, roof, cpu):
-    tr = roof.get("traffic")
-    return (f"| {name} | {cfg['batch_per_gpu'] if 'batch_per_gpu' in cfg else cfg['instances']} | {cfg['factor_path']}{', slabs in LDS' if cfg.get('lds_resident') else ''}, T={cfg['threads_per_block']} | {cfg['levels']} | "
-            f"{cfg['mean_iter']:.1f} | {cfg['optimal']} | {o['value']/1e3:.1f} k | {cpu['value']/1e3:.1f} k | {o['value']/cpu['value']:.2f}× | {roof['frac']:.3f} | "
-            f"{'%.1f GB = %.2f×' % (tr/1e9, tr/roof['algorithmic_bytes_per_launch']) if tr else '—'} | {cpu['exitcodes_equal']}/{cpu['iters_equal']} of {cpu['instances_compared']} |")
-print("| config | batch | path | levels | mean iter | OPTIMAL | GPU iter/s | CPU iter/s | ratio | frac | HBM traffic per launch (PMC) | code / iter equal |")
+print("| config | batch | path, threads | levels | mean iter | OPTIMAL | GPU iter/s | 16-core oracle iter/s | ratio | frac | launch ms (p95 / max instance ms) | code / iter equal |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-if head:
-    print(line("MPC02 pattern, generated feasible (config 1, headline)", head, head["config"], head["roofline"], head["cpu_baseline"]))
-    s = head["soc"]; print(line("MPC-SOC (332 cones of dim 3), in the headline line", s, s, s["roofline"], s["cpu_baseline"]))
 for o in rows:
-    w = o["config"]["workload"]
+    c, s = o["config"], o["config"]["summary"]["headline"]
+    w = c["workload"]
     name = w.split(",")[1].strip().split(" pattern")[0] + (" (perturbed)" if "perturbed" in w else "")
-    print(line(name, o, o["config"], o["roofline"], o["cpu_baseline"]))
+    print(f"| {name} | {s['batch']} | {s['path']}, T={c['threads_per_block']} | {c['levels']} | {s['mean_iter']:.1f} | {s['optimal']} | {s['value'] / 1e3:.1f} k | "
+          f"{s['cpu'] / 1e3:.1f} k | {s['x_cpu']:.2f}× | {s['frac']:.3f} | {s['kernel_ms']:.2f} ({s['inst_ms_p95']:.2f} / {s['inst_ms_max']:.2f}) | {s['codes_equal']} / {s['iters_equal']} |")
