@@ -29,6 +29,19 @@
 #include "envknob.hpp"
 
 using namespace eicos;
+// Workgroups per CU for a batch, at most `max_r`.  A workgroup slows down by about half of its stand-alone time per co-resident
+// workgroup (measured, MPC02: 13 / 19.8 / 25.8 ms per instance at 1 / 2 / 3 per CU), and a last, partly filled round still costs
+// more than half a round; the cheapest estimate wins (batch 1024 on 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3).
+static int launch_blocks_per_cu(int batch, int n_cu, int max_r) {
+    double best = 1e300; int best_r = 1;
+    for (int r = 1; r <= max_r; r++) {
+        const double rounds = (double)batch / ((double)n_cu * r);
+        const double full = std::floor(rounds), f = rounds - full;
+        const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
+        if (cost < best - 1e-12) { best = cost; best_r = r; }
+    }
+    return best_r;
+}
 static constexpr int KI_MAX_HOST = 2; // right-hand sides of a dual solve (kernels.hip: KI_MAX)
 
 static thread_local std::string g_err;
@@ -77,6 +90,8 @@ struct eicos_batch {
     bool in_chunked_update = false; // eicos_batch_update records ev_u0/ev_u1 around ALL of its chunks
     int64_t npairs = 0;
     std::vector<int> posB; // CSC entry of L -> slot in the backward value array
+    int ub_len = 1;        // length of that array (plan slots + dummy, + the dense apex image)
+    int bpc = 1, n_cu = 256; // workgroups per CU of the solve launch; CUs of the device
     TilePlan tiles;        // tile mode (Symbolic::tile): the dense-front plan
 };
 
@@ -114,9 +129,28 @@ int eicos_device_count(void) {
     return n;
 }
 
+static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *q, const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
+                             int batch, int device, bool allow_apex, eicos_batch **out);
+// The dense apex (symbolic.hpp) keeps an image of its block in LDS.  Whether that costs the launch a resident workgroup per CU is only
+// known once the real LDS layout and the runtime's occupancy answer exist -- at the end of the set-up.  So: set up with the apex; if the
+// batch is one that would run MORE workgroups per CU than came out, set up once more without it and keep the better launch shape
+// (MPC02: batches >= 1536 run three per CU without the apex, two with it: the third workgroup is worth more).
 int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
                        const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                        int batch, int device, eicos_batch **out) {
+    int rc = batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, true, out);
+    if (rc != EICOS_OK || (*out)->sym.apex0 < 0) return rc;
+    eicos_batch *h = *out;
+    if (launch_blocks_per_cu(batch, h->n_cu, h->bpc + 1) <= h->bpc) return rc; // one more per CU would not be taken anyway
+    eicos_batch *h0 = nullptr;
+    if (batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, h->device, false, &h0) != EICOS_OK) return rc;
+    if (h0->bpc > h->bpc) { eicos_batch_destroy(h); *out = h0; } else eicos_batch_destroy(h0);
+    return EICOS_OK;
+}
+
+static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *q,
+                       const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
+                       int batch, int device, bool allow_apex, eicos_batch **out) {
     if (!out) return fail(EICOS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (n < 0 || m < 0 || p < 0 || ncones < 0 || batch < 1) return fail(EICOS_E_INVALID, "negative dimension or batch < 1");
@@ -200,6 +234,10 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const int t = env_int("EICOS_THREADS", dflt, 128, 512);
         if (t != 128 && t != 256 && t != 512) { delete h; return fail(EICOS_E_INVALID, "EICOS_THREADS must be 128, 256 or 512"); }
         h->threads = t;
+        // ---- dense apex: not with 128-thread workgroups (small patterns; kernels.hip: apex_on), not when the caller found that it costs a
+        // resident workgroup (eicos_batch_create above) ----
+        if (h->sym.apex0 >= 0 && (t < 256 || !allow_apex)) h->sym.apex0 = -1;
+        h->n_cu = n_cu;
     }
     // ---- slab layouts ----
     SlabLayout L;
@@ -337,14 +375,20 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (D.nfs % TRI_DEPTH || D.nbs % TRI_DEPTH || D.nfs_ext % TRI_DEPTH || D.nfs_solo % TRI_DEPTH_SOLO || D.nbs_solo % TRI_DEPTH_SOLO) {
         delete h; return fail(EICOS_E_INVALID, "internal: a section of a sweep plan is not padded to its queue depth");
     }
-    D.w_UF = Wl.add((size_t)planF.slots + 8); D.w_UB = Wl.add((size_t)planB.slots + 8);
-    h->posB = planB.pos;
+    // (value arrays: the plan's slots + the dummy slot, then -- dense apex -- the na x 64 image of the block's own entries, zero wherever no
+    // entry of L lands: the work slabs are zeroed at creation and the factor program only ever writes entry slots)
+    D.w_UF = Wl.add((size_t)planF.ulen + 8); D.w_UB = Wl.add((size_t)planB.ulen + 8);
+    const bool apex = !tile && S.apex0 >= 0;
+    D.apex_na = apex ? S.N - S.apex0 : 0; D.apex_n0 = apex ? S.apex0 : 0; D.apex_f = planF.apex_base; D.apex_b = planB.apex_base;
+    D.apex_split_n = apex ? planF.split_n : 0; D.apex_split_slot = planF.split_slot0; D.apex_split_lane = planF.split_row - D.apex_n0;
+    if (D.apex_split_n > 0 && (tile || scalar_npad(NV) != ((NV + 1 + 15) & ~15) || planF.split_slot0 + planF.split_n > scalar_npad(NV))) { delete h; return fail(EICOS_E_INVALID, "internal: the split row of the apex does not fit the spare slots of the sweep vector"); }
+    h->posB = planB.pos; h->ub_len = planB.ulen;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
     FactorPlan planX;
     if (!tile1) planX = build_factor_plan(S, h->threads, planB.pos, planB.slots, planF.pos, planF.slots);
     else { planX.pa.assign(1, 0); planX.pb.assign(1, 0); planX.pbU.assign(1, 0); planX.pk.assign(1, 0); }
     D.fac_ns = (int)planX.sl.size(); D.fac_slots = planX.slots; D.fac_nt = (int)planX.target.size();
-    if ((long long)planB.slots + 1 >= IMG_BASE || (long long)S.N >= DIAG_POS / 2) { delete h; return fail(EICOS_E_UNSUPPORTED, "pattern too large for the factor program's destination codes"); }
+    if ((long long)planB.ulen + 1 >= IMG_BASE || (long long)S.N >= DIAG_POS / 2) { delete h; return fail(EICOS_E_UNSUPPORTED, "pattern too large for the factor program's destination codes"); }
     {   // level 0 of the factor program: the leaves of the elimination tree have no pairs; the kernel streams over their targets
         // (diagonals first: the per-level task order is stable for equal pair counts) instead of walking their slices
         D.fac_s1 = 0; D.fac_nd0 = 0; D.fac_nt0 = 0;
@@ -581,7 +625,9 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const size_t lds_static = 4096; // struct Sh + the per-instance states of kernels.hip (reductions + scalar state), rounded up
         // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
         // ... and the partial-sum slots of split blocks in the tile sweeps (TILE_PARTS x 16 rows x two right-hand sides)
-        const size_t scratch = tile ? ((size_t)(h->threads / 64) * TILE_SCR + (size_t)TILE_PARTS * 16 * KI_MAX_HOST) * sizeof(double) : 0;
+        // dense apex: the packed image of the block's L (same place: the scalar path has no tile scratch)
+        const size_t apex_img = D.apex_na > 0 ? (size_t)APEX_IMG * sizeof(double) : 0;
+        const size_t scratch = tile ? ((size_t)(h->threads / 64) * TILE_SCR + (size_t)TILE_PARTS * 16 * KI_MAX_HOST) * sizeof(double) : apex_img;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
         const int wgs_by_regs = (h->threads == 256 ? 3 : (h->threads == 512 ? 2 : 4)) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
         auto wgs_per_cu = [&](int slices) {
@@ -618,10 +664,11 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         const int defer_auto = (double)S.npairs <= 8.0 * (double)S.nnzL ? 1 : 0;
         D.fac_defer = (!tile1 && h->nlds >= 1 && env_int("EICOS_FAC_DEFER", defer_auto, 0, 1)) ? 1 : 0;
         D.fac_kpad = S.N;
-        h->dyn_lds = h->nlds >= 1 ? (size_t)nvec * vec + meta : scratch;
+        h->dyn_lds = h->nlds >= 1 ? (size_t)nvec * vec + meta : (tile ? scratch : 0); // (no LDS vector: the apex sweeps read the global images, no LDS image)
         D.lds_tab = h->nlds >= 1 ? nvec * D.Npad : 0;
         D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
         D.tl_part = D.tl_scratch + (h->threads / 64) * TILE_SCR;
+        D.apex_lds = (D.apex_na > 0 && h->nlds >= 1) ? D.tl_scratch : -1; // (no LDS vector: the apex sweeps read the global images)
         // LDS-resident variant (small patterns, kernels_ldsres.hip): when the instance slab and the workspace slab fit LDS
         // beside the vectors and tables, k_solve works on LDS copies of both, so the elementwise stages and the products wait
         // for LDS instead of L2 (+12 % on lp_afiro at batch 256; the level-by-level sweeps are issue-bound and do not change:
@@ -651,15 +698,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         // co-resident workgroup (measured, MPC02: 13 / 19.8 / 25.8 ms per instance at 1 / 2 / 3 per CU), and a last,
         // partly filled round still costs more than half a round; pick the cheapest estimate (e.g. batch 1024 on
         // 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3 per CU, batch >= 1536 takes 3 per CU).
-        double best = 1e300; int best_r = 1;
-        const double groups = (double)batch;
-        for (int r = 1; r <= bpc; r++) {
-            const double rounds = groups / ((double)prop.multiProcessorCount * r);
-            const double full = std::floor(rounds), f = rounds - full;
-            const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
-            if (cost < best - 1e-12) { best = cost; best_r = r; }
-        }
-        bpc = best_r;
+        bpc = launch_blocks_per_cu(batch, prop.multiProcessorCount, bpc);
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
     // 256 threads at <= 2 workgroups per CU: the build with 256 VGPRs per thread (the default one is held to 168 so that three fit)
@@ -688,6 +727,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
         }
         if (xs > 0) { D.e_lds = (int)xs; D.e_off = (int)(base / sizeof(double)); h->dyn_lds = base + xs * sizeof(double); }
     }
+    h->bpc = bpc;
     const int resident = prop.multiProcessorCount * bpc;
     h->grid = std::min(batch, resident);
     h->order_min = prop.multiProcessorCount;
@@ -1257,8 +1297,8 @@ int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     }
     if (Dout) HIP_TRY(hipMemcpy(Dout, h->d_work + h->dp.w_D, (size_t)h->sym.N * sizeof(double), hipMemcpyDeviceToHost));
     if (Uout) {
-        std::vector<double> ub((size_t)h->dp.nUB + 1);
-        HIP_TRY(hipMemcpy(ub.data(), h->d_work + h->dp.w_UB, (size_t)h->dp.nUB * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> ub((size_t)h->ub_len + 1);
+        HIP_TRY(hipMemcpy(ub.data(), h->d_work + h->dp.w_UB, (size_t)h->ub_len * sizeof(double), hipMemcpyDeviceToHost));
         for (int e = 0; e < h->dp.nnzL; e++) Uout[e] = ub[h->posB[e]];
     }
     return EICOS_OK;
@@ -1387,7 +1427,7 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
         double plan_err = 0;
         for (int T : {128, 256, 512}) {
             TriPlan pf = build_tri_plan(S, T, true), pb = build_tri_plan(S, T, false);
-            std::vector<double> UF(pf.slots + 1, 0.0), UB(pb.slots + 1, 0.0), ws(N + 1, 0.0);
+            std::vector<double> UF(pf.ulen, 0.0), UB(pb.ulen, 0.0), ws(scalar_npad(N), 0.0);
             { // numeric factorisation through the sliced-ELL factor plan, lane by lane as the kernel does it
                 FactorPlan px = build_factor_plan(S, T, pb.pos, pb.slots, pf.pos, pf.slots);
                 if (getenv("EICOS_PLAN_STATS")) { // developer aid: shape of the three programs for this workgroup size
@@ -1458,7 +1498,20 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                     }
                 }
             };
-            sweep(pf, UF, true); sweep(pb, UB, false);
+            sweep(pf, UF, true);
+            if (S.apex0 >= 0) { // the dense apex as apex_solve walks it: a column of the block per forward step, a row per backward step
+                const int n0 = S.apex0, na = N - n0;
+                for (int q_ = 0; q_ < pf.split_n; q_++) { ws[pf.split_row] += ws[pf.split_slot0 + q_]; ws[pf.split_slot0 + q_] = 0.; } // the parts of the split row
+                if (na > APEX_MAX || pf.n_ext % TRI_DEPTH) throw std::logic_error("apex: bad shape");
+                for (int k = 0; k < na; k++) for (int i = 0; i < na; i++) ws[n0 + i] -= UF[pf.apex_base + 64 * k + i] * ws[n0 + k];
+                for (int i = na - 1; i >= 0; i--) {
+                    ws[n0 + i] *= invD[n0 + i];
+                    for (int k = 0; k < na; k++) ws[n0 + k] -= UB[pb.apex_base + 64 * i + k] * ws[n0 + i];
+                }
+                for (int k = 0; k < na; k++) for (int i = 0; i <= k; i++) // (nothing may sit on or above the diagonal of either image)
+                    if (UF[pf.apex_base + 64 * k + i] != 0. || UB[pb.apex_base + 64 * i + k] != 0.) throw std::logic_error("apex: entry above the diagonal");
+            }
+            sweep(pb, UB, false);
             std::vector<double> xt(N);
             for (int j = 0; j < N; j++) xt[S.perm[j]] = ws[j];
             if (T == 128) x = xt;

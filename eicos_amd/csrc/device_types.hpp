@@ -89,6 +89,14 @@ constexpr int FAC_DEPTH = EICOS_FAC_DEPTH; // and for the static part of the fac
 // Everything the kernels need to know about the (shared) pattern.  All pointers are device
 // pointers into one int32 pattern buffer; all i_* / w_* members are offsets in doubles into
 // the per-instance slab / the per-resident-workgroup workspace slab.
+// Dense apex: where entry (i, k), k < i < 64, of the block's strictly lower triangle sits in its LDS image: 32 rows of 65 doubles, row i >= 32 in
+// image row 63 - i at columns 0 .. i - 1, row i < 32 in image row i from column 63 down (kernels.hip: apex_solve_lds)
+constexpr int APEX_IMG = 32 * 65;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int apex_img_at(int i, int k) { return i >= 32 ? (63 - i) * 65 + k : i * 65 + 63 - k; }
+
 struct DevPat {
     int n, p, m, l, nc, N, mt, nV, nnzA, nnzG, nnzL, nlev;
     int Npad; // N rounded up to 16 doubles: stride of the LDS-resident KKT-space vectors
@@ -154,7 +162,17 @@ struct DevPat {
     int tile, nb, nt, nblev;       // 1 = tile path, 2 = hybrid (top block of the tree on tiles); blocks, off-diagonal tiles, block levels
     int tl_base;                   // slot of block 0 in the KKT-space vectors (hybrid: the scalar part comes first)
     int w_Kimg;                    // workspace: dense tile image of K the tile factorisation starts from (= w_Kt in pure tile mode)
-    int nfs_ext;                   // hybrid: slices of the forward plan's extra level (rows of the top block, columns below it)
+    int nfs_ext;                   // hybrid / dense apex: slices of the forward plan's extra level (rows of the top block, columns below it)
+    // dense apex (symbolic.hpp): nodes apex_n0 .. apex_n0 + apex_na - 1 (apex_na = 0: none; <= 64), swept by wavefront 0 alone from the
+    // dense images UF + apex_f (column k of the block across the lanes: 64 k + i) and UB + apex_b (row i across the lanes: 64 i + k)
+    int apex_na, apex_n0, apex_f, apex_b;
+    // apex_lds >= 0 (NLDS >= 1 and room in LDS): offset (doubles, in the dynamic LDS) of the FOLDED strictly-lower image of the block's unit-lower L
+    // (apex_img_at below, APEX_IMG doubles) -- copied from the forward image after every factorisation; both sweeps then read LDS (a global
+    // load per step is a memory round trip per APEX_QD steps: measured, the sweeps got SLOWER with the apex on global images)
+    int apex_lds;
+    // one long row of the apex cut into apex_split_n parts by the forward plan's `ext` level (plans.hpp: TriPlan::split_row): the parts' sums sit, negated, in
+    // the sweep-vector slots apex_split_slot .. + apex_split_n - 1 when the apex sweep starts; it adds them to lane apex_split_lane and zeroes them
+    int apex_split_lane, apex_split_slot, apex_split_n;
     int tl_nimg, tl_scratch;       // entries of the K image scatter; offset (doubles) of the per-wave LDS scratch
     gint_p tl_blev, tl_tgt_lev, tl_tgt, tl_tp, tl_pa, tl_pb, tl_pk, tl_fin_lev, tl_fin; // levels, factor targets / pairs, finalise lists
     gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view

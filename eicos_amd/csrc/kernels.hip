@@ -726,6 +726,175 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     if (!SOLO) __syncthreads();
 }
 
+// The dense apex of the elimination tree (symbolic.hpp: Symbolic::apex0; the last levels of the schedule, <= 64 nodes in all) -- both
+// sweeps over it by ONE wavefront, lane = node, the iterate in a register:
+//   forward  (unit-lower L):  for k = 0 .. na-2:  y_i -= L[i,k] y_k  on the lanes i > k   -- column k of the block across the lanes
+//   backward (U = L.*D):      for i = na-1 .. 0:  x_i = acc_i / D_i;  acc_k -= U[i,k] x_i  on the lanes k < i  -- row i across the lanes
+// The entries come from dense na x 64 images behind the sweep plans' value arrays (zero where L has no entry: a step is one coalesced 512-byte
+// load, issued APEX_QD steps ahead -- it does not depend on the iterate -- a broadcast of the pivot lane's value and one multiply-subtract).
+// na dependent steps of ~30 cycles replace (levels of the apex) slice steps of ~1100 (MPC02: 63 nodes = levels 10..20 of 21).  Same operations
+// as a column-oriented substitution (the reference's, Eigen's, order); the level-scheduled sweeps sum a row first and subtract once.
+constexpr int APEX_QD = 8;
+// (128-thread workgroups -- small patterns, tight register budgets -- never carry an apex: api.cpp drops it with that workgroup size)
+template <int T> __device__ __forceinline__ bool apex_on(const DevPat &P) { if constexpr (T >= 256) return P.apex_na > 0; else return false; }
+// the parts of the split row (DevPat::apex_split_*): their sum -- every lane reads the same few slots -- and the slots zeroed for the next sweep
+template <int KI, class WS>
+__device__ __forceinline__ void apex_take_split(const DevPat &P, WS ws, int lane, double (&s)[KI]) {
+#pragma unroll
+    for (int r = 0; r < KI; r++) s[r] = 0.;
+    const int n = uni(P.apex_split_n), slot = uni(P.apex_split_slot);
+    if (n == 0) return;
+    for (int q = 0; q < n; q++) {
+        double t[KI];
+        ldK<KI>(ws, slot + q, t);
+#pragma unroll
+        for (int r = 0; r < KI; r++) s[r] += t[r];
+    }
+    double z[KI];
+#pragma unroll
+    for (int r = 0; r < KI; r++) z[r] = 0.;
+    if (lane < n) stK<KI>(ws, slot + lane, z);
+}
+__device__ __forceinline__ double rdlane_d(double v, int l) { // v of lane l (wavefront-uniform l) to every lane, through SGPRs
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int KI, class WS>
+__device__ __forceinline__ void apex_solve(const DevPat &P, gcdbl_p UF, gcdbl_p UB, gcdbl_p invD, WS ws) {
+    const int lane = threadIdx.x & 63;
+    const int na = uni(P.apex_na), n0 = uni(P.apex_n0);
+    gcdbl_p F = UF + uni(P.apex_f), R = UB + uni(P.apex_b);
+    const int me = n0 + min(lane, na); // (lanes beyond the block: slot N, the always-zero slot of the vector and of 1/D; their image entries are zero)
+    double x[KI], q[APEX_QD], sp[KI];
+    ldK<KI>(ws, me, x);
+    apex_take_split<KI>(P, ws, lane, sp);
+#pragma unroll
+    for (int r = 0; r < KI; r++) x[r] = lane == uni(P.apex_split_lane) ? x[r] + sp[r] : x[r];
+#pragma unroll
+    for (int d = 0; d < APEX_QD; d++) q[d] = ld_u32(F, min(d, na - 1) * 64 + lane);
+    for (int k0 = 0; k0 < na - 1; k0 += APEX_QD) { // (the last column has nothing below it; a trip may run past it: those steps re-read it -- all zeros)
+#pragma unroll
+        for (int d = 0; d < APEX_QD; d++) {
+            const int k = k0 + d;
+            const double lk = q[d];
+            q[d] = ld_u32(F, min(k + APEX_QD, na - 1) * 64 + lane);
+#pragma unroll
+            for (int r = 0; r < KI; r++) x[r] = x[r] - lk * rdlane_d(x[r], min(k, 63));
+        }
+    }
+    const double dinv = ld_u32(invD, me);
+#pragma unroll
+    for (int d = 0; d < APEX_QD; d++) q[d] = ld_u32(R, max(na - 1 - d, 0) * 64 + lane);
+    for (int i0 = na - 1; i0 >= 0; i0 -= APEX_QD) { // (steps below row 0 of the last trip re-read row 0 -- all zeros -- and finalise no lane)
+#pragma unroll
+        for (int d = 0; d < APEX_QD; d++) {
+            const int i = i0 - d;
+            const double ui = q[d];
+            q[d] = ld_u32(R, max(i - APEX_QD, 0) * 64 + lane);
+#pragma unroll
+            for (int r = 0; r < KI; r++) {
+                x[r] = (lane == i) ? x[r] * dinv : x[r]; // lane i: every row above it has been subtracted
+                x[r] = x[r] - ui * rdlane_d(x[r], max(i, 0));
+            }
+        }
+    }
+    if (lane < na) stK<KI>(ws, n0 + lane, x);
+}
+// The same from the LDS image of the block's unit-lower L (DevPat::apex_lds; filled by stage_factor).  The image is the strictly lower triangle FOLDED into
+// 32 rows of 65 doubles (device_types.hpp: apex_img_at): row i >= 32 lies in image row 63 - i at columns 0 .. i-1, row i < 32 in image row i
+// from column 63 DOWN -- a row of L is a run of consecutive addresses (backward: row i across the lanes k < i) and a column of L visits
+// consecutive image rows at stride 65 +- 1 (forward: lane i reads its own row at column k): both sweeps read without bank conflicts beyond
+// the two passes a 64-lane 8-byte read takes anyway.  Backward works on z = D^-1 y with L itself -- x_k = z_k - sum_{i > k} L[i,k] x_i -- so no
+// step carries a scaling.
+// NO MASKS: at forward step k the lanes <= k read some other slot of the image (finite: an entry of L or a zero) and their register is
+// overwritten with garbage -- but a lane's value is dead once it has been the pivot: step k broadcasts lane k BEFORE the update, and the
+// broadcast value (two SGPRs) is written into lane k of a result register with v_writelane.  Backward likewise (lanes >= i are dead at step i).
+// Both loops are FULLY unrolled in blocks of APEX_BLK steps -- the step number is a compile-time constant: pivot lane, written lane and the
+// row offsets of the backward reads are immediates -- and block b + 1 is read while block b's chain of broadcast / multiply / subtract
+// runs.  (Measured on the way: a rolled loop with a four-deep queue 186 cycles per step; masked reads under constant lane masks made the
+// compiler keep 63 exec masks in spilled SGPRs: 2400 instructions.)
+constexpr int APEX_BLK = 16;
+template <int L> __device__ __forceinline__ double wrlane_d(double into, double uniform_v) { // lane L of `into` = uniform_v (wavefront-uniform: SGPRs)
+    unsigned long long o = (unsigned long long)__double_as_longlong(into);
+    const unsigned long long v = (unsigned long long)__double_as_longlong(uniform_v);
+    unsigned lo = (unsigned)o, hi = (unsigned)(o >> 32);
+    // (no v_writelane builtin in this compiler)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((unsigned)v), "n"(L));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((unsigned)(v >> 32)), "n"(L));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int KI, class WS>
+__device__ __forceinline__ void apex_solve_lds(const DevPat &P, gcdbl_p invD, WS ws) {
+    constexpr int NB = 64 / APEX_BLK;
+    const int lane = threadIdx.x & 63;
+    const int na = uni(P.apex_na), n0 = uni(P.apex_n0), img = uni(P.apex_lds);
+    const int me = n0 + min(lane, na);
+    double x[KI], y[KI], sp[KI];
+    ldK<KI>(ws, me, x); // (lanes beyond the block: the zero slot N; the rows >= na of the image hold zeros, so they stay zero)
+    apex_take_split<KI>(P, ws, lane, sp);
+#pragma unroll
+    for (int r = 0; r < KI; r++) x[r] = lane == uni(P.apex_split_lane) ? x[r] + sp[r] : x[r];
+    const double dinv = ld_u32(invD, me);
+#pragma unroll
+    for (int r = 0; r < KI; r++) y[r] = 0.;
+    // ---- forward: lane i reads its own row of L at column k ----
+    const int cbase = img + (lane >= 32 ? (63 - lane) * 65 : lane * 65 + 63), cstep = lane >= 32 ? 1 : -1;
+    double a[2][APEX_BLK];
+    auto load_cols = [&](int k0, double (&o)[APEX_BLK]) {
+#pragma unroll
+        for (int d = 0; d < APEX_BLK; d++) o[d] = g_dyn[cbase + cstep * min(k0 + d, 62)];
+    };
+    load_cols(0, a[0]);
+    int done = 0; // pivots captured in y: [0, done)
+    static_for<0, NB, 1>([&](auto Bc) {
+        constexpr int b = decltype(Bc)::value;
+        if (b * APEX_BLK < na - 1) { // (wavefront-uniform; the last column has nothing below it)
+            if constexpr (b + 1 < NB) load_cols((b + 1) * APEX_BLK, a[(b + 1) & 1]);
+            static_for<0, APEX_BLK, 1>([&](auto Dc) {
+                constexpr int d = decltype(Dc)::value, k = b * APEX_BLK + d;
+#pragma unroll
+                for (int r = 0; r < KI; r++) {
+                    const double xk = rdlane_d(x[r], k);
+                    y[r] = wrlane_d<k>(y[r], xk);
+                    x[r] = x[r] - a[b & 1][d] * xk;
+                }
+            });
+            done = (b + 1) * APEX_BLK;
+        }
+    });
+    // z = D^-1 y: captured pivots, the live values of the lanes the loop did not reach
+#pragma unroll
+    for (int r = 0; r < KI; r++) { x[r] = (lane < done ? y[r] : x[r]) * dinv; y[r] = x[r]; }
+    // ---- backward: row i of L across the lanes k < i ----
+    const int rpos = img + lane, rneg = img + 63 - lane;
+    auto load_rows = [&](int i0, double (&o)[APEX_BLK]) { // rows i0, i0 - 1, ..., i0 - APEX_BLK + 1 (row 0 has no entries: any slot)
+#pragma unroll
+        for (int d = 0; d < APEX_BLK; d++) { const int i = max(i0 - d, 1); o[d] = i >= 32 ? g_dyn[rpos + (63 - i) * 65] : g_dyn[rneg + i * 65]; }
+    };
+    load_rows(63, a[0]);
+    static_for<0, NB, 1>([&](auto Bc) {
+        constexpr int b = decltype(Bc)::value, i0 = 63 - b * APEX_BLK;
+        if constexpr (b + 1 < NB) load_rows(i0 - APEX_BLK, a[(b + 1) & 1]);
+        if (i0 - APEX_BLK + 1 < na) { // (wavefront-uniform; else every row of this block lies beyond the apex: y keeps z there -- zeros)
+            static_for<0, APEX_BLK, 1>([&](auto Dc) {
+                constexpr int d = decltype(Dc)::value, i = i0 - d;
+                if constexpr (i >= 1) {
+#pragma unroll
+                    for (int r = 0; r < KI; r++) {
+                        const double xi = rdlane_d(x[r], i);
+                        y[r] = wrlane_d<i>(y[r], xi);
+                        x[r] = x[r] - a[b & 1][d] * xi;
+                    }
+                }
+            });
+        }
+    });
+#pragma unroll
+    for (int r = 0; r < KI; r++) y[r] = lane == 0 ? x[r] : y[r]; // (lane 0 is never a pivot of the backward loop and never dead)
+    if (lane < na) stK<KI>(ws, n0 + lane, y);
+}
+
 // ---------------- lambda = W z (ref scale :485-507); ends with a barrier ----------------
 // CONES_ONLY: the LP rows were done by the caller inside a fused pass (same product, out[i] = lpw[i] * zz[i])
 template <int T, bool CONES_ONLY = false>
@@ -1213,6 +1382,18 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
         });
         FTICK(11);
     }
+    }
+    if constexpr (NLDS >= 1) { // dense apex: the packed LDS image of the block's L, from the forward image the passes above have just written
+        if (P.apex_na > 0 && P.apex_lds >= 0) {
+            __syncthreads();
+            const int na = P.apex_na;
+            for (int e = tid; e < APEX_IMG; e += T) g_dyn[P.apex_lds + e] = 0.; // (the slots no entry of the triangle maps to are read too: dead lanes)
+            __syncthreads();
+            for (int e = tid; e < 63 * 64; e += T) { // (the whole image: rows beyond the apex are zeros)
+                const int k = e >> 6, i = e & 63;
+                if (i > k) g_dyn[P.apex_lds + apex_img_at(i, k)] = (i < na) ? ld_u32((gcdbl_p)UF, P.apex_f + e) : 0.;
+            }
+        }
     }
     if (tid == 0) { g_S.wi.n_factor++; g_S.tick[TK_FACTOR] += wall_clock64() - tk0_; }
     __syncthreads();
@@ -2067,6 +2248,22 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
                     tile_solve<T, true, KI>(P, Wg, SV);
                     if (wave0) tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
+            } else if (apex_on<T>(P)) { // dense apex: the narrow levels below it on wavefront 0, its rows against everything below (all wavefronts), the apex, back down
+                if (P.nfs_solo) {
+                    if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    __syncthreads();
+                }
+                tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                if (wave0) {
+#ifdef EICOS_SOLO_TICKS
+                    tick(TK_LDL);
+#endif
+                    if (P.apex_lds >= 0) apex_solve_lds<KI>(P, invD, SV); else apex_solve<KI>(P, UF, UB, invD, SV);
+                    tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+#ifdef EICOS_SOLO_TICKS
+                    tick(TK_FWD);
+#endif
+                }
             } else if (wave0) {
 #ifdef EICOS_SOLO_TICKS
                 tick(TK_LDL);
@@ -2088,6 +2285,17 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
                     tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     tile_solve<T, false, KI>(P, Wg, SV);
                     if (wave0) tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                }
+            } else if (apex_on<T>(P)) {
+                if (P.nfs_solo) {
+                    if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    __syncthreads();
+                }
+                tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                if (wave0) {
+                    apex_solve<KI>(P, UF, UB, invD, SV);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (slab vector: the apex's stores before the gathers of the levels below)
+                    tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
                 tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);

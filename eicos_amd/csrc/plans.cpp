@@ -28,10 +28,13 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     const std::vector<int> &ind = forward ? S.Rj : S.Li;
     // hybrid: the sweeps cover the levels below the cut; a row of the top block keeps only its entries in columns < n0
     // (a prefix: the columns of a row ascend), a column below the cut keeps all its rows
-    const bool hyb = S.tile == 2;
-    const int nlev = hyb ? S.lev_cut : S.nlev;
+    // (dense apex, Symbolic::apex0: the same cut on the scalar path -- the block above it is swept by apex_solve instead of the tile sweeps)
+    const bool apex = S.tile == 0 && S.apex0 >= 0;
+    const bool hyb = S.tile == 2 || apex;
+    const int cut_n0 = apex ? S.apex0 : S.n0;
+    const int nlev = hyb ? (apex ? S.apex_lev : S.lev_cut) : S.nlev;
     auto len = [&](int r) {
-        if (hyb && forward && r >= S.n0) return (int)(std::lower_bound(ind.begin() + ptr[r], ind.begin() + ptr[r + 1], S.n0) - (ind.begin() + ptr[r]));
+        if (hyb && forward && r >= cut_n0) return (int)(std::lower_bound(ind.begin() + ptr[r], ind.begin() + ptr[r + 1], cut_n0) - (ind.begin() + ptr[r]));
         return ptr[r + 1] - ptr[r];
     };
     auto pow2ceil = [](int x) { int p = 1; while (p < x) p <<= 1; return p; };
@@ -47,18 +50,52 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
         for (int i = r; i < r + cnt; i++) mx = std::max(mx, len(i));
         K = (mx + g - 1) / g;
     };
+    // the rows of the apex against the columns below (their order is the apex's lane order: no sorting): a slice is a RUN of consecutive
+    // rows that share the lanes-per-row factor of its first rows -- a much longer row (the root of an MPC tree: 935 entries among rows
+    // of 18..26) starts its own slice instead of forcing 64 lanes on every row of the block
+    auto shape_run = [&](int r, int end, int Tw, int &g, int &cnt, int &K) {
+        auto gof = [&](int m) { return std::max(1, std::min(64, pow2ceil((m + ELL_KMAX - 1) / ELL_KMAX))); };
+        int mx = len(r);
+        g = gof(mx); cnt = 1;
+        while (r + cnt < end && r + cnt != pl.split_row && gof(std::max(mx, len(r + cnt))) == g && (cnt + 1) * g <= Tw) { mx = std::max(mx, len(r + cnt)); cnt++; }
+        K = (mx + g - 1) / g;
+    };
     auto slices_of = [&](int v, int Tw) {
         int r = S.lev_ptr[v], n = 0;
         while (r < S.lev_ptr[v + 1]) { int g, cnt, K; shape(r, S.lev_ptr[v + 1], Tw, g, cnt, K); r += cnt; n++; }
         return n;
+    };
+    // dense apex: the one row of the block that would need sub-slices at 64 lanes (> 64 ELL_KMAX entries below the block), cut into parts
+    // that fill the spare slots of the sweep vector behind slot N (see TriPlan::split_row)
+    if (apex && forward) {
+        const int spare = scalar_npad(S.N) - (S.N + 1);
+        int longest = -1;
+        for (int r = cut_n0; r < S.N; r++) if (len(r) > 64 * ELL_KMAX && (longest < 0 || len(r) > len(longest))) longest = r;
+        if (longest >= 0) {
+            const int parts = std::min({spare, T / 64, (len(longest) + 64 * ELL_KMAX - 1) / (64 * ELL_KMAX)});
+            if (parts >= 2) { pl.split_row = longest; pl.split_slot0 = S.N + 1; pl.split_n = parts; }
+        }
+    }
+    auto emit_split = [&](bool first) { // the parts of split_row: ONE slice, 64 lanes per part
+        const int r = pl.split_row, n = len(r), P = pl.split_n, part = (n + P - 1) / P, lanes = 64 * P, K = (part + 63) / 64;
+        push_subslices(pl.sl, SliceMeta{pl.split_slot0, P, 6, K, pl.slots, first ? 1 : 0, 0, 0});
+        pl.idx.resize((size_t)pl.slots + (size_t)K * lanes, S.N);
+        for (int j = 0; j < n; j++) {
+            const int e = ptr[r] + j, p = j / part, jj = j % part, q = jj % 64, kk = jj / 64;
+            const int slot = pl.slots + kk * lanes + p * 64 + q;
+            pl.idx[slot] = ind[e];
+            pl.pos[S.Rpos[e]] = slot;
+        }
+        pl.slots += K * lanes;
     };
     auto emit_level = [&](int v, int Tw) { // v = nlev (hybrid, forward): the rows of the top block
         int r = S.lev_ptr[v];
         const int end = (hyb && v == nlev) ? S.N : S.lev_ptr[v + 1];
         bool first = true;
         while (r < end) {
+            if (apex && v == nlev && r == pl.split_row) { emit_split(first); first = false; r++; continue; }
             int g, cnt, K;
-            shape(r, end, Tw, g, cnt, K);
+            if (apex && v == nlev) shape_run(r, end, Tw, g, cnt, K); else shape(r, end, Tw, g, cnt, K);
             int lg = 0;
             while ((1 << lg) < g) lg++;
             const int lanes = cnt * g;
@@ -89,10 +126,14 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     if (allow_solo) while (vs > v_first && slices_of(vs - 1, 64) <= 2) vs--;
     if (forward) {
         for (int v = v_first; v < vs; v++) emit_level(v, T);
+        // dense apex with no narrow levels below it: its rows against the columns below are simply the last level of the workgroup-wide
+        // part (one tri_sweep call: the loads of these slices are prefetched behind the levels before instead of starting cold)
+        const bool ext_merged = apex && std::max(vs, v_first) >= nlev;
+        if (ext_merged) emit_level(nlev, T);
         pad(); pl.n_wide = (int)pl.sl.size();
         for (int v = std::max(vs, v_first); v < nlev; v++) emit_level(v, 64);
         pad_solo(); pl.n_solo = (int)pl.sl.size() - pl.n_wide;
-        if (hyb) { emit_level(nlev, T); pad(); pl.n_ext = (int)pl.sl.size() - pl.n_wide - pl.n_solo; }
+        if (hyb && !ext_merged) { emit_level(nlev, T); pad(); pl.n_ext = (int)pl.sl.size() - pl.n_wide - pl.n_solo; }
     } else {
         for (int v = nlev - 1; v >= std::max(vs, v_first); v--) emit_level(v, 64);
         pad_solo(); pl.n_solo = (int)pl.sl.size();
@@ -101,6 +142,17 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     }
     for (SliceMeta &m : pl.sl) if (m.cnt == 0) m.off = pl.slots; // padding slices read the dummy slot
     pl.idx.push_back(S.N); // slot `slots`: the dummy (index N, value 0) read by inactive lanes
+    pl.ulen = pl.slots + 1;
+    if (apex) { // the entries inside the apex: dense image behind the dummy slot
+        const int na = S.N - S.apex0;
+        pl.apex_base = ((pl.slots + 1 + 63) / 64) * 64;
+        pl.ulen = pl.apex_base + 64 * na;
+        for (int j = S.apex0; j < S.N; j++)
+            for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
+                const int i = S.Li[e] - S.apex0, k = j - S.apex0; // (rows of a column lie above it in the order: i > k, both inside the apex)
+                pl.pos[e] = pl.apex_base + (forward ? 64 * k + i : 64 * i + k);
+            }
+    }
     return pl;
 }
 

@@ -19,7 +19,21 @@ struct TriPlan {
     std::vector<int> idx;      // per slot: index of the gathered solve-vector entry (padding -> N)
     std::vector<int> pos;      // per CSC entry of L: its slot
     int slots = 0;
+    // dense apex (Symbolic::apex0 >= 0): the sweeps stop below the apex like the hybrid's (forward: its rows against the columns below as the
+    // `ext` level); the entries of L INSIDE the apex have their slots in a dense na x 64 image behind the dummy slot, from apex_base on
+    // (a multiple of 64): forward (k, i) -> apex_base + 64 (k - apex0) + (i - apex0) -- column k across the lanes i -- backward
+    // (i, k) -> apex_base + 64 (i - apex0) + (k - apex0) -- row i across the lanes k.  Image positions no entry names stay zero.
+    int apex_base = 0;
+    int ulen = 1;              // length of the plan's value array: slots + 1 (the dummy), or apex_base + 64 * na
+    // dense apex, forward plan: ONE row of the apex that is much longer than the others (the root of an MPC tree: 935 entries in the columns
+    // below the block against 18..26) is cut into split_n parts that sit side by side in ONE slice of the `ext` level -- part p is the
+    // pseudo-row split_slot0 + p of the sweep vector (spare slots behind the zero slot N: zero when the sweep starts, so a part leaves
+    // -(its partial sum) there) -- instead of split_n sub-slices of a 64-lane slice that run one after the other; apex_solve adds the
+    // parts to the row and zeroes them again.  split_row < 0: none.
+    int split_row = -1, split_slot0 = 0, split_n = 0;
 };
+// length of the KKT-space vectors of the scalar path on the device (>= N + 1: slot N is the always-zero target of ELL padding)
+inline int scalar_npad(int N) { return (N + 1 + 15) & ~15; }
 
 // T = workgroup size the plan is laid out for.
 TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo = true);

@@ -443,16 +443,24 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
     // ---- hybrid: does the scalar schedule end in a chain worth handing to the tile path? ----
     if (!tile && program && hybrid && N > 0) {
         int cut = S.nlev;
-        constexpr int wmax = 4;
+        // (EICOS_HYBRID_WMAX, experiment knob: a wider tail, taken whatever its length -- the top of a tree that is not a chain)
+        const int wmax = env_knob("EICOS_HYBRID_WMAX", 4, 1, 64);
+        const bool forced = wmax != 4;
         while (cut > 0 && S.lev_ptr[cut] - S.lev_ptr[cut - 1] <= wmax) cut--; // maximal tail of levels with <= 4 nodes
         const int nD = N - S.lev_ptr[cut], nbD = (nD + 15) / 16;
         // worth it: the tail is long (each of its levels costs the sweeps a dependent step, one block costs about two)
-        if (nD >= 24 && nD <= 1024 && S.nlev - cut >= 12 && 3 * nbD <= S.nlev - cut) {
+        if (nD >= 24 && nD <= 1024 && (forced || (S.nlev - cut >= 12 && 3 * nbD <= S.nlev - cut))) {
             S.tile = 2; S.lev_cut = cut; S.n0 = S.lev_ptr[cut];
             S.nblk = nbD; S.nblev = nbD;
             S.blk_ptr.clear(); S.blev_ptr.clear();
             for (int b = 0; b <= nbD; b++) { S.blk_ptr.push_back(std::min(N, S.n0 + 16 * b)); S.blev_ptr.push_back(b); }
         }
+    }
+    // ---- dense apex: the maximal tail of levels that holds at most APEX_MAX nodes (level 0 always stays on the level schedule) ----
+    if (!tile && program && S.tile == 0 && N >= APEX_MIN_N && env_knob("EICOS_APEX", 1, 0, 1)) {
+        int cut = S.nlev;
+        while (cut > 1 && N - S.lev_ptr[cut - 1] <= APEX_MAX) cut--;
+        if (S.nlev - cut >= APEX_MIN_LEVELS) { S.apex0 = S.lev_ptr[cut]; S.apex_lev = cut; }
     }
     if (tile || !program) { // tile mode has its own (tile-level) program, tiles.cpp; structure-only calls need none
         int64_t np = 0;

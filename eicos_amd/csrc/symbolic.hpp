@@ -66,6 +66,14 @@ struct Symbolic {
     int lev_cut = 0, n0 = 0;
     int nblk = 0, nblev = 0;
     std::vector<int> blk_ptr;           // nblk+1: node range of each block
+    // ---- dense apex (scalar path, tile == 0).  The last levels of the schedule -- the top of the elimination tree: levels apex_lev..nlev-1,
+    // nodes apex0..N-1, at most APEX_MAX of them -- are narrow (1..16 rows) and each costs both sweeps a dependent slice step on one
+    // wavefront.  They are swept instead as ONE dense triangular system by one wavefront, lane = node, the iterate in a register, a column
+    // (forward) / row (backward) of the block per step: na dependent multiply-subtract steps instead of (nlev - apex_lev) slice steps.
+    // The factor program is unchanged; the entries of L inside the block get slots in a dense na x 64 image behind each sweep plan's
+    // value array (plans.hpp: TriPlan::apex_base), everything else of the rows of the block (their entries in columns < apex0) becomes one
+    // workgroup-wide level of the forward plan (as in the hybrid).  apex0 < 0: none.
+    int apex0 = -1, apex_lev = 0;
     std::vector<int> blev_ptr;          // nblev+1: block range of each block level
 };
 
@@ -75,5 +83,8 @@ struct Symbolic {
 // tile: 0 = scalar (sliced-ELL) path, 1 = tile path, 2 = scalar with the top of the tree on tiles (hybrid) when it pays,
 // < 0 = choose: tiles when L is dense (nnz(L) >= 16 dim_K), otherwise hybrid when the scalar schedule ends in a long chain
 Symbolic analyze(const ProblemPattern &P, int order_mode = -1, int tile = -1);
+constexpr int APEX_MAX = 64;        // nodes of the dense apex: one per lane of a wavefront
+constexpr int APEX_MIN_LEVELS = 5;  // worth it from this many levels on (it costs about three slice steps per solve itself)
+constexpr int APEX_MIN_N = 512;     // small patterns keep the level schedule (their slabs live in LDS: no room for dense images)
 
 } // namespace eicos
