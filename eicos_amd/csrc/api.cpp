@@ -1503,13 +1503,13 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                 const int n0 = S.apex0, na = N - n0;
                 for (int q_ = 0; q_ < pf.split_n; q_++) { ws[pf.split_row] += ws[pf.split_slot0 + q_]; ws[pf.split_slot0 + q_] = 0.; } // the parts of the split row
                 if (na > APEX_MAX || pf.n_ext % TRI_DEPTH) throw std::logic_error("apex: bad shape");
-                for (int k = 0; k < na; k++) for (int i = 0; i < na; i++) ws[n0 + i] -= UF[pf.apex_base + 64 * k + i] * ws[n0 + k];
+                for (int k = 0; k < na; k++) for (int i = k + 1; i < na; i++) ws[n0 + i] -= UF[pf.apex_base + apex_img_at(i, k)] * ws[n0 + k];
                 for (int i = na - 1; i >= 0; i--) {
                     ws[n0 + i] *= invD[n0 + i];
                     for (int k = 0; k < na; k++) ws[n0 + k] -= UB[pb.apex_base + 64 * i + k] * ws[n0 + i];
                 }
-                for (int k = 0; k < na; k++) for (int i = 0; i <= k; i++) // (nothing may sit on or above the diagonal of either image)
-                    if (UF[pf.apex_base + 64 * k + i] != 0. || UB[pb.apex_base + 64 * i + k] != 0.) throw std::logic_error("apex: entry above the diagonal");
+                for (int k = 0; k < na; k++) for (int i = 0; i <= k; i++) // (nothing may sit on or above the diagonal of the row-major image)
+                    if (UB[pb.apex_base + 64 * i + k] != 0.) throw std::logic_error("apex: entry above the diagonal");
             }
             sweep(pb, UB, false);
             std::vector<double> xt(N);

@@ -771,14 +771,15 @@ __device__ __forceinline__ void apex_solve(const DevPat &P, gcdbl_p UF, gcdbl_p 
     apex_take_split<KI>(P, ws, lane, sp);
 #pragma unroll
     for (int r = 0; r < KI; r++) x[r] = lane == uni(P.apex_split_lane) ? x[r] + sp[r] : x[r];
+    auto fcol = [&](int k) { return lane > k && lane < na ? ld_u32(F, apex_img_at(lane, k)) : 0.; }; // (the forward image is the folded one: a gather here)
 #pragma unroll
-    for (int d = 0; d < APEX_QD; d++) q[d] = ld_u32(F, min(d, na - 1) * 64 + lane);
+    for (int d = 0; d < APEX_QD; d++) q[d] = fcol(min(d, na - 1));
     for (int k0 = 0; k0 < na - 1; k0 += APEX_QD) { // (the last column has nothing below it; a trip may run past it: those steps re-read it -- all zeros)
 #pragma unroll
         for (int d = 0; d < APEX_QD; d++) {
             const int k = k0 + d;
             const double lk = q[d];
-            q[d] = ld_u32(F, min(k + APEX_QD, na - 1) * 64 + lane);
+            q[d] = fcol(min(k + APEX_QD, na - 1));
 #pragma unroll
             for (int r = 0; r < KI; r++) x[r] = x[r] - lk * rdlane_d(x[r], min(k, 63));
         }
@@ -1383,16 +1384,10 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
         FTICK(11);
     }
     }
-    if constexpr (NLDS >= 1) { // dense apex: the packed LDS image of the block's L, from the forward image the passes above have just written
-        if (P.apex_na > 0 && P.apex_lds >= 0) {
+    if constexpr (NLDS >= 1) { // dense apex: the LDS image of the block's L -- a straight copy of the forward image the passes above have just written
+        if (P.apex_na > 0 && P.apex_lds >= 0) { // (measured: sharing the region with the head of E -- dead during the sweeps -- and copying the image in at every solve costs the sweeps what it gives the residuals)
             __syncthreads();
-            const int na = P.apex_na;
-            for (int e = tid; e < APEX_IMG; e += T) g_dyn[P.apex_lds + e] = 0.; // (the slots no entry of the triangle maps to are read too: dead lanes)
-            __syncthreads();
-            for (int e = tid; e < 63 * 64; e += T) { // (the whole image: rows beyond the apex are zeros)
-                const int k = e >> 6, i = e & 63;
-                if (i > k) g_dyn[P.apex_lds + apex_img_at(i, k)] = (i < na) ? ld_u32((gcdbl_p)UF, P.apex_f + e) : 0.;
-            }
+            for (int e = tid; e < APEX_IMG; e += T) g_dyn[P.apex_lds + e] = ld_u32((gcdbl_p)UF, P.apex_f + e);
         }
     }
     if (tid == 0) { g_S.wi.n_factor++; g_S.tick[TK_FACTOR] += wall_clock64() - tk0_; }
