@@ -199,24 +199,8 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
 
     const Symbolic &S = h->sym;
     const ProblemPattern &P = h->pat;
-    h->batch = batch; h->device = device; h->npairs = S.npairs;
-    if (S.npairs >= (int64_t)1 << 31) { delete h; return fail(EICOS_E_UNSUPPORTED, "factor program exceeds 2^31 pairs"); }
+    h->batch = batch; h->device = device;
     DevPat &D = h->dp;
-    if (S.tile) { // the tile image, the tile arrays of L and their workspace offsets are indexed with 32-bit ints
-        const long long img = ((long long)h->tiles.nb + h->tiles.nt) * 256;
-        if (img >= IMG_BASE || (long long)S.N + img >= DIAG_POS / 2 || 3 * img * (long long)sizeof(double) > (8LL << 30)) {
-            delete h; return fail(EICOS_E_UNSUPPORTED, "dense-front pattern too large: the tile image of L exceeds the per-workgroup workspace budget");
-        }
-    }
-    const bool tile = S.tile != 0;  // some part of L lives in 16 x 16 tiles: all of it (S.tile == 1) or the top block (hybrid, == 2)
-    const bool tile1 = S.tile == 1; // pure tile mode: no scalar programs at all
-    const TilePlan &TP = h->tiles;
-    // NV = length of the KKT-space vectors on the device: dim_K in elimination order, or (tile mode) the blocks padded to 16
-    const int NV = tile ? TP.N16 : S.N;
-    auto posK = [&](int old) { return tile ? TP.slot[S.iperm[old]] : S.iperm[old]; }; // KKT index -> device slot
-    D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = NV; D.mt = S.mt; D.nV = S.nV;
-    D.nnzA = S.nnzA; D.nnzG = S.nnzG; D.nnzL = S.nnzL; D.nlev = S.nlev;
-
     auto env_int = [](const char *k, int dflt, int lo, int hi) { return env_knob(k, dflt, lo, hi); };
     {
         // workgroup size by problem size (measured, batch 256: dim_K 129 -> 128, 1249 -> 256, >= 3815 -> 512 threads);
@@ -237,8 +221,35 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
         // ---- dense apex: not with 128-thread workgroups (small patterns; kernels.hip: apex_on), not when the caller found that it costs a
         // resident workgroup (eicos_batch_create above) ----
         if (h->sym.apex0 >= 0 && (t < 256 || !allow_apex)) h->sym.apex0 = -1;
+        // small patterns whose narrow tree top would go to the tile path (hybrid): the level schedule + dense apex does better there -- a
+        // handful of 16 x 16 blocks costs two workgroup-wide block levels each, the apex swallows the whole tail in 2 x 64 register steps
+        // (lp_adlittle 1.13 -> 1.33 M, lp_blend 0.92 -> 1.08 M iter/s at batch 256; larger tops -- lp_bandm, lp_agg, lp_25fv47 -- stay hybrid:
+        // their top blocks are dense and the MFMA factorisation of the block is what pays there)
+        if (h->sym.tile == 2 && S.N < APEX_OVER_HYBRID_BELOW && t >= 256 && allow_apex && env_knob("EICOS_TILES", -1, 0, 2) < 0) {
+            try {
+                Symbolic alt = analyze(P, env_knob("EICOS_ORDER", -1, 0, 16), 0);
+                if (alt.apex0 >= 0) { h->sym = std::move(alt); h->tiles = TilePlan(); }
+            } catch (const std::exception &) { /* keep the hybrid analysis */ }
+        }
         h->n_cu = n_cu;
     }
+    h->npairs = S.npairs;
+    if (S.npairs >= (int64_t)1 << 31) { delete h; return fail(EICOS_E_UNSUPPORTED, "factor program exceeds 2^31 pairs"); }
+    if (S.tile) { // the tile image, the tile arrays of L and their workspace offsets are indexed with 32-bit ints
+        const long long img = ((long long)h->tiles.nb + h->tiles.nt) * 256;
+        if (img >= IMG_BASE || (long long)S.N + img >= DIAG_POS / 2 || 3 * img * (long long)sizeof(double) > (8LL << 30)) {
+            delete h; return fail(EICOS_E_UNSUPPORTED, "dense-front pattern too large: the tile image of L exceeds the per-workgroup workspace budget");
+        }
+    }
+    const bool tile = S.tile != 0;  // some part of L lives in 16 x 16 tiles: all of it (S.tile == 1) or the top block (hybrid, == 2)
+    const bool tile1 = S.tile == 1; // pure tile mode: no scalar programs at all
+    const TilePlan &TP = h->tiles;
+    // NV = length of the KKT-space vectors on the device: dim_K in elimination order, or (tile mode) the blocks padded to 16
+    const int NV = tile ? TP.N16 : S.N;
+    auto posK = [&](int old) { return tile ? TP.slot[S.iperm[old]] : S.iperm[old]; }; // KKT index -> device slot
+    D.n = S.n; D.p = S.p; D.m = S.m; D.l = S.l; D.nc = S.nc; D.N = NV; D.mt = S.mt; D.nV = S.nV;
+    D.nnzA = S.nnzA; D.nnzG = S.nnzG; D.nnzL = S.nnzL; D.nlev = S.nlev;
+
     // ---- slab layouts ----
     SlabLayout L;
     D.i_Av = L.add(S.nnzA); D.i_Gv = L.add(S.nnzG);

@@ -457,7 +457,7 @@ static Symbolic analyze_mode(const ProblemPattern &P, int order_mode, bool tile,
         }
     }
     // ---- dense apex: the maximal tail of levels that holds at most APEX_MAX nodes (level 0 always stays on the level schedule) ----
-    if (!tile && program && S.tile == 0 && N >= APEX_MIN_N && env_knob("EICOS_APEX", 1, 0, 1)) {
+    if (!tile && program && S.tile == 0 && N >= env_knob("EICOS_APEX_MIN_N", APEX_MIN_N, 64, 1 << 20) && env_knob("EICOS_APEX", 1, 0, 1)) {
         int cut = S.nlev;
         while (cut > 1 && N - S.lev_ptr[cut - 1] <= APEX_MAX) cut--;
         if (S.nlev - cut >= APEX_MIN_LEVELS) { S.apex0 = S.lev_ptr[cut]; S.apex_lev = cut; }
