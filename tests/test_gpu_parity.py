@@ -215,6 +215,34 @@ def test_deferred_l_factorisation_is_bit_identical_to_the_stored_l_one(name, mon
         assert np.array_equal(a_, b_)
 
 
+@pytest.mark.parametrize("env", [{}, {"EICOS_NLDS": "0"}, {"EICOS_NLDS": "2"}, {"EICOS_THREADS": "512"}, {"EICOS_DUAL": "0", "EICOS_NLDS": "1"},
+                                 {"EICOS_THREADS": "256", "EICOS_W2": "0"}, {"EICOS_IDX16": "0"}])
+def test_dense_apex_agrees_with_the_level_schedule(env, monkeypatch):
+    # the last levels of the elimination tree (MPC02: levels 10..20, 63 nodes) swept as a dense triangular system by one wavefront
+    # (the apex, reference ldlt.solve src/eicos.cpp:1477,1599) against the same handle with the apex off: a column-oriented
+    # substitution rounds differently from the row sums of the level schedule, so not the bits -- but the same exit codes and iteration
+    # counts on every instance, refinement counts within one or two solves, and x to 1e-9; in every launch shape that carries an apex: the LDS image (one and two vectors,
+    # dual solves at this batch), the fallback from the images in the workspace slab (no LDS vector), 512 threads, 32-bit indices
+    pat, sets = load_fixture("MPC02")
+    B = 48
+    d = feasible_batch(pat, sets[0], 0, B)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("EICOS_APEX", flag)
+        g = eicos_amd.BatchSolver(pat, B)
+        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"]); codes = g.solve().copy(); ia = g.info_arrays()
+        out.append((codes, ia["iter"].copy(), ia["n_ldlsolve"].copy(), g.solution().copy()))
+        g.close()
+    assert np.all(out[0][0] == 0) and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # (refinement steps stop on an error norm: the different rounding moves a few instances by one LDL solve out of ~ 86)
+    assert np.max(np.abs(out[0][2] - out[1][2])) <= 2 and abs(int(out[0][2].sum()) - int(out[1][2].sum())) <= 0.01 * out[0][2].sum()
+    xa, xb = out[0][3], out[1][3]
+    assert not np.array_equal(xa, xb)  # (the apex was really on: different rounding)
+    assert np.max(np.abs(xa - xb) / np.maximum(1.0, np.max(np.abs(xa), axis=1, keepdims=True))) < 1e-9
+
+
 def test_kernel_build_reported_for_the_handle(monkeypatch):
     # which compilation of k_solve a handle launches is part of its description: 256-thread workgroups at <= 2 per CU take the
     # 256-VGPR build ("w2"), small patterns the LDS-resident one, everything else the default one; EICOS_W2=0 forbids the first
