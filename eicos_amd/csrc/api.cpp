@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <cmath>
@@ -869,6 +870,25 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
 // x16 link moves ~50 GB/s: a single-threaded bounce copy would be the slowest stage of a host-pointer updateData).  Shared by every
 // handle of the process, started on first use, joined at exit.
 namespace {
+// memcpy with non-temporal stores: the destination of a bounce copy is read next by the GPU over PCIe (or is the caller's result array), never
+// by this core -- regular stores would first read every destination line into the cache (read-for-ownership: a third more memory traffic)
+// and evict the caller's working set.  glibc switches to such stores only above a few MB per call; the pool's pieces are ~1.5 MB.
+static void stream_copy(void *dst, const void *src, size_t bytes) {
+    static const bool nt = env_knob("EICOS_COPY_NT", 1, 0, 1) != 0;
+    char *d = (char *)dst; const char *s = (const char *)src;
+    if (!nt || bytes < 4096) { std::memcpy(d, s, bytes); return; }
+    const size_t head = std::min(bytes, (size_t)((16 - ((uintptr_t)d & 15)) & 15));
+    std::memcpy(d, s, head); d += head; s += head; bytes -= head;
+    const size_t blocks = bytes / 64;
+    for (size_t i = 0; i < blocks; i++, d += 64, s += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)s), b = _mm_loadu_si128((const __m128i *)(s + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i *)(s + 32)), e = _mm_loadu_si128((const __m128i *)(s + 48));
+        _mm_stream_si128((__m128i *)d, a); _mm_stream_si128((__m128i *)(d + 16), b);
+        _mm_stream_si128((__m128i *)(d + 32), c); _mm_stream_si128((__m128i *)(d + 48), e);
+    }
+    _mm_sfence();
+    std::memcpy(d, s, bytes - blocks * 64);
+}
 class CopyPool {
   public:
     static CopyPool &get() { static CopyPool p; return p; }
@@ -876,7 +896,7 @@ class CopyPool {
     void copy(void *dst, const void *src, size_t bytes) {
         const size_t piece = 1u << 20;
         const int parts = (int)std::min<size_t>((size_t)nthreads_ + 1, (bytes + piece - 1) / piece);
-        if (parts <= 1) { std::memcpy(dst, src, bytes); return; }
+        if (parts <= 1) { stream_copy(dst, src, bytes); return; }
         const size_t per = ((bytes + parts - 1) / parts + 63) & ~(size_t)63;
         // completion state on the caller's stack: the count is changed and the caller notified INSIDE the lock, so a helper's last access to
         // these objects is its unlock, which the caller's wait cannot overtake
@@ -885,12 +905,12 @@ class CopyPool {
         for (int k = 1; k < parts; k++) {
             const size_t a = std::min(bytes, (size_t)k * per), b = std::min(bytes, a + per);
             push([=, &left, &done_mu, &done_cv] {
-                if (b > a) std::memcpy((char *)dst + a, (const char *)src + a, b - a);
+                if (b > a) stream_copy((char *)dst + a, (const char *)src + a, b - a);
                 std::lock_guard<std::mutex> lk(done_mu);
                 if (--left == 0) done_cv.notify_one();
             });
         }
-        std::memcpy(dst, src, std::min(bytes, per));
+        stream_copy(dst, src, std::min(bytes, per));
         std::unique_lock<std::mutex> lk(done_mu);
         done_cv.wait(lk, [&] { return left == 0; });
     }

@@ -9,6 +9,9 @@ bits, not one update with the final values.  After every sequence all three solv
 bit-identical, and the result copies into pageable and pinned memory must agree.
 """
 import os, sys
+# (the single handle of 600 runs three workgroups per CU -- no dense apex -- its shards of 300 two per CU WITH one: different rounding, 1e-13 on x.
+#  This tool compares bits across the two, so the apex is switched off for both; its own test is test_dense_apex_agrees_with_the_level_schedule)
+os.environ["EICOS_EXPERIMENT"] = "1"; os.environ["EICOS_APEX"] = "0"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
