@@ -132,6 +132,7 @@ int eicos_device_count(void) {
 
 static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *q, const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                              int batch, int device, bool allow_apex, eicos_batch **out);
+constexpr int EICOS_RETRY_NO_APEX = -99; // (internal: never leaves eicos_batch_create)
 // The dense apex (symbolic.hpp) keeps an image of its block in LDS.  Whether that costs the launch a resident workgroup per CU is only
 // known once the real LDS layout and the runtime's occupancy answer exist -- at the end of the set-up.  So: set up with the apex; if the
 // batch is one that would run MORE workgroups per CU than came out, set up once more without it and keep the better launch shape
@@ -140,6 +141,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
                        const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                        int batch, int device, eicos_batch **out) {
     int rc = batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, true, out);
+    if (rc == EICOS_RETRY_NO_APEX) return batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, false, out);
     if (rc != EICOS_OK || (*out)->sym.apex0 < 0) return rc;
     eicos_batch *h = *out;
     if (launch_blocks_per_cu(batch, h->n_cu, h->bpc + 1) <= h->bpc) return rc; // one more per CU would not be taken anyway
@@ -221,7 +223,9 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
         h->threads = t;
         // ---- dense apex: not with 128-thread workgroups (small patterns; kernels.hip: apex_on), not when the caller found that it costs a
         // resident workgroup (eicos_batch_create above) ----
-        if (h->sym.apex0 >= 0 && (t < 256 || !allow_apex)) h->sym.apex0 = -1;
+        // (128 threads: only the LDS-resident build carries an apex -- its images then live in the LDS copy of the workspace slab; whether that
+        // build is taken is known after the slab layout: if not, the set-up is repeated without the apex, EICOS_RETRY_NO_APEX below)
+        if (h->sym.apex0 >= 0 && ((t < 256 && !(t == 128 && env_knob("EICOS_LDSRES", 1, 0, 1) && batch <= n_cu)) || !allow_apex)) h->sym.apex0 = -1;
         // small patterns whose narrow tree top would go to the tile path (hybrid): the level schedule + dense apex does better there -- a
         // handful of 16 x 16 blocks costs two workgroup-wide block levels each, the apex swallows the whole tail in 2 x 64 register steps
         // (lp_adlittle 1.13 -> 1.33 M, lp_blend 0.92 -> 1.08 M iter/s at batch 256; larger tops -- lp_bandm, lp_agg, lp_25fv47 -- stay hybrid:
@@ -638,7 +642,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
         // tile mode: one 16 x 17 fp64 scratch tile per wavefront (dense LDL' of the diagonal tiles), behind the tables
         // ... and the partial-sum slots of split blocks in the tile sweeps (TILE_PARTS x 16 rows x two right-hand sides)
         // dense apex: the packed image of the block's L (same place: the scalar path has no tile scratch)
-        const size_t apex_img = D.apex_na > 0 ? (size_t)APEX_IMG * sizeof(double) : 0;
+        const size_t apex_img = (D.apex_na > 0 && h->threads >= 256) ? (size_t)APEX_IMG * sizeof(double) : 0; // (128 threads: the image IS the slab's, in LDS)
         const size_t scratch = tile ? ((size_t)(h->threads / 64) * TILE_SCR + (size_t)TILE_PARTS * 16 * KI_MAX_HOST) * sizeof(double) : apex_img;
         // workgroups per CU that 160 KB of LDS allow with one vector + tables of `slices` entries
         const int wgs_by_regs = (h->threads == 256 ? 3 : (h->threads == 512 ? 2 : 4)) * 4 / (h->threads / 64); // waves_per_eu<T>() of kernels.hip
@@ -681,6 +685,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
         D.tl_scratch = h->nlds >= 1 ? nvec * D.Npad + D.lm_total * 2 : 0; // in doubles from the start of the dynamic LDS
         D.tl_part = D.tl_scratch + (h->threads / 64) * TILE_SCR;
         D.apex_lds = (D.apex_na > 0 && h->nlds >= 1) ? D.tl_scratch : -1; // (no LDS vector: the apex sweeps read the global images)
+        D.apex_inplace = 0;
         // LDS-resident variant (small patterns, kernels_ldsres.hip): when the instance slab and the workspace slab fit LDS
         // beside the vectors and tables, k_solve works on LDS copies of both, so the elementwise stages and the products wait
         // for LDS instead of L2 (+12 % on lp_afiro at batch 256; the level-by-level sweeps are issue-bound and do not change:
@@ -695,6 +700,10 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
                 h->ldsres = 1; D.lr_inst = (int)(base / sizeof(double)); D.lr_work = D.lr_inst + (int)islab;
                 h->dyn_lds = total;
             }
+        }
+        if (D.apex_na > 0 && h->threads == 128) { // the apex of a 128-thread handle reads the forward image where it is: the LDS copy of the workspace slab
+            if (!h->ldsres) return bail(EICOS_RETRY_NO_APEX, "internal: 128-thread handle with an apex but without the LDS-resident build");
+            D.apex_lds = D.lr_work + D.w_UF + D.apex_f; D.apex_inplace = 1;
         }
     }
     int bpc = 1;
@@ -1537,10 +1546,8 @@ double eicos_debug_host_check(int n, int m, int p, int ncones, const int *q, con
                 for (int k = 0; k < na; k++) for (int i = k + 1; i < na; i++) ws[n0 + i] -= UF[pf.apex_base + apex_img_at(i, k)] * ws[n0 + k];
                 for (int i = na - 1; i >= 0; i--) {
                     ws[n0 + i] *= invD[n0 + i];
-                    for (int k = 0; k < na; k++) ws[n0 + k] -= UB[pb.apex_base + 64 * i + k] * ws[n0 + i];
+                    for (int k = 0; k < i; k++) ws[n0 + k] -= UB[pb.apex_base + apex_img_at(i, k)] * ws[n0 + i];
                 }
-                for (int k = 0; k < na; k++) for (int i = 0; i <= k; i++) // (nothing may sit on or above the diagonal of the row-major image)
-                    if (UB[pb.apex_base + 64 * i + k] != 0.) throw std::logic_error("apex: entry above the diagonal");
             }
             sweep(pb, UB, false);
             std::vector<double> xt(N);

@@ -164,12 +164,13 @@ struct DevPat {
     int w_Kimg;                    // workspace: dense tile image of K the tile factorisation starts from (= w_Kt in pure tile mode)
     int nfs_ext;                   // hybrid / dense apex: slices of the forward plan's extra level (rows of the top block, columns below it)
     // dense apex (symbolic.hpp): nodes apex_n0 .. apex_n0 + apex_na - 1 (apex_na = 0: none; <= 64), swept by wavefront 0 alone from the
-    // dense images UF + apex_f (column k of the block across the lanes: 64 k + i) and UB + apex_b (row i across the lanes: 64 i + k)
+    // folded images (apex_img_at below) UF + apex_f (the block's unit-lower L) and UB + apex_b (U = L.*D)
     int apex_na, apex_n0, apex_f, apex_b;
     // apex_lds >= 0 (NLDS >= 1 and room in LDS): offset (doubles, in the dynamic LDS) of the FOLDED strictly-lower image of the block's unit-lower L
     // (apex_img_at below, APEX_IMG doubles) -- copied from the forward image after every factorisation; both sweeps then read LDS (a global
     // load per step is a memory round trip per APEX_QD steps: measured, the sweeps got SLOWER with the apex on global images)
     int apex_lds;
+    int apex_inplace; // 1 (LDS-resident build): apex_lds points at the forward image inside the LDS copy of the workspace slab -- nothing to copy after a factorisation
     // one long row of the apex cut into apex_split_n parts by the forward plan's `ext` level (plans.hpp: TriPlan::split_row): the parts' sums sit, negated, in
     // the sweep-vector slots apex_split_slot .. + apex_split_n - 1 when the apex sweep starts; it adds them to lane apex_split_lane and zeroes them
     int apex_split_lane, apex_split_slot, apex_split_n;

@@ -735,8 +735,8 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 // na dependent steps of ~30 cycles replace (levels of the apex) slice steps of ~1100 (MPC02: 63 nodes = levels 10..20 of 21).  Same operations
 // as a column-oriented substitution (the reference's, Eigen's, order); the level-scheduled sweeps sum a row first and subtract once.
 constexpr int APEX_QD = 8;
-// (128-thread workgroups -- small patterns, tight register budgets -- never carry an apex: api.cpp drops it with that workgroup size)
-template <int T> __device__ __forceinline__ bool apex_on(const DevPat &P) { if constexpr (T >= 256) return P.apex_na > 0; else return false; }
+// (128-thread workgroups carry an apex only in the LDS-resident build -- 256 VGPRs, the images inside the LDS copy of the workspace slab: api.cpp)
+template <int T> __device__ __forceinline__ bool apex_on(const DevPat &P) { if constexpr (T >= 256 || EICOS_LDSRES != 0) return P.apex_na > 0; else return false; }
 // the parts of the split row (DevPat::apex_split_*): their sum -- every lane reads the same few slots -- and the slots zeroed for the next sweep
 template <int KI, class WS>
 __device__ __forceinline__ void apex_take_split(const DevPat &P, WS ws, int lane, double (&s)[KI]) {
@@ -785,14 +785,15 @@ __device__ __forceinline__ void apex_solve(const DevPat &P, gcdbl_p UF, gcdbl_p 
         }
     }
     const double dinv = ld_u32(invD, me);
+    auto brow = [&](int i) { return lane < i ? ld_u32(R, apex_img_at(max(i, 1), lane)) : 0.; }; // (U[i, lane]: the folded image again)
 #pragma unroll
-    for (int d = 0; d < APEX_QD; d++) q[d] = ld_u32(R, max(na - 1 - d, 0) * 64 + lane);
+    for (int d = 0; d < APEX_QD; d++) q[d] = brow(max(na - 1 - d, 0));
     for (int i0 = na - 1; i0 >= 0; i0 -= APEX_QD) { // (steps below row 0 of the last trip re-read row 0 -- all zeros -- and finalise no lane)
 #pragma unroll
         for (int d = 0; d < APEX_QD; d++) {
             const int i = i0 - d;
             const double ui = q[d];
-            q[d] = ld_u32(R, max(i - APEX_QD, 0) * 64 + lane);
+            q[d] = brow(max(i - APEX_QD, 0));
 #pragma unroll
             for (int r = 0; r < KI; r++) {
                 x[r] = (lane == i) ? x[r] * dinv : x[r]; // lane i: every row above it has been subtracted
@@ -1385,7 +1386,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
     }
     }
     if constexpr (NLDS >= 1) { // dense apex: the LDS image of the block's L -- a straight copy of the forward image the passes above have just written
-        if (P.apex_na > 0 && P.apex_lds >= 0) { // (measured: sharing the region with the head of E -- dead during the sweeps -- and copying the image in at every solve costs the sweeps what it gives the residuals)
+        if (P.apex_na > 0 && P.apex_lds >= 0 && !P.apex_inplace) { // (measured: sharing the region with the head of E -- dead during the sweeps -- and copying the image in at every solve costs the sweeps what it gives the residuals)
             __syncthreads();
             for (int e = tid; e < APEX_IMG; e += T) g_dyn[P.apex_lds + e] = ld_u32((gcdbl_p)UF, P.apex_f + e);
         }

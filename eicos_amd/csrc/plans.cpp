@@ -146,11 +146,12 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     if (apex) { // the entries inside the apex: dense image behind the dummy slot
         const int na = S.N - S.apex0;
         pl.apex_base = ((pl.slots + 1 + 63) / 64) * 64;
-        pl.ulen = pl.apex_base + (forward ? APEX_IMG : 64 * na);
+        pl.ulen = pl.apex_base + APEX_IMG;
+        (void)na;
         for (int j = S.apex0; j < S.N; j++)
             for (int e = S.Lp[j]; e < S.Lp[j + 1]; e++) {
                 const int i = S.Li[e] - S.apex0, k = j - S.apex0; // (rows of a column lie above it in the order: i > k, both inside the apex)
-                pl.pos[e] = pl.apex_base + (forward ? apex_img_at(i, k) : 64 * i + k);
+                pl.pos[e] = pl.apex_base + apex_img_at(i, k);
             }
     }
     return pl;

@@ -21,10 +21,9 @@ struct TriPlan {
     int slots = 0;
     // dense apex (Symbolic::apex0 >= 0): the sweeps stop below the apex like the hybrid's (forward: its rows against the columns below as the
     // `ext` level); the entries of L INSIDE the apex have their slots in a dense image behind the dummy slot, from apex_base on (a multiple
-    // of 64).  Forward (the unit-lower L the apex sweeps read): the FOLDED image of device_types.hpp, apex_img_at(i - apex0, k - apex0), APEX_IMG
-    // doubles -- the order the LDS copy has, so that copy is a straight one.  Backward (U = L.*D, operands of the factor program; read by
-    // the sweeps only when no LDS vector exists): row i across the lanes k, apex_base + 64 (i - apex0) + (k - apex0).  Image positions no
-    // entry names stay zero.
+    // of 64): the FOLDED image of device_types.hpp, apex_img_at(i - apex0, k - apex0), APEX_IMG doubles, in both plans.  Forward = the
+    // unit-lower L the apex sweeps read -- the order the LDS copy has, so that copy is a straight one.  Backward = U = L.*D, the operands of
+    // the factor program (read by the sweeps only when no LDS vector exists).  Image positions no entry names stay zero.
     int apex_base = 0;
     int ulen = 1;              // length of the plan's value array: slots + 1 (the dummy), or apex_base + the image
     // dense apex, forward plan: ONE row of the apex that is much longer than the others (the root of an MPC tree: 935 entries in the columns

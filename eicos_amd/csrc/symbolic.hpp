@@ -85,7 +85,7 @@ struct Symbolic {
 Symbolic analyze(const ProblemPattern &P, int order_mode = -1, int tile = -1);
 constexpr int APEX_MAX = 64;        // nodes of the dense apex: one per lane of a wavefront
 constexpr int APEX_MIN_LEVELS = 5;  // worth it from this many levels on (it costs about three slice steps per solve itself)
-constexpr int APEX_MIN_N = 256;     // small patterns keep the level schedule (128-thread workgroups, slabs in LDS: no room for dense images)
+constexpr int APEX_MIN_N = 96;      // (128-thread workgroups carry an apex only in the LDS-resident build: api.cpp decides)
 constexpr int APEX_OVER_HYBRID_BELOW = 512; // below this size the apex replaces the hybrid's tile block when both apply (api.cpp; measured on lp_adlittle, lp_blend: +17 %)
 
 } // namespace eicos
