@@ -391,7 +391,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     if (D.nfs % TRI_DEPTH || D.nbs % TRI_DEPTH || D.nfs_ext % TRI_DEPTH || D.nfs_solo % TRI_DEPTH_SOLO || D.nbs_solo % TRI_DEPTH_SOLO) {
         delete h; return fail(EICOS_E_INVALID, "internal: a section of a sweep plan is not padded to its queue depth");
     }
-    // (value arrays: the plan's slots + the dummy slot, then -- dense apex -- the na x 64 image of the block's own entries, zero wherever no
+    // (value arrays: the plan's slots + the dummy slot, then -- dense apex -- the folded image of the block's own entries (APEX_IMG doubles), zero wherever no
     // entry of L lands: the work slabs are zeroed at creation and the factor program only ever writes entry slots)
     D.w_UF = Wl.add((size_t)planF.ulen + 8); D.w_UB = Wl.add((size_t)planB.ulen + 8);
     const bool apex = !tile && S.apex0 >= 0;

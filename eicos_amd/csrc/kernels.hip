@@ -730,10 +730,11 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
 // sweeps over it by ONE wavefront, lane = node, the iterate in a register:
 //   forward  (unit-lower L):  for k = 0 .. na-2:  y_i -= L[i,k] y_k  on the lanes i > k   -- column k of the block across the lanes
 //   backward (U = L.*D):      for i = na-1 .. 0:  x_i = acc_i / D_i;  acc_k -= U[i,k] x_i  on the lanes k < i  -- row i across the lanes
-// The entries come from dense na x 64 images behind the sweep plans' value arrays (zero where L has no entry: a step is one coalesced 512-byte
-// load, issued APEX_QD steps ahead -- it does not depend on the iterate -- a broadcast of the pivot lane's value and one multiply-subtract).
 // na dependent steps of ~30 cycles replace (levels of the apex) slice steps of ~1100 (MPC02: 63 nodes = levels 10..20 of 21).  Same operations
 // as a column-oriented substitution (the reference's, Eigen's, order); the level-scheduled sweeps sum a row first and subtract once.
+// apex_solve below is the FALLBACK for handles without an LDS vector (patterns too large for LDS): it gathers the entries, APEX_QD steps ahead,
+// from the folded images behind the sweep plans' value arrays in the workspace slab (device_types.hpp: apex_img_at; zero where L has no entry)
+// -- a memory round trip per APEX_QD steps, slower than the level schedule on MPC02.  The product path is apex_solve_lds.
 constexpr int APEX_QD = 8;
 // (128-thread workgroups carry an apex only in the LDS-resident build -- 256 VGPRs, the images inside the LDS copy of the workspace slab: api.cpp)
 template <int T> __device__ __forceinline__ bool apex_on(const DevPat &P) { if constexpr (T >= 256 || EICOS_LDSRES != 0) return P.apex_na > 0; else return false; }

@@ -70,7 +70,7 @@ struct Symbolic {
     // nodes apex0..N-1, at most APEX_MAX of them -- are narrow (1..16 rows) and each costs both sweeps a dependent slice step on one
     // wavefront.  They are swept instead as ONE dense triangular system by one wavefront, lane = node, the iterate in a register, a column
     // (forward) / row (backward) of the block per step: na dependent multiply-subtract steps instead of (nlev - apex_lev) slice steps.
-    // The factor program is unchanged; the entries of L inside the block get slots in a dense na x 64 image behind each sweep plan's
+    // The factor program is unchanged; the entries of L inside the block get slots in a dense (folded, APEX_IMG doubles) image behind each sweep plan's
     // value array (plans.hpp: TriPlan::apex_base), everything else of the rows of the block (their entries in columns < apex0) becomes one
     // workgroup-wide level of the forward plan (as in the hybrid).  apex0 < 0: none.
     int apex0 = -1, apex_lev = 0;
