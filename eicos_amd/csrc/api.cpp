@@ -384,7 +384,8 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     // (tile mode: the sweeps and the factorisation run over the tile plan instead; the scalar plans stay empty)
     TriPlan planF, planB;
-    if (!tile1) { planF = build_tri_plan(S, h->threads, true); planB = build_tri_plan(S, h->threads, false); }
+    // (dense apex on a handle of at most one workgroup per CU: no single-wavefront part in the forward sweep either -- plans.cpp)
+    if (!tile1) { planF = build_tri_plan(S, h->threads, true, !(!tile && S.apex0 >= 0 && batch <= h->n_cu)); planB = build_tri_plan(S, h->threads, false); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
     // every section of a sweep plan is a whole number of queue-depth trips (tri_sweep's remainder loop executes full trips)

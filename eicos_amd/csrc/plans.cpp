@@ -1,5 +1,6 @@
 // Host-side construction of the sliced-ELL triangular-solve plans.
 #include "plans.hpp"
+#include "envknob.hpp"
 
 #include <algorithm>
 
@@ -123,7 +124,12 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     // levels >= vs form the narrow top of the tree (each fits one wavefront in at most two slices)
     const int v_first = forward ? 1 : 0; // forward (L y = b, unit lower L): level-0 rows have no entries: y = b
     int vs = nlev;
-    if (allow_solo) while (vs > v_first && slices_of(vs - 1, 64) <= 2) vs--;
+    // (with a dense apex the backward sweep has no single-wavefront part: the few narrow levels left below the apex run as workgroup-wide
+    // slices, so that the backward sweep is ONE call whose loads start while wavefront 0 is still in the apex -- measured +0.5 ... 2 %)
+    // (the forward sweep of a handle that runs one workgroup per CU likewise -- api.cpp passes allow_solo = false: lp_blend +4 %, lp_adlittle +2 %; with a
+    // second workgroup on the CU the idle wavefronts of a single-wavefront part are issue slots for the neighbour, and the narrow levels stay on it)
+    const bool solo_here = allow_solo && !(apex && !forward && env_knob("EICOS_APEX_BSOLO", 0, 0, 1) == 0);
+    if (solo_here) while (vs > v_first && slices_of(vs - 1, 64) <= 2) vs--;
     if (forward) {
         for (int v = v_first; v < vs; v++) emit_level(v, T);
         // dense apex with no narrow levels below it: its rows against the columns below are simply the last level of the workgroup-wide
