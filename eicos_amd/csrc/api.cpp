@@ -384,8 +384,11 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     // ---- sliced-ELL plans of the two triangular sweeps (device_types.hpp: SliceMeta) ----
     // (tile mode: the sweeps and the factorisation run over the tile plan instead; the scalar plans stay empty)
     TriPlan planF, planB;
-    // (dense apex on a handle of at most one workgroup per CU: no single-wavefront part in the forward sweep either -- plans.cpp)
-    if (!tile1) { planF = build_tri_plan(S, h->threads, true, !(!tile && S.apex0 >= 0 && batch <= h->n_cu)); planB = build_tri_plan(S, h->threads, false); }
+    // A handle of at most one workgroup per CU gives NO level to a single wavefront: the idle wavefronts of such a part are issue slots for a
+    // neighbour on the CU -- without one, every extra sweep call only adds a cold start (lp_bandm +2.2 %, lp_beaconfd +2.6 %, lp_blend +4 %,
+    // lp_adlittle +2 %, lp_agg +0.6 %, lp_25fv47 +-0; MPC02 at three per CU -3 ... -7 %, which keeps its single-wavefront tree top)
+    const bool solo_ok = batch > h->n_cu;
+    if (!tile1) { planF = build_tri_plan(S, h->threads, true, solo_ok); planB = build_tri_plan(S, h->threads, false, solo_ok); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
     // every section of a sweep plan is a whole number of queue-depth trips (tri_sweep's remainder loop executes full trips)

@@ -126,8 +126,8 @@ TriPlan build_tri_plan(const Symbolic &S, int T, bool forward, bool allow_solo) 
     int vs = nlev;
     // (with a dense apex the backward sweep has no single-wavefront part: the few narrow levels left below the apex run as workgroup-wide
     // slices, so that the backward sweep is ONE call whose loads start while wavefront 0 is still in the apex -- measured +0.5 ... 2 %)
-    // (the forward sweep of a handle that runs one workgroup per CU likewise -- api.cpp passes allow_solo = false: lp_blend +4 %, lp_adlittle +2 %; with a
-    // second workgroup on the CU the idle wavefronts of a single-wavefront part are issue slots for the neighbour, and the narrow levels stay on it)
+    // (a handle that runs one workgroup per CU has no single-wavefront parts at all -- api.cpp passes allow_solo = false; with a second workgroup on
+    // the CU the idle wavefronts of a single-wavefront part are issue slots for the neighbour, and the narrow levels stay on it)
     const bool solo_here = allow_solo && !(apex && !forward && env_knob("EICOS_APEX_BSOLO", 0, 0, 1) == 0);
     if (solo_here) while (vs > v_first && slices_of(vs - 1, 64) <= 2) vs--;
     if (forward) {
