@@ -150,8 +150,11 @@ class Job:
         self.solver.solve_async()
         self.step_no += 1
 
-    def run(self, dist, steps, warmup):
-        """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides."""
+    def run(self, dist, steps, warmup, min_seconds=0.0):
+        """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides.  The timed loop only ENQUEUES (update +
+        solve per step, no host synchronisation inside): every launch's duration is read afterwards from the handle's ring of HIP events
+        (eicos_batch_ms_history), so the wall time holds no host round trip per step.  min_seconds > 0 (auxiliary legs): K is raised until the
+        timed region lasts at least that long (sized from one fenced pilot step)."""
         torch = self.torch
 
         def fence():
@@ -170,10 +173,20 @@ class Job:
         for _ in range(warmup):
             self.step()
         fence()
-        kernel_ms, update_ms, shard_ms = [], [], []
+        if min_seconds > 0:
+            tp = time.perf_counter()
+            self.step()
+            fence()
+            steps = min(5000, max(steps, int(np.ceil(min_seconds / max(time.perf_counter() - tp, 1e-6)))))
+        # (a library of a previous round -- the prev_round leg -- has no event ring: its launches are read one by one, with a host round trip per step)
+        ring = (not self.multi) and self.solver.ms_history("solve", 1) is not None
+        kernel_ms, update_ms, shard_ms, step_ms = [], [], [], []
         t0 = time.perf_counter()
         for _ in range(steps):
+            ts = time.perf_counter()
             self.step()
+            if ring:
+                continue
             # per-launch kernel duration from HIP events recorded on the solver's own stream
             if self.multi:
                 mx, per = self.solver.last_solve_ms()
@@ -182,8 +195,12 @@ class Job:
             else:
                 kernel_ms.append(self.solver.last_solve_ms())
                 update_ms.append(self.solver.last_update_ms())
+            step_ms.append((time.perf_counter() - ts) * 1e3)
         fence()
         dt = time.perf_counter() - t0
+        if ring:  # the last min(K, 64) launches of the timed region, on the GPU's own clock
+            k = min(steps, 64)
+            kernel_ms, update_ms, step_ms = (self.solver.ms_history(w, k) for w in ("solve", "update", "step"))
         ia = self.solver.info_arrays()
         dev = getattr(self, "ctl_device", None) or self.devs[0]["c"].device
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -196,7 +213,12 @@ class Job:
             dist.all_reduce(kmin, op=dist.ReduceOp.MIN)  # launch skew between the ranks (timing only: no data-path collective)
             dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         tot_iters, tot_ok, tot_B, ranks_seen = (int(v) for v in cnt.tolist())
+        sm = np.asarray(step_ms, dtype=np.float64)
         return dict(ranks_seen=ranks_seen, dt=float(t.item()), iters=tot_iters, ok=tot_ok, instances=tot_B, ia=ia, kernel_ms=km, update_ms=float(np.mean(update_ms)),
+                    steps=steps, timing=("event ring, no host synchronisation inside the timed loop" if ring else "one host round trip per step"),
+                    # one step = updateData start -> solve end (ring: on the GPU's clock; else the host's clock around the step incl. its event wait)
+                    step_ms={"min": float(np.nanmin(sm)), "median": float(np.nanmedian(sm)), "max": float(np.nanmax(sm)), "n": int(sm.size)},
+                    kernel_ms_minmax=[float(np.min(kernel_ms)), float(np.max(kernel_ms))],
                     kernel_ms_min_over_ranks=float(kmin.item()), kernel_ms_max_over_ranks=float(kmax.item()),
                     shard_kernel_ms=([float(v) for v in np.mean(np.asarray(shard_ms), axis=0)] if shard_ms else None))
 
@@ -219,6 +241,10 @@ class Job:
         inst_ms = np.sort(ia["solve_us"]) * 1e-3  # device wall time of every instance's solve (its workgroup): the launch's tail
         return {
             "value": r["iters"] * steps / r["dt"], "unit": "iter/s", "ms_per_step": r["dt"] / steps * 1e3,
+            # the same iterations over the kernel time alone (mean HIP-event duration of the solve launches of the timed region): what the
+            # wall-clock value would be with nothing but the solve kernel in a step -- the gap between the two is updateData + launch gaps
+            "value_kernel": r["iters"] / (r["kernel_ms_max_over_ranks"] * 1e-3), "steps": steps,
+            "step_ms": r["step_ms"], "kernel_ms_minmax": r["kernel_ms_minmax"], "timing": r["timing"],
             "solves_per_sec": r["instances"] * steps / r["dt"], "optimal": r["ok"], "instances": r["instances"],
             "dim_K": dims["dim_K"], "nnzK": dims["nnzK"], "nnzL": dims["nnzL"], "levels": dims["nlevels"], "cones": dims["ncones"],
             "mean_iter": r["iters"] / max(1, r["instances"]),  # (over ALL ranks / shards, like `value`)
@@ -372,7 +398,9 @@ def summarise(rep):
     """Compact form of one workload's report for `config.summary` (short keys, numbers rounded: the whole line stays below 6 KB)."""
     roof, cpu = rep["roofline"], rep.get("cpu_baseline")
     r3 = lambda v: None if v is None else float(f"{v:.4g}")
-    o = {"value": r3(rep["value"]), "batch": rep["instances"], "optimal": rep["optimal"], "mean_iter": r3(rep["mean_iter"]),
+    sm = rep["step_ms"]
+    o = {"value": r3(rep["value"]), "value_kernel": r3(rep["value_kernel"]), "steps": rep["steps"], "step_ms": [r3(sm["min"]), r3(sm["median"]), r3(sm["max"])],
+         "batch": rep["instances"], "optimal": rep["optimal"], "mean_iter": r3(rep["mean_iter"]),
          "ldl_per_iter": r3(rep["mean_ldl_solves_per_iter"]), "path": rep["factor_path"] + "/" + str(rep.get("kernel_build")),
          "kernel_ms": r3(roof["kernel_ms"]), "frac": r3(roof["frac"]), "frac_dual": r3(roof["frac_dual"]),
          "algo_GB": r3(roof["algorithmic_bytes_per_launch"] / 1e9),
@@ -384,8 +412,9 @@ def summarise(rep):
     return o
 
 
-def run_config(args, name, pattern, batch, local_rank, perturb=False, soc=False, steps=3, warmup=1, cpu_s=6.0):
-    """One additional BASELINE.json config on this GPU, timed like the headline (updateData + solve per step): its own
+def run_config(args, name, pattern, batch, local_rank, perturb=False, soc=False, steps=10, warmup=3, cpu_s=6.0, min_seconds=0.3):
+    """One additional BASELINE.json config on this GPU, timed like the headline (updateData + solve per step; at least `steps` steps AND
+    `min_seconds` of timed work, after `warmup` steps that bring the clocks back up behind the previous leg's CPU baseline): its own
     value, roofline and CPU baseline (a smaller sample than the headline's, so that the default run stays within minutes)."""
     import copy
     import eicos_amd
@@ -398,8 +427,8 @@ def run_config(args, name, pattern, batch, local_rank, perturb=False, soc=False,
     else:
         pat, sets = eicos_amd.read_problem(os.path.join(ROOT, "tests", "golden", pattern + ".epb"))
     job = Job(a, pat, sets, 0, batch, local_rank, soc=soc)
-    res = job.run(None, steps, warmup)
-    rep = job.report(res, steps, f"{pattern}{'-SOC' if soc else ''} batch={batch}")
+    res = job.run(None, steps, warmup, min_seconds)
+    rep = job.report(res, res["steps"], f"{pattern}{'-SOC' if soc else ''} batch={batch}")
     rep["workload"] = f"{pattern}{'-SOC' if soc else ''}, batch {batch}, {'perturbed (c,h)' if perturb else 'strictly feasible generated (c,h,b)'}"
     rep["exit_codes"] = {str(k): int(v) for k, v in zip(*np.unique(res["ia"]["exitcode"], return_counts=True))}
     if not args.no_cpu_baseline:
@@ -407,6 +436,57 @@ def run_config(args, name, pattern, batch, local_rank, perturb=False, soc=False,
         rep["gpu_over_cpu"] = rep["value"] / rep["cpu_baseline"]["value"]
     job.solver.close()
     return rep
+
+
+def aux_legs():
+    """The auxiliary legs of the default N = 1 line: (summary key, run_config arguments).  Every leg: >= 10 steps and >= 0.3 s timed, warm-up 3."""
+    legs = [("dense_front_b512", dict(name="dense_front", pattern="dense-front", batch=512, cpu_s=8.0))]
+    legs += [(f"{nm}_b256", dict(name=nm, pattern=nm, batch=256, perturb=True, cpu_s=4.0)) for nm in ("lp_afiro", "lp_bandm", "lp_25fv47")]
+    legs += [("mpc_b512", dict(name="mpc_b512", pattern="MPC02", batch=512, cpu_s=6.0)),
+             ("mpc_b4096", dict(name="mpc_b4096", pattern="MPC02", batch=4096, cpu_s=6.0))]
+    return legs
+
+
+PREV_LIB = os.path.join(ROOT, "build_exp", "r05", "libeicos_amd.so")  # the previous round's final library (git worktree at 87ad960 + make; build_exp/ is not tracked)
+
+
+def legs_only(args, local_rank=0):
+    """`--legs-json`: every workload of the default line (headline, soc, the auxiliary legs) on whatever library EICOS_AMD_LIB names, GPU part
+    only (no CPU baseline), one compact json object on stdout.  The default run calls this in CHILD processes for the previous round's
+    library and for the current one, back to back on the same box: `config.summary.prev_round`."""
+    r3 = lambda v: float(f"{v:.4g}")
+    out = {}
+    legs = [("headline", dict(name="headline", pattern="MPC02", batch=1024)), ("soc", dict(name="soc", pattern="MPC02", batch=1024, soc=True))] + aux_legs()
+    args.no_cpu_baseline = True
+    for k, kw in legs:
+        kw.pop("cpu_s", None)
+        try:
+            v = run_config(args, kw.pop("name"), kw.pop("pattern"), kw.pop("batch"), local_rank, **kw)
+            out[k] = [r3(v["value"]), r3(v["value_kernel"])]
+        except Exception as e:  # noqa: BLE001
+            out[k] = str(e)[:120]
+    print(json.dumps(out), flush=True)
+
+
+def prev_round_legs(local_rank):
+    """Same-box round-over-round delta: the legs on the previous round's library and on the current one, each in its own child process, back to
+    back (process-to-process spread on one box is +-3 %: read the pair, not one number).  None when the previous library is not there."""
+    import subprocess
+    if not os.path.exists(PREV_LIB):
+        return None
+    out = {"lib": os.path.relpath(PREV_LIB, ROOT), "columns": "[value, value_kernel] iter/s", "order": "prev, cur, prev, cur"}
+    for tag, lib in (("prev", PREV_LIB), ("cur", ""), ("prev2", PREV_LIB), ("cur2", "")):
+        env = dict(os.environ)
+        env.pop("EICOS_AMD_LIB", None)
+        if lib:
+            env["EICOS_AMD_LIB"] = lib
+        env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(local_rank))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--legs-json"], env=env, capture_output=True, text=True, timeout=600)
+            out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            out[tag] = str(e)[:120]
+    return out
 
 
 def launch_mode(gpus, env, multi, visible_devices):
@@ -463,7 +543,16 @@ def main():
     ap.add_argument("--io", choices=("local", "root"), default="local", help="local: every rank regenerates its own shard "
                     "(no collective, default); root: rank 0 holds the whole batch and scatters shards over RCCL/xGMI "
                     "before the timed region, results are gathered back after it (times reported in config)")
+    ap.add_argument("--legs-json", action="store_true", help="(internal) the GPU part of every workload of the default line on the library "
+                    "EICOS_AMD_LIB names; used by the default run for config.summary.prev_round")
+    ap.add_argument("--no-prev-round", action="store_true", help="skip the previous-round comparison legs (config.summary.prev_round)")
     args = ap.parse_args()
+    if args.legs_json:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch  # noqa: F401
+        args.perturb, args.resolve, args.warm = False, 0.0, 0.0
+        legs_only(args)
+        return
 
     # (the host driver of this pool supports dmabuf IPC only: RCCL / peer mappings across processes need it; already exported on the GPU boxes)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -591,11 +680,7 @@ def main():
             # every other BASELINE.json config, driver-run: configs[4] dense-front (MFMA path), configs[3] LPnetlib (three of the
             # ten patterns: the smallest, a mid-size hybrid one, the deepest), the per-GPU share of configs[2] and north_star's
             # ">= 10x the host at batch 4096 on one GPU" configuration
-            legs = [("dense_front_b512", dict(name="dense_front", pattern="dense-front", batch=512, steps=2, warmup=1, cpu_s=8.0))]
-            legs += [(f"{nm}_b256", dict(name=nm, pattern=nm, batch=256, perturb=True, steps=5, warmup=1, cpu_s=4.0)) for nm in ("lp_afiro", "lp_bandm", "lp_25fv47")]
-            legs += [("mpc_b512", dict(name="mpc_b512", pattern="MPC02", batch=512, steps=5, warmup=1, cpu_s=6.0)),
-                     ("mpc_b4096", dict(name="mpc_b4096", pattern="MPC02", batch=4096, steps=3, warmup=1, cpu_s=6.0))]
-            for k, kw in legs:
+            for k, kw in aux_legs():
                 try:  # (an auxiliary leg must not cost the headline line: its failure is reported in its own entry)
                     v = run_config(args, kw.pop("name"), kw.pop("pattern"), kw.pop("batch"), local_rank, **kw)
                     details[k] = v
@@ -611,6 +696,11 @@ def main():
                                               "path": he[v]["update_path"]} for v in ("pageable", "registered", "pinned") if v in he}}
             except Exception as e:  # noqa: BLE001
                 summary["host_e2e"] = {"error": str(e)[:200]}
+            if not args.no_prev_round:
+                pr = prev_round_legs(local_rank)
+                if pr is not None:
+                    details["prev_round"] = pr
+                    summary["prev_round"] = pr
         out = {
             "metric": "ipm_iterations_per_sec", "value": value, "unit": unit,
             "n_gpus": (len(set(multi_ids)) if multi_ids else len(set(rank_devices))), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -87,16 +87,20 @@ def _lib():
         L.eicos_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_last_update_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_destroy.argtypes = [vp]
-        L.eicos_batch_last_update_path.argtypes = [vp]
-        L.eicos_batch_last_update_path.restype = C.c_int
-        L.eicos_host_alloc.argtypes = [C.c_size_t]
-        L.eicos_host_alloc.restype = vp
-        L.eicos_host_free.argtypes = [vp]
-        L.eicos_host_free.restype = C.c_int
-        L.eicos_host_register.argtypes = [vp, C.c_size_t]
-        L.eicos_host_register.restype = C.c_int
-        L.eicos_host_unregister.argtypes = [vp]
-        L.eicos_host_unregister.restype = C.c_int
+        if hasattr(L, "eicos_batch_ms_history"):  # (round 6; absent from a previous round's library)
+            L.eicos_batch_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
+            L.eicos_batch_ms_history.restype = C.c_int
+        if hasattr(L, "eicos_host_alloc"):  # absent from a previous round's library (EICOS_AMD_LIB: same-box A/B runs, bench.py's prev_round leg)
+            L.eicos_batch_last_update_path.argtypes = [vp]
+            L.eicos_batch_last_update_path.restype = C.c_int
+            L.eicos_host_alloc.argtypes = [C.c_size_t]
+            L.eicos_host_alloc.restype = vp
+            L.eicos_host_free.argtypes = [vp]
+            L.eicos_host_free.restype = C.c_int
+            L.eicos_host_register.argtypes = [vp, C.c_size_t]
+            L.eicos_host_register.restype = C.c_int
+            L.eicos_host_unregister.argtypes = [vp]
+            L.eicos_host_unregister.restype = C.c_int
         L.eicos_debug_factor.argtypes = [vp, C.c_int, dp, dp]
         L.eicos_debug_pattern.argtypes = [vp, ip, ip, ip]
         L.eicos_debug_trace.argtypes = [vp, C.c_int, dp]
@@ -301,6 +305,18 @@ class BatchSolver:
         ms = C.c_float()
         _chk(_lib().eicos_batch_last_update_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def ms_history(self, which="solve", cap=64):
+        """HIP-event durations (ms) of the most recent solve launches / updateData calls, oldest first (the handle's ring of 64 event pairs; which = "solve" | "update" | "step" = update start -> solve end):
+        lets a caller time K back-to-back steps without synchronising inside its loop.  None with a library that predates the call."""
+        L = _lib()
+        if not hasattr(L, "eicos_batch_ms_history"):
+            return None
+        buf = (C.c_float * cap)()
+        n = L.eicos_batch_ms_history(self._h, {"solve": 0, "update": 1, "step": 2}[which], buf, cap)
+        if n < 0:
+            _chk(n)
+        return [float(buf[i]) for i in range(n)]
 
     def last_update_path(self) -> str:
         """How the most recent host-pointer / peer updateData moved its inputs (UPDATE_PATHS)."""

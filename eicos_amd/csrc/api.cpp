@@ -30,15 +30,25 @@
 #include "envknob.hpp"
 
 using namespace eicos;
-// Workgroups per CU for a batch, at most `max_r`.  A workgroup slows down by about half of its stand-alone time per co-resident
-// workgroup (measured, MPC02: 13 / 19.8 / 25.8 ms per instance at 1 / 2 / 3 per CU), and a last, partly filled round still costs
-// more than half a round; the cheapest estimate wins (batch 1024 on 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3).
-static int launch_blocks_per_cu(int batch, int n_cu, int max_r) {
+// Workgroups per CU for a batch, at most `max_r`: the cheapest estimate of the launch's duration wins.
+//   time of one "round" (every resident workgroup solves one instance) at r per CU, relative to r = 1:  1 + 0.5 (r - 1) up to r = 2; the
+//   256-thread kernel beyond two per CU grows in proportion to r (+ 1.5 %): re-measured with the final round-5 library, same box, interleaved
+//   (profiles/r06_log_ab_r04_r05_libs.log, r06_log_launch_shapes.log; MPC02): 11.15 ms per round of 512 at two per CU (the 256-VGPR build, dense
+//   apex, residual head in LDS) against 17.0 ms per round of 768 at three (168 VGPRs, neither) -- 45.9 against 45.2 instances per ms: the
+//   third workgroup buys nothing in the steady state any more, it only rounds a batch differently;
+//   a partly filled LAST round costs more than its share (0.55 + 0.45 f) only when it follows a single full round (batch 768: 20.6 ms as
+//   1.5 rounds at two per CU, 18.7 ms as one round at three); behind two or more full rounds the longest-first queue evens the tail out
+//   and the share is what it costs (measured f = 2/3 behind two rounds: 0.63; f = 1/3 behind five: 0.22).
+// MPC02 on 256 CUs: 3 per CU for 513 ... 768 instances only; 1024, 1536, 2048, 3072 and 4096 run at two (measured: +4 % at 1536, +2.5 % at
+// 3072, +-1 % at 2048, -2 % at 4096 against three per CU -- inside the +-3 % spread between two processes on one box -- on 1.18 x instead of
+// 1.33 x the algorithmic HBM traffic), so the set-up no longer runs twice for the large batches (eicos_batch_create).
+static int launch_blocks_per_cu(int batch, int n_cu, int max_r, int threads) {
     double best = 1e300; int best_r = 1;
     for (int r = 1; r <= max_r; r++) {
         const double rounds = (double)batch / ((double)n_cu * r);
         const double full = std::floor(rounds), f = rounds - full;
-        const double cost = (1.0 + 0.5 * (r - 1)) * (full + (f > 0 ? 0.55 + 0.45 * f : 0.0));
+        const double round_time = (threads == 256 && r > 2) ? 1.5 * 1.015 * (r / 2.0) : 1.0 + 0.5 * (r - 1);
+        const double cost = round_time * (full + (f > 0 ? (full >= 2 ? f : 0.55 + 0.45 * f) : 0.0));
         if (cost < best - 1e-12) { best = cost; best_r = r; }
     }
     return best_r;
@@ -86,6 +96,13 @@ struct eicos_batch {
     double warm_shift = 0.; // > 0: warm start (eicos_batch_set_warm_start)
     double dyn_delta = 0., dyn_eps = 0.; // > 0: dynamic regularisation (eicos_batch_set_dynamic_regularization)
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // HIP events around every solve launch / every updateData call, on the handle's stream.  A RING of pairs: the durations of the last
+    // EV_RING launches can be read after the fact (eicos_batch_ms_history), so that a caller timing K back-to-back steps need not
+    // synchronise with the GPU inside its loop to learn each launch's duration.  ev_* = the most recent pair of each ring.
+    static constexpr int EV_RING = 64;
+    hipEvent_t ring_s[EV_RING][2] = {}, ring_u[EV_RING][2] = {};
+    hipEvent_t ring_step0[EV_RING] = {}; // per solve slot: start event of the updateData call that preceded it (the start of the caller's "step")
+    long n_solve_rec = 0, n_update_rec = 0;
     hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr;
     bool solve_timed = false, update_timed = false;
     bool in_chunked_update = false; // eicos_batch_update records ev_u0/ev_u1 around ALL of its chunks
@@ -144,7 +161,7 @@ int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
     if (rc == EICOS_RETRY_NO_APEX) return batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, false, out);
     if (rc != EICOS_OK || (*out)->sym.apex0 < 0) return rc;
     eicos_batch *h = *out;
-    if (launch_blocks_per_cu(batch, h->n_cu, h->bpc + 1) <= h->bpc) return rc; // one more per CU would not be taken anyway
+    if (launch_blocks_per_cu(batch, h->n_cu, h->bpc + 1, h->threads) <= h->bpc) return rc; // one more per CU would not be taken anyway
     eicos_batch *h0 = nullptr;
     if (batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, h->device, false, &h0) != EICOS_OK) return rc;
     if (h0->bpc > h->bpc) { eicos_batch_destroy(h); *out = h0; } else eicos_batch_destroy(h0);
@@ -719,11 +736,8 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     bpc = std::max(1, std::min(bpc, 8));
     HIP_TRY_H(update_set_max_lds()); // (per handle = per device, after hipSetDevice: the entry-parallel updateData kernels use up to 160 KB of dynamic LDS)
     {
-        // Workgroups per CU for this batch.  A workgroup slows down by about half of its stand-alone time per
-        // co-resident workgroup (measured, MPC02: 13 / 19.8 / 25.8 ms per instance at 1 / 2 / 3 per CU), and a last,
-        // partly filled round still costs more than half a round; pick the cheapest estimate (e.g. batch 1024 on
-        // 256 CUs: two full rounds at 2 per CU beat 1 1/3 rounds at 3 per CU, batch >= 1536 takes 3 per CU).
-        bpc = launch_blocks_per_cu(batch, prop.multiProcessorCount, bpc);
+        // Workgroups per CU for this batch: the cheapest estimate (launch_blocks_per_cu, measured constants)
+        bpc = launch_blocks_per_cu(batch, prop.multiProcessorCount, bpc, h->threads);
     }
     bpc = std::max(1, std::min(bpc, env_int("EICOS_BLOCKS_PER_CU", bpc, 1, 8)));
     // 256 threads at <= 2 workgroups per CU: the build with 256 VGPRs per thread (the default one is held to 168 so that three fit)
@@ -795,8 +809,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     HIP_TRY_H(hipMalloc(&h->d_scratch, (size_t)h->upd_grid * (size_t)(S.n + S.p + S.m + 8) * sizeof(double)));
     HIP_TRY_H(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    HIP_TRY_H(hipEventCreate(&h->ev_s0)); HIP_TRY_H(hipEventCreate(&h->ev_s1));
-    HIP_TRY_H(hipEventCreate(&h->ev_u0)); HIP_TRY_H(hipEventCreate(&h->ev_u1));
+    // (the event pairs of the timing rings are created on first use: next_events)
     HIP_TRY_H(hipDeviceSynchronize());
     *out = h;
     return EICOS_OK;
@@ -836,7 +849,8 @@ int eicos_batch_destroy(eicos_batch *h) {
     // in-flight work may sit on a caller stream (eicos_batch_set_stream): wait for it before the slabs go away
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
-    for (hipEvent_t e : {h->ev_s0, h->ev_s1, h->ev_u0, h->ev_u1}) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < eicos_batch::EV_RING; i++)
+        for (hipEvent_t e : {h->ring_s[i][0], h->ring_s[i][1], h->ring_u[i][0], h->ring_u[i][1]}) if (e) (void)hipEventDestroy(e);
     for (void *ptr : {(void *)h->d_pattern, (void *)h->d_inst, (void *)h->d_work, (void *)h->d_queue, (void *)h->d_scratch,
                       (void *)h->d_stage, (void *)h->d_flag})
         if (ptr) (void)hipFree(ptr);
@@ -865,6 +879,20 @@ int eicos_batch_set_stream(eicos_batch *h, void *hip_stream) {
     return EICOS_OK;
 }
 
+// the next event pair of a timing ring (created on first use) becomes the handle's current pair
+static int next_events(hipEvent_t (*ring)[2], long &count, hipEvent_t &e0, hipEvent_t &e1) {
+    hipEvent_t *slot = ring[count % eicos_batch::EV_RING];
+    for (int i = 0; i < 2; i++) if (!slot[i]) HIP_TRY(hipEventCreate(&slot[i]));
+    e0 = slot[0]; e1 = slot[1]; count++;
+    return EICOS_OK;
+}
+static int begin_update_timing(eicos_batch *h) {
+    int rc = next_events(h->ring_u, h->n_update_rec, h->ev_u0, h->ev_u1);
+    if (rc != EICOS_OK) return rc;
+    HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+    return EICOS_OK;
+}
+
 int eicos_batch_update_device(eicos_batch *h, int first, int count, const double *dG, const double *dA,
                               const double *dc, const double *dh, const double *db) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
@@ -872,7 +900,7 @@ int eicos_batch_update_device(eicos_batch *h, int first, int count, const double
     if (dG && !dh && h->dp.m > 0) return fail(EICOS_E_INVALID, "Gpr given without h");
     if (dA && !db && h->dp.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
     HIP_TRY(hipSetDevice(h->device));
-    if (!h->in_chunked_update) HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+    if (!h->in_chunked_update) { const int rc = begin_update_timing(h); if (rc != EICOS_OK) return rc; }
     HIP_TRY(launch_update(h->pslot, h->d_inst, first, count, dG, dA, dc, dh, db, h->d_scratch, std::min(count, h->upd_grid), h->upd_lds, h->upd_vals_lds, h->stream));
     if (!h->in_chunked_update) { HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true; }
     return EICOS_OK;
@@ -973,16 +1001,27 @@ class CopyPool {
 
 // Is `p` host memory the GPU can address directly (hipHostMalloc / hipHostRegister / eicos_host_alloc)?  Then kernels read or write it
 // in place over PCIe and no bounce copy is needed.
-// 0 = pageable host memory, 1 = pinned / registered host memory, 2 = device (or managed) memory
+// 0 = pageable (or managed) host-addressable memory, 1 = pinned / registered host memory, 2 = device memory
 int pointer_kind(const void *p) {
     if (!p) return 0;
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; } // (plain malloc memory: "invalid value")
     if (a.type == hipMemoryTypeHost) return 1;
-    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray) return 2;
-    return 0;
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return 2;
+    return 0; // (managed memory is host-addressable: it takes the bounce path like pageable memory)
 }
-bool is_pinned_host(const void *p) { return pointer_kind(p) == 1; }
+// Is the WHOLE extent [p, p + bytes) pinned / registered host memory?  The kernels read (updateData) or the copy engine writes (results) every byte of
+// it in place, so the first byte alone does not decide: a pointer into a registered buffer with a count that runs past its end, or a buffer
+// registered a second time with a larger size (hipHostRegister reports "already registered" and maps nothing new), would be a GPU page
+// fault instead of an error code.  First byte, last byte and one probe per 2 MB in between (a lookup costs about a microsecond).
+bool is_pinned_host(const void *p, size_t bytes) {
+    if (pointer_kind(p) != 1) return false;
+    if (bytes <= 1) return true;
+    const char *b = (const char *)p;
+    if (pointer_kind(b + bytes - 1) != 1) return false;
+    for (size_t o = 2u << 20; o < bytes - 1; o += 2u << 20) if (pointer_kind(b + o) != 1) return false;
+    return true;
+}
 // the handle's two pinned bounce buffers hold at least `doubles` each
 int ensure_pin(eicos_batch *h, size_t doubles) {
     if (doubles <= h->pin_doubles) return EICOS_OK;
@@ -1016,7 +1055,11 @@ int eicos_host_free(void *p) {
 int eicos_host_register(void *p, size_t bytes) {
     if (!p || bytes == 0) return fail(EICOS_E_INVALID, "bad argument");
     const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
-    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return EICOS_OK; }
+    if (e == hipErrorHostMemoryAlreadyRegistered) { // fine only if the existing registration covers the whole range asked for
+        (void)hipGetLastError();
+        if (is_pinned_host(p, bytes)) return EICOS_OK;
+        return fail(EICOS_E_INVALID, "eicos_host_register: the pointer is already registered with a SMALLER extent (unregister it first)");
+    }
     if (e != hipSuccess) return fail(EICOS_E_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
     return EICOS_OK;
 }
@@ -1078,7 +1121,7 @@ int eicos_internal_update_staged(eicos_batch *h, int first, int count, const dou
             h->stage_doubles = need;
         }
         int rc = EICOS_OK;
-        HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+        { const int rc0 = begin_update_timing(h); if (rc0 != EICOS_OK) return rc0; }
         h->in_chunked_update = true;
         for (int o = 0; o < count && rc == EICOS_OK; o += chunk) {
             const int cnt = std::min(chunk, count - o);
@@ -1101,7 +1144,12 @@ int eicos_internal_update_staged(eicos_batch *h, int first, int count, const dou
     }
     // ---- host pointers ----
     bool all_pinned = true, any_device = false;
-    for (const Arr &a : arr) if (a.src && a.w) { const int kind = pointer_kind(a.src); if (kind != 1) all_pinned = false; if (kind == 2) any_device = true; }
+    for (const Arr &a : arr) if (a.src && a.w) {
+        const int kind = pointer_kind(a.src);
+        if (kind == 2) any_device = true;
+        // pinned in place only when EVERY byte the kernel will read is mapped (else the bounce path, which reads with the host's own loads)
+        if (kind != 1 || !is_pinned_host(a.src, (size_t)count * a.w * sizeof(double))) all_pinned = false;
+    }
     // a device pointer handed to the HOST-pointer entry point must not reach the bounce copy (a host memcpy from it would fault)
     if (any_device) return fail(EICOS_E_INVALID, "eicos_batch_update takes host pointers: an array lives in device memory (use eicos_batch_update_device)");
     if (all_pinned && !env_knob("EICOS_HOST_BOUNCE", 0, 0, 1)) {
@@ -1117,7 +1165,8 @@ int eicos_internal_update_staged(eicos_batch *h, int first, int count, const dou
     if (count > chunk && count < 2 * chunk) chunk = (count + 1) / 2; // two even chunks rather than a long one and a stub
     int rc = ensure_pin(h, (size_t)chunk * row);
     if (rc != EICOS_OK) return rc;
-    HIP_TRY(hipEventRecord(h->ev_u0, h->stream));
+    rc = begin_update_timing(h);
+    if (rc != EICOS_OK) return rc;
     h->in_chunked_update = true;
     CopyPool &pool = CopyPool::get();
     int k = 0;
@@ -1154,6 +1203,8 @@ int eicos_batch_update(eicos_batch *h, int first, int count, const double *G, co
 int eicos_batch_solve_async(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
     HIP_TRY(hipSetDevice(h->device));
+    { const int rc = next_events(h->ring_s, h->n_solve_rec, h->ev_s0, h->ev_s1); if (rc != EICOS_OK) return rc; }
+    h->ring_step0[(h->n_solve_rec - 1) % eicos_batch::EV_RING] = h->update_timed ? h->ev_u0 : h->ev_s0;
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
     HIP_TRY(solve_build(h->threads, h->ldsres, h->w2).launch(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds,
                                                              h->dp.idx16, h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
@@ -1176,7 +1227,7 @@ int eicos_batch_sync(eicos_batch *h) {
 static int fetch_rows(eicos_batch *h, double *dst, int off, int width) {
     if (!dst || width == 0) return EICOS_OK;
     const size_t wb = (size_t)width * sizeof(double), pitch = h->dp.inst_stride * sizeof(double);
-    if (is_pinned_host(dst) || (size_t)h->batch * wb < (256u << 10)) {
+    if (is_pinned_host(dst, (size_t)h->batch * wb) || (pointer_kind(dst) != 1 && (size_t)h->batch * wb < (256u << 10))) {
         HIP_TRY(hipMemcpy2DAsync(dst, wb, h->d_inst + off, pitch, wb, (size_t)h->batch, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         return EICOS_OK;
@@ -1304,6 +1355,25 @@ static int elapsed(eicos_batch *h, bool ok, hipEvent_t a, hipEvent_t b, float *m
 }
 int eicos_batch_last_solve_ms(eicos_batch *h, float *ms) { return elapsed(h, h && h->solve_timed, h ? h->ev_s0 : nullptr, h ? h->ev_s1 : nullptr, ms); }
 int eicos_batch_last_update_ms(eicos_batch *h, float *ms) { return elapsed(h, h && h->update_timed, h ? h->ev_u0 : nullptr, h ? h->ev_u1 : nullptr, ms); }
+// Durations (ms, HIP events on the handle's stream) of the most recent launches, oldest first: which = 0 the solve launches, 1 the
+// updateData calls, 2 the span from the start of the updateData call that preceded a solve launch to the end of that solve (one "step").  Returns how many were written (<= cap, <= 64: the ring's depth); waits for the most recent one to finish.
+int eicos_batch_ms_history(eicos_batch *h, int which, float *ms, int cap) {
+    if (!h || !ms || cap < 0 || which < 0 || which > 2) return fail(EICOS_E_INVALID, "bad argument");
+    hipEvent_t (*ring)[2] = which != 1 ? h->ring_s : h->ring_u;
+    const long total = which != 1 ? h->n_solve_rec : h->n_update_rec;
+    if (which != 1 ? !h->solve_timed : !h->update_timed) return 0;
+    const int cnt = (int)std::min<long>(std::min<long>(cap, eicos_batch::EV_RING), total);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(which != 1 ? h->ev_s1 : h->ev_u1));
+    for (int i = 0; i < cnt; i++) {
+        const long at = (total - cnt + i) % eicos_batch::EV_RING;
+        hipEvent_t *slot = ring[at];
+        // (which = 2: the step's span.  The update ring turns as fast as the solve ring when updateData and solve alternate -- the caller's step --
+        // so the start event a solve slot remembers is still that step's; with several updates per solve the span is NaN or too short: documented)
+        if (hipEventElapsedTime(&ms[i], which == 2 ? h->ring_step0[at] : slot[0], slot[1]) != hipSuccess) { (void)hipGetLastError(); ms[i] = NAN; } // (a call that failed half way)
+    }
+    return cnt;
+}
 
 int eicos_debug_factor(eicos_batch *h, int inst, double *Dout, double *Uout) {
     if (!h || inst < 0 || inst >= h->batch) return fail(EICOS_E_INVALID, "bad argument");

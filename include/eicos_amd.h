@@ -157,6 +157,12 @@ int eicos_batch_set_stream(eicos_batch *hd, void *hip_stream);
 /* HIP-event timing of the most recent solve / update kernels on the handle's stream (ms). */
 int eicos_batch_last_solve_ms(eicos_batch *hd, float *ms);
 int eicos_batch_last_update_ms(eicos_batch *hd, float *ms);
+/* The durations (ms) of the most recent launches, oldest first: which = 0 the solve launches, 1 the updateData calls, 2 the span of a
+ * whole step (start of the updateData call that preceded a solve launch -> end of that solve; meaningful when the two alternate).  The handle keeps a
+ * ring of 64 event pairs, so a caller that enqueues K steps back to back (update + solve_async, no host synchronisation in between) can
+ * read every launch's duration afterwards.  Returns the number written (<= cap, <= 64) or a negative error; waits for the most recent
+ * launch to finish.  No reference counterpart (measurement only). */
+int eicos_batch_ms_history(eicos_batch *hd, int which, float *ms, int cap);
 /* replaces the Solver destructor / ECOS_cleanup (reference test/ecos.h:31-34) */
 int eicos_batch_destroy(eicos_batch *hd);
 

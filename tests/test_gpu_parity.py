@@ -1168,6 +1168,86 @@ def test_warm_start_matches_oracle_and_saves_iterations(soc):
     g.close()
 
 
+def test_partly_pinned_extents_take_the_bounce_path_and_reregistering_larger_is_refused():
+    # an array is read / written in place only when EVERY byte of its extent is pinned.  A registration of the first
+    # rows only, a pointer whose count runs past the registered end, and a second registration of the same base with a larger size
+    # (hipHostRegister answers "already registered" and maps nothing new) used to be classified from the first byte alone -> GPU page fault.
+    from eicos_amd.binding import _lib
+    pat, sets = load_fixture("lp_afiro")
+    B = 64
+    d = feasible_batch(pat, sets[0], 0, B)
+    keys = ("Gpr", "Apr", "c", "h", "b")
+    L = _lib()
+    g = eicos_amd.BatchSolver(pat, B, device=0)
+    g.update(*[d[k] for k in keys]); codes0 = g.solve(); x0 = g.solution()
+    big = np.ascontiguousarray(np.tile(d["Gpr"], (400, 1)))  # 400 * 64 rows: several MB, only the first rows get registered
+    half = big[: B // 2]
+    assert L.eicos_host_register(half.ctypes.data, half.nbytes) == 0
+    try:
+        # all B rows from the half-registered buffer: the extent is not fully pinned -> bounce path, same bits
+        others = {k: np.ascontiguousarray(d[k]).copy() for k in keys if k != "Gpr"}
+        for v in others.values():
+            if v.size:
+                eicos_amd.host_register(v)
+        g.update(big[:B], others["Apr"], others["c"], others["h"], others["b"])
+        assert g.last_update_path() == "pinned bounce"
+        assert np.array_equal(g.solve(), codes0) and np.array_equal(g.solution(), x0)
+        # ... and the fully registered half IS read in place
+        g.update(big[: B // 2], others["Apr"][: B // 2], others["c"][: B // 2], others["h"][: B // 2], others["b"][: B // 2], first=0, count=B // 2)
+        assert g.last_update_path() == "pinned source in place"
+        assert np.array_equal(g.solve(), codes0) and np.array_equal(g.solution(), x0)
+        for v in others.values():
+            if v.size:
+                eicos_amd.host_unregister(v)
+        # results into a buffer that is pinned at its first byte only: staged, not written past the mapping
+        xb = np.zeros((40 * B, pat.n))
+        assert L.eicos_host_register(xb.ctypes.data, xb[: B // 2].nbytes) == 0
+        assert np.array_equal(g.solution_into(xb[:B]), x0)
+        assert L.eicos_host_unregister(xb.ctypes.data) == 0
+        # the same base pointer registered again with a LARGER size: either the runtime maps the larger range (then all of it is usable in
+        # place) or it answers "already registered" and maps nothing new -- which is refused, not reported as success
+        rc = L.eicos_host_register(big.ctypes.data, big.nbytes)
+        assert rc == 0 or (rc == -1 and b"SMALLER" in L.eicos_last_error())
+        others = {k: np.ascontiguousarray(d[k]).copy() for k in keys if k != "Gpr"}
+        for v in others.values():
+            if v.size:
+                eicos_amd.host_register(v)
+        g.update(big[:B], others["Apr"], others["c"], others["h"], others["b"])
+        assert g.last_update_path() in (("pinned source in place", "pinned bounce") if rc == 0 else ("pinned bounce",))  # (in place only if every probe of the extent answers "pinned")
+        assert np.array_equal(g.solve(), codes0) and np.array_equal(g.solution(), x0)
+        for v in others.values():
+            if v.size:
+                eicos_amd.host_unregister(v)
+    finally:
+        L.eicos_host_unregister(half.ctypes.data)
+    g.close()
+
+
+def test_launch_durations_are_kept_in_a_ring_of_events():
+    # eicos_batch_ms_history: K steps enqueued back to back, every launch's duration read afterwards (bench.py's timed loop has no host
+    # synchronisation inside); the ring holds 64, oldest first; "step" = updateData start -> solve end >= update + solve
+    pat, sets = load_fixture("lp_afiro")
+    B = 32
+    d = feasible_batch(pat, sets[0], 0, B)
+    g = eicos_amd.BatchSolver(pat, B, device=0)
+    assert g.ms_history("solve") == [] and g.ms_history("update") == []
+    for k in range(5):
+        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+        g.solve_async()
+    g.sync()
+    hs, hu, ht = g.ms_history("solve"), g.ms_history("update"), g.ms_history("step")
+    assert len(hs) == len(hu) == len(ht) == 5 and all(v > 0 for v in hs + hu)
+    assert abs(hs[-1] - g.last_solve_ms()) < 1e-6 and abs(hu[-1] - g.last_update_ms()) < 1e-6
+    assert all(t >= s_ + u - 1e-3 for t, s_, u in zip(ht, hs, hu))
+    assert g.ms_history("solve", 2) == hs[-2:]
+    for k in range(70):
+        g.solve_async()
+    g.sync()
+    assert len(g.ms_history("solve", 100)) == 64
+    assert np.all(g.info_arrays()["exitcode"] == 0)
+    g.close()
+
+
 def test_bench_emits_the_contract_json_line():
     # bench.py's one-line JSON: metric/unit of BASELINE.json, roofline and cpu_baseline objects, whole-job value
     import json, os, subprocess, sys
@@ -1199,7 +1279,10 @@ def test_bench_emits_the_contract_json_line():
     # a batch of 64 fits one workgroup per CU: the two independent KKT systems of a pass are solved as one dual solve, so the yardstick
     # that charges the passes over L really made is the stricter one; the launch's tail is reported
     assert 0 < r["frac_dual"] < r["frac"] and s["inst_ms_max"] >= s["inst_ms_p95"] > 0
-    assert len(out.stdout.strip().splitlines()[-1]) < 6144
+    assert len(out.stdout.strip().splitlines()[-1]) < 8192
+    # every summary entry: the kernel-only rate beside the wall-clock one, the steps timed and the step's span (min / median / max, GPU clock)
+    for e in (d["config"]["summary"]["headline"], s):
+        assert e["steps"] == 2 and e["value_kernel"] >= e["value"] > 0 and len(e["step_ms"]) == 3 and e["step_ms"][0] <= e["step_ms"][1] <= e["step_ms"][2]
 
 
 def test_bench_multi_flag_drives_the_product_multi_gpu_layer():
