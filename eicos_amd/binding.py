@@ -290,11 +290,12 @@ class BatchSolver:
         return d.asdict()
 
     def kernel_build(self) -> str:
-        """Which compilation of the solve kernel the handle launches: 'default', 'lds-resident' or 'w2' (256 VGPRs, <= 2 workgroups per CU)."""
+        """Which compilation of the solve kernel the handle launches: 'default', 'lds-resident', 'w2' (256 VGPRs, <= 2 workgroups per CU) or
+        'u-in-lds' (one workgroup per CU, the factor operand array in LDS)."""
         v = _lib().eicos_batch_kernel_build(self._h)
         if v < 0:
             _chk(v)
-        return ("default", "lds-resident", "w2")[v]
+        return ("default", "lds-resident", "w2", "u-in-lds")[v]
 
     def last_solve_ms(self) -> float:
         ms = C.c_float()

@@ -79,6 +79,7 @@ struct eicos_batch {
     size_t dyn_lds = 0;
     int nlds = 0;
     int w2 = 0;               // 1: solves run the two-waves-per-SIMD build of the 256-thread kernel (w2::launch_solve)
+    int ubl = 0;              // 1: solves run the build with the factor operand array U in LDS (ubl256:: / ubl512::launch_solve; one workgroup per CU)
     int ldsres = 0;           // 1: solves run the LDS-resident kernel (ldsres::launch_solve), slabs copied in and out per instance
     size_t pattern_ints = 0;
     double *d_inst = nullptr, *d_work = nullptr, *d_scratch = nullptr;
@@ -748,7 +749,22 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
         HIP_TRY_H(w2::solve_occupancy(h->threads, h->nlds, h->dp.idx16, h->dyn_lds, &got));
         if (got >= bpc) h->w2 = 1;
     }
-    const SolveBuild sbuild = solve_build(h->threads, h->ldsres, h->w2);
+    // One workgroup per CU (batch <= CUs) and the factor operand array U = L.*D fits the LDS that the lone workgroup leaves idle: the build that
+    // keeps it there (kernels_ubl*.hip).  The numeric factorisation of a deep pattern is a chain of levels that each wait for operand gathers
+    // and for their stores to land -- L2 round trips with U in the workspace slab, LDS round trips here; bit-identical results.
+    h->ubl = 0; D.ub_lds = -1; D.ub_len = h->ub_len;
+    if (!h->ldsres && (h->threads == 256 || h->threads == 512) && bpc == 1 && batch <= prop.multiProcessorCount && h->nlds >= 1 && D.fac_defer && !tile1 &&
+        !(D.apex_na > 0 && D.apex_lds < 0) && env_int("EICOS_UBL", 1, 0, 1)) {
+        const size_t base = (h->dyn_lds + 15) & ~(size_t)15, need = base + ((size_t)h->ub_len + 8) * sizeof(double);
+        if (need + 4096 <= 160 * 1024) { // (4 KB: the static block, as budgeted above)
+            const SolveBuild ub = solve_build(h->threads, false, false, true);
+            int got = 0;
+            HIP_TRY_H(ub.set_max_lds(h->threads, h->nlds, h->dp.idx16, need));
+            HIP_TRY_H(ub.occupancy(h->threads, h->nlds, h->dp.idx16, need, &got));
+            if (got >= 1) { h->ubl = 1; h->w2 = 0; D.ub_lds = (int)(base / sizeof(double)); h->dyn_lds = need; }
+        }
+    }
+    const SolveBuild sbuild = solve_build(h->threads, h->ldsres, h->w2, h->ubl);
     auto v_set_max_lds = sbuild.set_max_lds;
     auto v_occupancy = sbuild.occupancy;
     // The LDS that `bpc` resident workgroups leave free takes the head of the refinement residual E (device_types.hpp: e_lds): its
@@ -1206,7 +1222,7 @@ int eicos_batch_solve_async(eicos_batch *h) {
     { const int rc = next_events(h->ring_s, h->n_solve_rec, h->ev_s0, h->ev_s1); if (rc != EICOS_OK) return rc; }
     h->ring_step0[(h->n_solve_rec - 1) % eicos_batch::EV_RING] = h->update_timed ? h->ev_u0 : h->ev_s0;
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
-    HIP_TRY(solve_build(h->threads, h->ldsres, h->w2).launch(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds,
+    HIP_TRY(solve_build(h->threads, h->ldsres, h->w2, h->ubl).launch(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds,
                                                              h->dp.idx16, h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
@@ -1317,7 +1333,7 @@ int eicos_batch_solution_device(eicos_batch *h, const double **dx, size_t *strid
 
 int eicos_batch_kernel_build(eicos_batch *h) {
     if (!h) return fail(EICOS_E_INVALID, "NULL handle");
-    return h->ldsres ? 1 : (h->w2 ? 2 : 0);
+    return h->ldsres ? 1 : (h->w2 ? 2 : (h->ubl ? 3 : 0));
 }
 
 int eicos_internal_device(const eicos_batch *h) { return h ? h->device : -1; }

@@ -157,6 +157,9 @@ struct DevPat {
     // NLDS = 1 without dual right-hand sides: elimination positions [0, e_lds) of the refinement residual E are kept in LDS at g_dyn + e_off
     // (doubles) -- the part of the CU's LDS that the chosen number of resident workgroups leaves unused
     int e_lds, e_off;
+    // U-in-LDS builds (kernels_ubl*.hip; one workgroup per CU): the factor operand array U = L.*D (w_UB, ub_len doubles incl. padding and dummy slots)
+    // lives at g_dyn + ub_lds (doubles) instead of in the workspace slab; -1 = not this build
+    int ub_lds, ub_len;
     int fac_defer, fac_kpad; gint_p fac_pk, fac_k16; // fac_kpad: the pivot-column index of padding pairs (its mirror slot holds 0)
     // ---- tile mode (dense fronts, tiles.hpp): L = block-sparse matrix of dense 16 x 16 tiles; D.N is then 16 * nb ----
     int tile, nb, nt, nblev;       // 1 = tile path, 2 = hybrid (top block of the tree on tiles); blocks, off-diagonal tiles, block levels

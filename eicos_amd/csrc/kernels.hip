@@ -58,7 +58,16 @@
 #ifndef EICOS_TSPLIT
 #define EICOS_TSPLIT 0
 #endif
-#define EICOS_MAIN_BUILD (!EICOS_LDSRES && !EICOS_W2 && !EICOS_TSPLIT)
+// Two more (kernels_ubl256.o / kernels_ubl512.o, namespaces eicos::ubl256 / ubl512, EICOS_UBL = the workgroup size): the 256- / 512-thread solve
+// kernel for launches of ONE workgroup per CU (batch <= CUs: BASELINE configs[3]) whose factor operand array U = L.*D (DevPat::w_UB) fits the
+// LDS that a lone workgroup leaves idle.  There the numeric factorisation is a chain of dependent levels whose operand gathers and
+// stores each cost an L2 round trip (lp_bandm: 73 levels, 1.7 us per level); with U in LDS (`ubdbl_p` below is an LDS pointer in this
+// build; DevPat::ub_lds = its offset in the dynamic LDS) a level costs LDS round trips, and the backward sweep streams U from LDS as well.
+// Same program, same order of operations: results are bit-identical to the HBM-slab kernels.  256 VGPRs (two waves per SIMD).
+#ifndef EICOS_UBL
+#define EICOS_UBL 0
+#endif
+#define EICOS_MAIN_BUILD (!EICOS_LDSRES && !EICOS_W2 && !EICOS_TSPLIT && !EICOS_UBL)
 
 namespace eicos {
 #if EICOS_LDSRES
@@ -72,6 +81,12 @@ typedef double EICOS_DATA *gdbl_p;        // (shadow the global-memory typedefs 
 typedef const double EICOS_DATA *gcdbl_p;
 #elif EICOS_W2
 namespace w2 {
+#define EICOS_DATA EICOS_GLOBAL
+#elif EICOS_UBL == 256
+namespace ubl256 {
+#define EICOS_DATA EICOS_GLOBAL
+#elif EICOS_UBL == 512
+namespace ubl512 {
 #define EICOS_DATA EICOS_GLOBAL
 #elif EICOS_TSPLIT == 128
 namespace t128 {
@@ -99,7 +114,7 @@ constexpr int EX_NOT_CONVERGED = -87;
 // attributor propagates the kernel's budget to the non-inlined stage functions.
 #if EICOS_LDSRES
 template <int T> constexpr int waves_per_eu() { return 2; } // LDS allows at most three small workgroups per CU
-#elif EICOS_W2
+#elif EICOS_W2 || EICOS_UBL
 template <int T> constexpr int waves_per_eu() { return 2; }
 #else
 template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : (T == 512 ? 2 : 4); }
@@ -110,7 +125,7 @@ template <int T> constexpr int waves_per_eu() { return T == 256 ? 3 : (T == 512 
 // in round 2: +0.2 ... +0.7 % on every config -- the loops wait for their operands, not for issue slots.)
 __device__ __forceinline__ double madd(double acc, double a, double b) { return acc + a * b; }
 constexpr int RED_SLOTS = 8 * 8; // up to 8 wavefronts (512 threads) x 8 values per reduction
-constexpr bool ELL_DQ = EICOS_W2 != 0; // product loops keep decoded slice descriptors in their queue (ell_dots, ell_dots_k)
+constexpr bool ELL_DQ = EICOS_W2 != 0 || EICOS_UBL != 0; // product loops keep decoded slice descriptors in their queue (ell_dots, ell_dots_k)
 
 // scalar slots in LDS (written by thread 0 only)
 enum { SV_RESX0 = 0, SV_RESY0, SV_RESZ0, SV_PRESPREV, SV_RT, SV_DTAUDEN, SV_DTAUAFF, SV_DKAPAFF, SV_BKAP,
@@ -179,6 +194,15 @@ __device__ __forceinline__ double ld_u32_nt(const double EICOS_DATA *base, int i
 __device__ __forceinline__ d2_t ld_u32(const d2_t EICOS_DATA *base, int i) { return base[i]; }
 __device__ __forceinline__ d2_t ld_u32_nt(const d2_t EICOS_DATA *base, int i) { return base[i]; }
 #endif
+// the factor operand array U (DevPat::w_UB): in the workspace slab, or (EICOS_UBL builds) in the dynamic LDS at DevPat::ub_lds
+#if EICOS_UBL && defined(__HIP_DEVICE_COMPILE__)
+typedef double __attribute__((address_space(3))) *ubdbl_p;
+typedef const double __attribute__((address_space(3))) *ubcdbl_p;
+__device__ __forceinline__ double ld_u32(ubcdbl_p base, int i) { return base[i]; }
+#else
+typedef gdbl_p ubdbl_p;
+typedef gcdbl_p ubcdbl_p;
+#endif
 
 // ---- KI-interleaved arrays (the two right-hand sides of a dual solve): element (i, k) sits at i * KI + k, so the
 // KI values of one slot are ONE load / store of 8 KI bytes (KI = 2: 16 bytes per lane, the width the memory system likes best).
@@ -198,6 +222,12 @@ template <int KI, class P> __device__ __forceinline__ void stK(P base, int i, co
     else { static_assert(KI == 2, "KI"); reinterpret_cast<typename vec2_of<P>::type>(base)[i] = d2_t{o[0], o[1]}; }
 }
 // global array, 32-bit byte offset addressing (ld_u32), optionally non-temporal
+#if EICOS_UBL && defined(__HIP_DEVICE_COMPILE__)
+template <int KI, bool NT> __device__ __forceinline__ void ldK_g(ubcdbl_p base, int i, double (&o)[KI]) { // (U in LDS: the backward sweep's value stream)
+    if constexpr (KI == 1) o[0] = base[i];
+    else { static_assert(KI == 2, "KI"); const d2_t v = reinterpret_cast<const d2_t __attribute__((address_space(3))) *>(base)[i]; o[0] = v.x; o[1] = v.y; }
+}
+#endif
 template <int KI, bool NT> __device__ __forceinline__ void ldK_g(gcdbl_p base, int i, double (&o)[KI]) {
     if constexpr (KI == 1) o[0] = NT ? ld_u32_nt(base, i) : ld_u32(base, i);
     else {
@@ -622,8 +652,8 @@ __device__ __forceinline__ void lds_barrier() {
 // workgroup barrier between its levels (one wavefront's LDS accesses execute in order), the other wavefronts
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
 // VSH (dual right-hand sides of ONE instance): the vector ws is KI-interleaved, the factor (eval, invD) is a single one.
-template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class WS>
-__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, gcdbl_p eval, gcdbl_p invD, WS ws,
+template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class EV, class WS>
+__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, EV eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
     // KI = 2 (with VSH): the two right-hand sides of a dual solve -- one factor, the sweep vector ws 2-interleaved, so every
     // gather / store of the pair is one 16-byte LDS access
@@ -1186,7 +1216,8 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
     ps = uni(ps); Wg = uni_ptr(Wg);
     const DevPat &P = c_pat[ps];
     const int tid = threadIdx.x;
-    gdbl_p UF = Wg + P.w_UF, U = Wg + P.w_UB, D = Wg + P.w_D, invD = Wg + P.w_invD; // pa/pb index UB slots
+    gdbl_p UF = Wg + P.w_UF, D = Wg + P.w_D, invD = Wg + P.w_invD;
+    ubdbl_p U = [&] { if constexpr (EICOS_UBL != 0) return (ubdbl_p)(g_dyn + P.ub_lds); else return (ubdbl_p)(Wg + P.w_UB); }(); // pa/pb index UB slots
     gcdbl_p Kt = Wg + P.w_Kt;    // KKT entries in target order (solve prologue + updateKKTScalings)
     gdbl_p Kimg = Wg + P.w_Kimg; // hybrid: targets of the top block go to its tile image
     __syncthreads();
@@ -1208,7 +1239,8 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
     // 1/D[k] of a pair's pivot column: from the LDS mirror ([0, N] at the start of the dynamic LDS, slot fac_kpad = 0 for padding
     // pairs), or -- kernels without an LDS vector: only the debug entry, api.cpp sets fac_defer with NLDS >= 1 -- from the array itself
     auto inv_of = [&](int k) -> double { if constexpr (NLDS >= 1) return g_dyn[k]; else return invD[k]; };
-    gcdbl_p Lsrc = defer ? (gcdbl_p)U : (gcdbl_p)UF;
+    // the pair's second operand: deferred -- U[j,k] (times 1/D[k] from the mirror); stored L -- the forward array
+    auto ld_l = [&](int i) -> double { if constexpr (defer) return ld_u32((ubcdbl_p)U, i); else return ld_u32((gcdbl_p)UF, i); };
     double carry = 0.; // partial sum of targets cut into sub-slices
     const bool tab_lds = NLDS >= 1 && P.lm_fac >= 0; // slice table staged in LDS by k_solve (no global round trip per slice)
     // slice descriptors: from the LDS copy, or (table not staged) from global memory one slice further ahead than
@@ -1307,7 +1339,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
             double (&cu)[ELL_KMAX] = gu[d & 1], (&cl)[ELL_KMAX] = gl[d & 1], (&ck)[ELL_KMAX] = gk[d & 1];
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < ELL_KMAX; u++) { cu[u] = ld_u32((gcdbl_p)U, c.ia[u]); cl[u] = ld_u32(Lsrc, c.ib[u]); ck[u] = defer ? inv_of(c.ik[u]) : 1.; }
+                for (int u = 0; u < ELL_KMAX; u++) { cu[u] = ld_u32((ubcdbl_p)U, c.ia[u]); cl[u] = ld_l(c.ib[u]); ck[u] = defer ? inv_of(c.ik[u]) : 1.; }
             }
             have = !c.last;
             { // UNCONDITIONAL (when the next slice opens a new level its operands are not final yet: they are fetched again
@@ -1316,7 +1348,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
                 const FSlot &nx = q[(d + 1) % FAC_DEPTH];
 #pragma unroll
                 for (int u = 0; u < ELL_KMAX; u++) {
-                    gu[(d + 1) & 1][u] = ld_u32((gcdbl_p)U, nx.ia[u]); gl[(d + 1) & 1][u] = ld_u32(Lsrc, nx.ib[u]);
+                    gu[(d + 1) & 1][u] = ld_u32((ubcdbl_p)U, nx.ia[u]); gl[(d + 1) & 1][u] = ld_l(nx.ib[u]);
                     gk[(d + 1) & 1][u] = defer ? inv_of(nx.ik[u]) : 1.;
                 }
             }
@@ -2192,7 +2224,8 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
     auto tab_rA = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rA; else return P.rA_sl; }();
     auto tab_rG = [&] { if constexpr (NLDS >= 1) return tabs + P.lm_rG; else return P.rG_sl; }();
     gdbl_p dxr = Wg + P.w_dxr;
-    gdbl_p UF = Wg + P.w_UF, UB = Wg + P.w_UB, invD = Wg + P.w_invD; // (one factor, also for two right-hand sides)
+    gdbl_p UF = Wg + P.w_UF, invD = Wg + P.w_invD; // (one factor, also for two right-hand sides)
+    ubcdbl_p UB = [&] { if constexpr (EICOS_UBL != 0) return (ubcdbl_p)(g_dyn + P.ub_lds); else return (ubcdbl_p)(Wg + P.w_UB); }();
     __syncthreads();
     unsigned long long tk0_ = (tid == 0) ? wall_clock64() : 0ull;
     auto tick = [&](int slot) {
@@ -2255,7 +2288,8 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
 #ifdef EICOS_SOLO_TICKS
                     tick(TK_LDL);
 #endif
-                    if (P.apex_lds >= 0) apex_solve_lds<KI>(P, invD, SV); else apex_solve<KI>(P, UF, UB, invD, SV);
+                    if (P.apex_lds >= 0) apex_solve_lds<KI>(P, invD, SV);
+                    else if constexpr (EICOS_UBL == 0) apex_solve<KI>(P, UF, UB, invD, SV); // (UBL handles always carry the LDS image: api.cpp)
                     tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
 #ifdef EICOS_SOLO_TICKS
                     tick(TK_FWD);
@@ -3004,6 +3038,11 @@ __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
         if (P.lm_fac >= 0) stage(P.fac_sl, P.fac_ns, P.lm_fac);
         __syncthreads();
     }
+#if EICOS_UBL
+    // U in LDS: the padding slots and the dummy slot (value 0) are never written by the factor program -- zero the array once per workgroup
+    for (int q = threadIdx.x; q < P.ub_len; q += T) g_dyn[P.ub_lds + q] = 0.;
+    __syncthreads();
+#endif
     if (threadIdx.x == 0) { g_S.dyn_delta = dyn_delta; g_S.dyn_eps = dyn_eps; }
     // Instances differ in iteration count (12..18 on the headline batch): after its first instance (= its own index, so
     // that workspace slot g holds the history of instance g when the batch fits the grid) a workgroup pulls the next
@@ -3342,15 +3381,21 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
         constexpr int T = decltype(tc)::value;
         if (idx16) {
             if (nlds >= 2) return f((const void *)k_solve<T, 2, true>);
-            if (nlds == 1) return f((const void *)k_solve<T, 1, true>);
+            if (nlds == 1 || EICOS_UBL != 0) return f((const void *)k_solve<T, 1, true>); // (U-in-LDS builds: api.cpp never asks for nlds = 0)
+#if !EICOS_UBL
             return f((const void *)k_solve<T, 0, true>);
+#endif
         }
         if (nlds >= 2) return f((const void *)k_solve<T, 2, false>);
-        if (nlds == 1) return f((const void *)k_solve<T, 1, false>);
+        if (nlds == 1 || EICOS_UBL != 0) return f((const void *)k_solve<T, 1, false>);
+#if !EICOS_UBL
         return f((const void *)k_solve<T, 0, false>);
+#endif
     };
 #if EICOS_TSPLIT
     return byT(std::integral_constant<int, EICOS_TSPLIT>{}); // (this build exists for one workgroup size only)
+#elif EICOS_UBL
+    return byT(std::integral_constant<int, EICOS_UBL>{});
 #else
     return byT(std::integral_constant<int, 256>{}); // (kernels.o / kernels_w2.o: 256 threads; 128 and 512 live in kernels_t128.o / kernels_t512.o)
 #endif
@@ -3439,6 +3484,10 @@ hipError_t upload_pattern(int ps, const DevPat &P) {
 } // namespace ldsres
 #elif EICOS_W2
 } // namespace w2
+#elif EICOS_UBL == 256
+} // namespace ubl256
+#elif EICOS_UBL == 512
+} // namespace ubl512
 #elif EICOS_TSPLIT == 128
 } // namespace t128
 #elif EICOS_TSPLIT == 512

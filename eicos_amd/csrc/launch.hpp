@@ -47,6 +47,22 @@ hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
 } // namespace t512
+// the 256- / 512-thread k_solve with the factor operand array U resident in LDS (kernels_ubl256.hip / kernels_ubl512.hip = kernels.hip compiled
+// with EICOS_UBL): launches of one workgroup per CU whose U fits the idle LDS
+namespace ubl256 {
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
+hipError_t upload_pattern(int ps, const DevPat &P);
+} // namespace ubl256
+namespace ubl512 {
+hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
+hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
+hipError_t upload_pattern(int ps, const DevPat &P);
+} // namespace ubl512
 // one k_solve build = these four entry points
 struct SolveBuild {
     decltype(&launch_solve) launch;
@@ -54,8 +70,11 @@ struct SolveBuild {
     decltype(&solve_set_max_lds) set_max_lds;
     decltype(&upload_pattern) upload;
 };
-// the build a handle's solves run: LDS-resident (128 threads), two-waves-per-SIMD (256 threads), or the default one of its workgroup size
-inline SolveBuild solve_build(int threads, bool ldsres, bool w2) {
+// the build a handle's solves run: U in LDS (one workgroup per CU, 256 / 512 threads), LDS-resident (128 threads), two-waves-per-SIMD (256 threads),
+// or the default one of its workgroup size
+inline SolveBuild solve_build(int threads, bool ldsres, bool w2, bool ubl = false) {
+    if (ubl && threads == 256) return {ubl256::launch_solve, ubl256::solve_occupancy, ubl256::solve_set_max_lds, ubl256::upload_pattern};
+    if (ubl && threads == 512) return {ubl512::launch_solve, ubl512::solve_occupancy, ubl512::solve_set_max_lds, ubl512::upload_pattern};
     if (ldsres) return {ldsres::launch_solve, ldsres::solve_occupancy, ldsres::solve_set_max_lds, ldsres::upload_pattern};
     if (w2) return {w2::launch_solve, w2::solve_occupancy, w2::solve_set_max_lds, w2::upload_pattern};
     if (threads == 128) return {t128::launch_solve, t128::solve_occupancy, t128::solve_set_max_lds, t128::upload_pattern};

@@ -150,7 +150,8 @@ int eicos_batch_set_dynamic_regularization(eicos_batch *hd, double delta, double
 int eicos_batch_dims(eicos_batch *hd, eicos_dims *out);
 /* Which compilation of the solve kernel this handle launches (chosen at creation from pattern size and batch; no reference
  * counterpart): 0 = default build, 1 = LDS-resident build for small patterns (eicos_dims.lds_resident), 2 = the 256-thread kernel
- * compiled for two waves per SIMD (launches of at most two workgroups per CU).  Negative: error code. */
+ * compiled for two waves per SIMD (launches of at most two workgroups per CU), 3 = the 256- / 512-thread kernel with the factor operand
+ * array resident in LDS (launches of one workgroup per CU whose factor fits the idle LDS).  Negative: error code. */
 int eicos_batch_kernel_build(eicos_batch *hd);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the own stream. */
 int eicos_batch_set_stream(eicos_batch *hd, void *hip_stream);

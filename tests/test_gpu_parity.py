@@ -272,18 +272,50 @@ def test_dense_apex_in_the_lds_resident_build(monkeypatch):
 
 
 def test_kernel_build_reported_for_the_handle(monkeypatch):
-    # which compilation of k_solve a handle launches is part of its description: 256-thread workgroups at <= 2 per CU take the
-    # 256-VGPR build ("w2"), small patterns the LDS-resident one, everything else the default one; EICOS_W2=0 forbids the first
+    # which compilation of k_solve a handle launches is part of its description: one workgroup per CU with the factor operand array in
+    # the idle LDS ("u-in-lds") when it fits; else 256-thread workgroups at <= 2 per CU take the 256-VGPR build ("w2"), small patterns the
+    # LDS-resident one, everything else the default one; EICOS_UBL=0 / EICOS_W2=0 forbid the first two
     pat, sets = load_fixture("MPC02")
     g = eicos_amd.BatchSolver(pat, 4); d = g.dims(); kb = g.kernel_build(); g.close()
-    assert kb == ("w2" if d["threads_per_block"] == 256 else "default") and not d["lds_resident"]
+    assert kb in ("u-in-lds", "w2" if d["threads_per_block"] == 256 else "default") and not d["lds_resident"]
+    monkeypatch.setenv("EICOS_UBL", "0")
     monkeypatch.setenv("EICOS_THREADS", "256")
     g = eicos_amd.BatchSolver(pat, 4); assert g.kernel_build() == "w2"; g.close()
     monkeypatch.setenv("EICOS_W2", "0")
     g = eicos_amd.BatchSolver(pat, 4); assert g.kernel_build() == "default"; g.close()
-    monkeypatch.delenv("EICOS_W2"); monkeypatch.delenv("EICOS_THREADS")
+    monkeypatch.delenv("EICOS_W2"); monkeypatch.delenv("EICOS_THREADS"); monkeypatch.delenv("EICOS_UBL")
+    g = eicos_amd.BatchSolver(pat, 1024); assert g.kernel_build() == "w2"; g.close()  # (the headline launch: two per CU)
     pat, sets = load_fixture("lp_afiro")
     g = eicos_amd.BatchSolver(pat, 4); d = g.dims(); assert (g.kernel_build() == "lds-resident") == bool(d["lds_resident"]); g.close()
+    pat, sets = load_fixture("lp_bandm")
+    g = eicos_amd.BatchSolver(pat, 256); assert g.kernel_build() == "u-in-lds" and g.dims()["threads_per_block"] == 512; g.close()
+
+
+@pytest.mark.parametrize("name,B,threads", [("lp_bandm", 96, None), ("lp_adlittle", 64, None), ("lp_agg", 48, None), ("lp_beaconfd", 32, None), ("lp_blend", 32, "512"),
+                                            ("update_data", 8, "256"), ("issue98", 4, "256"), ("infeasible1", 4, "512"), ("unboundedLP1", 4, "256")])
+def test_u_in_lds_build_is_bit_identical_to_the_hbm_slab_kernels(name, B, threads, monkeypatch):
+    # at one workgroup per CU the factor operand array U = L.*D lives in the idle LDS when it fits (kernels_ubl*.hip):
+    # the same programs in the same order of operations -- every bit of the result equal to the build that keeps U in the workspace slab
+    # (LP hybrid / apex / MPC-size scalar / SOC / infeasible patterns; perturbed Netlib batches hold ill-posed instances with long solves)
+    pat, sets = load_fixture(name)
+    if name.startswith("lp_"):
+        d = perturbed_batch(pat, sets[0], 0, B)
+    else:  # (the small SOC / infeasible / unbounded fixtures: their own data, workgroup size forced so that they leave the 128-thread LDS-resident build)
+        d = dict(zip(("Gpr", "Apr", "c", "h", "b"), rep(sets[0], B)))
+    if threads:
+        monkeypatch.setenv("EICOS_THREADS", threads)
+    out = []
+    for ubl in ("1", "0"):
+        monkeypatch.setenv("EICOS_UBL", ubl)
+        g = eicos_amd.BatchSolver(pat, B)
+        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+        codes = g.solve(); ia = g.info_arrays(); x = g.solution(); y, z, s_ = g.duals()
+        codes2 = g.solve()  # (a second solve on the same handle: the LDS copy is rebuilt by every factorisation)
+        out.append((g.kernel_build(), codes, ia["iter"], ia["n_ldlsolve"], x, y, z, s_, ia["pcost"], codes2, g.solution()))
+        g.close()
+    assert out[0][0] == "u-in-lds" and out[1][0] != "u-in-lds", (out[0][0], out[1][0])
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
 
 
 def test_g_tile_products_match_the_ell_products_on_dense_fronts(monkeypatch):
@@ -607,6 +639,15 @@ def _all_instances_against_the_oracle(pat, d, codes, ia, x, x_rtol=1e-8, tag=Non
     rec = {"workload": tag or f"n={pat.n} m={pat.m} cones={pat.ncones} batch={len(codes)}", "iters_equal": int(same.sum()), "iters_pm1": int((~same).sum()),
            "xerr_equal_max": float(err[same].max()), "xerr_pm1_max": float(err[~same].max()) if (~same).any() else None,
            "pcost_rel_max": float((np.abs(ia["pcost"] - r["pcost"]) / np.maximum(1.0, np.abs(r["pcost"]))).max())}
+    # How far do two CPU builds of the SAME oracle source differ on these instances?  -O2 (portable: the checker) against -O2 -march=native
+    # (g++ contracts a * b + c into FMAs there: different rounding, same algorithm).  That spread is the conditioning of the problem at the
+    # solver's own stopping tolerance -- the yardstick the GPU's distance has to be read against.
+    rn = orc.batch_solve(pat, d["Gpr"], d["Apr"], d["c"], d["h"], d["b"], len(os.sched_getaffinity(0)), want_x=True, native=True)
+    if rn["native"]:
+        same_n = rn["iters"].astype(int) == it_o
+        err_n = np.abs(rn["x"] - r["x"]).max(axis=1) / np.maximum(1.0, np.abs(r["x"]).max(axis=1))
+        rec.update({"oracle_native_vs_portable_xerr_max": float(err_n[same_n].max()), "oracle_native_iters_equal": int(same_n.sum()),
+                    "gpu_vs_native_xerr_max": float((np.abs(x - rn["x"]).max(axis=1) / np.maximum(1.0, np.abs(rn["x"]).max(axis=1)))[same_n & same].max())})
     print("x parity:", json.dumps(rec))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
