@@ -507,7 +507,11 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
 #pragma unroll
         for (int kk = 0; kk < ELL_KMAX; kk++) {
             const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
+#ifdef EICOS_PROBE_NOVAL // (dev probe: what would the products cost with their value stream free?  wrong numerics, timing only)
+            nv[kk] = 1e-3 * (double)(slot & 7);
+#else
             nv[kk] = ld_u32_nt(eval, slot); // streamed once per pass: keep the shared index arrays in L2
+#endif
         }
         nr = pre(act ? nm.row0 + (t >> nm.lg) : 0);
     };
@@ -575,7 +579,11 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
             const int slot = (act && kk < nm.K) ? nm.off + kk * lanes + t : dummy_slot;
             // streamed once per pass: keep the shared index arrays in L2.  SHARED (dual right-hand sides of ONE instance):
             // the KI vectors are multiplied by the same matrix values -> one load
+#ifdef EICOS_PROBE_NOVAL
+            nv[kk][0] = 1e-3 * (double)(slot & 7);
+#else
             nv[kk][0] = ld_u32_nt(eval[0], slot);
+#endif
 #pragma unroll
             for (int k = 1; k < KI; k++) nv[kk][k] = SHARED ? nv[kk][0] : ld_u32_nt(eval[k], slot);
         }
@@ -1364,7 +1372,13 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void stage_facto
                 else if (c.dst < 0) pivot(c.dst, val);
                 else U[c.dst] = val;
             }
-            if (c.last && defer) { FTICK(9); __syncthreads(); FTICK(10); } // the level's U, D and the pivot mirror are final
+            if (c.last && defer) { // the level's U, D and the pivot mirror are final
+                FTICK(9);
+                // (U in LDS: everything the next level reads -- U, the mirror of 1/D -- went through LDS, so the barrier need not drain the global
+                // stores of D / 1/D (read by the sweeps, after the stage's last barrier) nor the static prefetch of the next slices)
+                if constexpr (EICOS_UBL != 0 && NLDS >= 1) lds_barrier(); else __syncthreads();
+                FTICK(10);
+            }
             else if (c.last) {
                 FTICK(9);
                 __syncthreads();
