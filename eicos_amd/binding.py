@@ -38,7 +38,8 @@ class Dims(C.Structure):
                [("factor_pairs", C.c_longlong), ("inst_bytes", C.c_size_t), ("work_bytes", C.c_size_t),
                 ("pattern_bytes", C.c_size_t), ("threads_per_block", C.c_int), ("resident_blocks", C.c_int),
                 ("lds_bytes", C.c_int), ("instances_per_block", C.c_int),
-                ("lds_resident", C.c_int), ("factor_path", C.c_int), ("cone_order", C.c_int), ("dual_rhs", C.c_int)]
+                ("lds_resident", C.c_int), ("factor_path", C.c_int), ("cone_order", C.c_int), ("dual_rhs", C.c_int),
+                ("arithmetic_profile", C.c_int), ("apex_nodes", C.c_int), ("solo_slices", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -136,6 +137,11 @@ def _lib():
             getattr(L, "eicos_multi_" + f).restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def set_arithmetic_profile(profile: int) -> None:
+    """0 (default): plans shaped by the launch; 1: by the pattern alone -- batch- and shard-independent bits (eicos_set_arithmetic_profile)."""
+    _chk(_lib().eicos_set_arithmetic_profile(int(profile)))
 
 
 def device_count() -> int:

@@ -56,6 +56,8 @@ static int launch_blocks_per_cu(int batch, int n_cu, int max_r, int threads) {
 static constexpr int KI_MAX_HOST = 2; // right-hand sides of a dual solve (kernels.hip: KI_MAX)
 
 static thread_local std::string g_err;
+// eicos_set_arithmetic_profile: 0 = plans shaped by the launch (default), 1 = plans shaped by the pattern alone (batch-independent bits)
+static std::atomic<int> g_arith_profile{0};
 static std::mutex g_slot_mu;
 static std::map<int, std::vector<char>> g_slot_used; // per device: which constant-memory descriptor slots are taken (under g_slot_mu)
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -111,6 +113,7 @@ struct eicos_batch {
     std::vector<int> posB; // CSC entry of L -> slot in the backward value array
     int ub_len = 1;        // length of that array (plan slots + dummy, + the dense apex image)
     int bpc = 1, n_cu = 256; // workgroups per CU of the solve launch; CUs of the device
+    int arith_profile = 0;   // eicos_set_arithmetic_profile at creation
     TilePlan tiles;        // tile mode (Symbolic::tile): the dense-front plan
 };
 
@@ -142,6 +145,13 @@ extern "C" {
 
 const char *eicos_last_error(void) { return g_err.c_str(); }
 
+int eicos_set_arithmetic_profile(int profile) {
+    if (profile != 0 && profile != 1) return fail(EICOS_E_INVALID, "arithmetic profile must be 0 or 1");
+    g_arith_profile.store(profile);
+    return EICOS_OK;
+}
+int eicos_get_arithmetic_profile(void) { return g_arith_profile.load(); }
+
 int eicos_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -158,13 +168,17 @@ constexpr int EICOS_RETRY_NO_APEX = -99; // (internal: never leaves eicos_batch_
 int eicos_batch_create(int n, int m, int p, int l, int ncones, const int *q,
                        const int *Gjc, const int *Gir, const int *Ajc, const int *Air,
                        int batch, int device, eicos_batch **out) {
-    int rc = batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, true, out);
+    int rc = batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, g_arith_profile.load() == 0, out);
     if (rc == EICOS_RETRY_NO_APEX) return batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, device, false, out);
     if (rc != EICOS_OK || (*out)->sym.apex0 < 0) return rc;
     eicos_batch *h = *out;
     if (launch_blocks_per_cu(batch, h->n_cu, h->bpc + 1, h->threads) <= h->bpc) return rc; // one more per CU would not be taken anyway
     eicos_batch *h0 = nullptr;
-    if (batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, h->device, false, &h0) != EICOS_OK) return rc;
+    if (batch_create_impl(n, m, p, l, ncones, q, Gjc, Gir, Ajc, Air, batch, h->device, false, &h0) != EICOS_OK) {
+        static std::atomic<bool> told{false}; // (e.g. out of memory with both handles alive: the launch shape WITH the apex is kept -- say so once)
+        if (!told.exchange(true)) std::fprintf(stderr, "eicos_amd: the set-up without the dense apex failed (%s); keeping %d workgroup(s) per CU\n", g_err.c_str(), h->bpc);
+        return rc;
+    }
     if (h0->bpc > h->bpc) { eicos_batch_destroy(h); *out = h0; } else eicos_batch_destroy(h0);
     return EICOS_OK;
 }
@@ -231,7 +245,12 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
         int n_cu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device < 0 ? 0 : device) == hipSuccess) n_cu = pr.multiProcessorCount; }
         // (sparse factors only: with ~50 entries per row of L -- the dense-front config -- 512 threads stay ahead)
-        const bool throughput_bound = batch > n_cu && (long long)S.nnzL < 16LL * S.N;
+        // (arithmetic profile 1: every choice that shapes a PLAN -- and with it the order of the floating-point operations -- is made as for a
+        // batch beyond one workgroup per CU, whatever the batch really is: workgroup size by pattern size alone, no dense apex, the
+        // single-wavefront tree top; the launch shape itself -- grid, LDS residency, dual solves, which are bit-neutral -- follows the real batch)
+        h->arith_profile = g_arith_profile.load();
+        const bool as_large = h->arith_profile == 1;
+        const bool throughput_bound = (batch > n_cu || as_large) && (long long)S.nnzL < 16LL * S.N;
         // one workgroup per CU (batch <= CUs): latency-bound, more wavefronts per instance pay earlier (measured at batch 256 with
         // the 256-VGPR build of the 512-thread kernels: lp_blend / lp_adlittle, dim_K ~ 300: 256 threads +5..8 % over 128;
         // lp_beaconfd / lp_bandm / lp_agg, dim_K 763..1718: 512 threads +7..12 % over 256)
@@ -405,7 +424,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     // A handle of at most one workgroup per CU gives NO level to a single wavefront: the idle wavefronts of such a part are issue slots for a
     // neighbour on the CU -- without one, every extra sweep call only adds a cold start (lp_bandm +2.2 %, lp_beaconfd +2.6 %, lp_blend +4 %,
     // lp_adlittle +2 %, lp_agg +0.6 %, lp_25fv47 +-0; MPC02 at three per CU -3 ... -7 %, which keeps its single-wavefront tree top)
-    const bool solo_ok = batch > h->n_cu;
+    const bool solo_ok = batch > h->n_cu || h->arith_profile == 1;
     if (!tile1) { planF = build_tri_plan(S, h->threads, true, solo_ok); planB = build_tri_plan(S, h->threads, false, solo_ok); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
@@ -419,7 +438,9 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     const bool apex = !tile && S.apex0 >= 0;
     D.apex_na = apex ? S.N - S.apex0 : 0; D.apex_n0 = apex ? S.apex0 : 0; D.apex_f = planF.apex_base; D.apex_b = planB.apex_base;
     D.apex_split_n = apex ? planF.split_n : 0; D.apex_split_slot = planF.split_slot0; D.apex_split_lane = planF.split_row - D.apex_n0;
-    if (D.apex_split_n > 0 && (tile || scalar_npad(NV) != ((NV + 1 + 15) & ~15) || planF.split_slot0 + planF.split_n > scalar_npad(NV))) { delete h; return fail(EICOS_E_INVALID, "internal: the split row of the apex does not fit the spare slots of the sweep vector"); }
+    // (the parts' pseudo-rows N + 1 ... use the spare slots of the sweep vector: checked here against the plan's own bound and below, where the
+    // vector's stride D.Npad is fixed, against that stride itself)
+    if (D.apex_split_n > 0 && (tile || planF.split_slot0 + planF.split_n > scalar_npad(NV))) { delete h; return fail(EICOS_E_INVALID, "internal: the split row of the apex does not fit the spare slots of the sweep vector"); }
     h->posB = planB.pos; h->ub_len = planB.ulen;
     // numeric factorisation program: reads L.*D through the backward (column) slots; slot nUB is the zero dummy
     FactorPlan planX;
@@ -655,6 +676,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     // launch shape: env overrides are for experiments (bench sweeps); defaults chosen from measurements
     // KKT-space vectors (solve vector, current solution, refinement residual) live in LDS when they fit:
     // 160 KiB per CU minus the static block (reductions + scalar state)
+    if (D.apex_split_n > 0 && D.apex_split_slot + D.apex_split_n > Npad_v) { delete h; return fail(EICOS_E_INVALID, "internal: the split row of the apex runs past the sweep vector's stride"); }
     D.Npad = Npad_v; // tile ? NV + 16 : (NV + 1 + 15) & ~15 // >= N+1: slot N is the always-zero target of ELL padding (tile mode: a whole zero block)
     {
         D.lm_f = 0; D.lm_b = D.lm_f + D.nfs + D.nfs_solo + D.nfs_ext; D.lm_cag = D.lm_b + D.nbs + D.nbs_solo; D.lm_rA = D.lm_cag + D.cag_ns; D.lm_rG = D.lm_rA + D.rA_ns;
@@ -1358,6 +1380,7 @@ int eicos_batch_dims(eicos_batch *h, eicos_dims *o) {
     o->pattern_bytes = h->pattern_ints * sizeof(int);
     o->threads_per_block = h->threads; o->resident_blocks = h->grid; o->lds_bytes = (int)h->dyn_lds; o->instances_per_block = 1;
     o->lds_resident = h->ldsres; o->factor_path = h->sym.tile; o->cone_order = h->sym.cone_order; o->dual_rhs = h->dp.dual;
+    o->arithmetic_profile = h->arith_profile; o->apex_nodes = h->dp.apex_na; o->solo_slices = h->dp.nfs_solo + h->dp.nbs_solo;
     return EICOS_OK;
 }
 

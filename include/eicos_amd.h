@@ -74,7 +74,20 @@ typedef struct eicos_dims {
     int cone_order;   /* 1: the two expansion columns of every second-order cone are eliminated after the cone's own rows (the
                        * numerically preferable order, csrc/symbolic.cpp); 0: unconstrained minimum degree (or no cones) */
     int dual_rhs;     /* 1: the two independent KKT systems of the initialisation and of every pass are solved in one sweep */
+    /* the arithmetic path of this handle (what decides the rounding of a result besides the data): the profile it was created under
+     * (eicos_set_arithmetic_profile), the nodes of the dense apex (0 = none: level schedule to the root) and the slices of the
+     * single-wavefront part of the two sweep plans (0 = no split); two handles on one pattern with equal threads_per_block, factor_path,
+     * apex_nodes and solo_slices give bit-identical results for equal data */
+    int arithmetic_profile, apex_nodes, solo_slices;
 } eicos_dims;
+
+/* Process-wide choice of how a handle's PLANS are shaped, read by eicos_batch_create / eicos_multi_create (no reference counterpart: the
+ * reference has one code path).  0 (default): by the launch -- workgroup size, dense apex and the single-wavefront tree top follow the
+ * batch size, so the last bits of an instance's result can depend on the batch (or shard) it is solved in.  1: by the pattern alone, as
+ * for a batch beyond one workgroup per CU -- an instance gives the same bits in a batch of 1, of 4096 and in any shard of an eicos_multi
+ * (at the price of the small-batch plan choices: a few percent below profile 0 there).  Returns EICOS_OK or EICOS_E_INVALID. */
+int eicos_set_arithmetic_profile(int profile);
+int eicos_get_arithmetic_profile(void);
 
 /* ---- construction: replaces Solver::Solver(n,m,p,l,ncones,q,Gpr,Gjc,Gir,Apr,Ajc,Air,c,h,b)
  * (reference include/eicos.hpp:151-154, src/eicos.cpp:91-120) + build() (:132-187), for a
@@ -204,7 +217,11 @@ int eicos_multi_update(eicos_multi *mh, int first, int count, const double *Gpr,
                        const double *c, const double *h, const double *b);
 /* updateData from arrays resident in the HBM of ONE GPU (src_device): shards on that GPU read them in place; the others read their rows
  * in place as well, over xGMI (peer access is enabled between the listed devices at creation), or -- without peer access -- pull them with
- * staged hipMemcpyPeerAsync copies on their own streams: the "batch scatter" of north_star without a collective */
+ * staged hipMemcpyPeerAsync copies on their own streams: the "batch scatter" of north_star without a collective.
+ * ASYNCHRONOUS, like eicos_batch_update_device: the call returns with the updateData kernels enqueued on the shards' streams, and those
+ * kernels read the source buffers IN PLACE (on src_device itself and, with peer access, from the other GPUs).  The source buffers must stay
+ * valid and unmodified until eicos_multi_sync (or a solve / result call, which synchronise) has returned; work that PRODUCES them on
+ * src_device must have completed before the call (the shards' streams are not ordered against the producer's stream). */
 int eicos_multi_update_device(eicos_multi *mh, int src_device, int first, int count, const double *dGpr, const double *dApr,
                               const double *dc, const double *dh, const double *db);
 /* solve: async = enqueue every shard's kernels on its stream and return; sync waits for all; eicos_multi_solve = both (+ exit codes, may be NULL) */

@@ -258,10 +258,10 @@ def test_stage_functions_save_no_callee_saved_registers(tmp_path):
             m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
             if m and name and "k_solve" in name:
                 seen[name] = int(m.group(1))
-    assert len(seen) >= 20, seen  # five builds of kernels.hip (per workgroup size, LDS-resident, two waves per SIMD)
+    assert len(seen) >= 28, seen  # seven builds of kernels.hip (per workgroup size, LDS-resident, two waves per SIMD, U in LDS x 2)
     # measured with the saves: 816 (256-VGPR build of the 256-thread kernel), 528-560 (168-VGPR build), 912 (512 threads), 704 (LDS-resident)
     for name, size in seen.items():
-        limit = 600 if ("w2" in name or "ldsres" in name or "ILi512E" in name) else 450
+        limit = 600 if ("w2" in name or "ldsres" in name or "ubl" in name or "ILi512E" in name) else 450  # (256-VGPR builds / 512 threads; else the 168-VGPR build)
         assert size <= limit, (name, size)
 
 

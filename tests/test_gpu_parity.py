@@ -1264,6 +1264,34 @@ def test_partly_pinned_extents_take_the_bounce_path_and_reregistering_larger_is_
     g.close()
 
 
+def test_arithmetic_profile_one_gives_batch_independent_bits():
+    # the plans of a handle (workgroup size, dense apex, single-wavefront tree top) follow the batch size, so the last bits of an
+    # instance's result depend on the batch / shard it is solved in.  eicos_set_arithmetic_profile(1) shapes the plans by the pattern alone:
+    # the same instances give the same bits alone, inside a batch of 300 (one workgroup per CU), of 700 and of 1100 (two per CU, queue)
+    pat, sets = load_fixture("MPC02")
+    d = feasible_batch(pat, sets[0], 0, 1100)
+    keys = ("Gpr", "Apr", "c", "h", "b")
+    try:
+        eicos_amd.set_arithmetic_profile(1)
+        ref = None
+        for B in (6, 300, 700, 1100):
+            g = eicos_amd.BatchSolver(pat, B)
+            dm = g.dims()
+            assert dm["arithmetic_profile"] == 1 and dm["apex_nodes"] == 0 and dm["threads_per_block"] == 256
+            g.update(*[d[k][:B] for k in keys])
+            codes = g.solve(); ia = g.info_arrays()
+            out = (codes[:6], ia["iter"][:6], ia["pcost"][:6], g.solution()[:6], g.duals()[1][:6])
+            g.close()
+            if ref is None:
+                ref = out
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b), B
+    finally:
+        eicos_amd.set_arithmetic_profile(0)
+    g = eicos_amd.BatchSolver(pat, 6); dm = g.dims(); g.close()
+    assert dm["arithmetic_profile"] == 0
+
+
 def test_launch_durations_are_kept_in_a_ring_of_events():
     # eicos_batch_ms_history: K steps enqueued back to back, every launch's duration read afterwards (bench.py's timed loop has no host
     # synchronisation inside); the ring holds 64, oldest first; "step" = updateData start -> solve end >= update + solve
