@@ -88,6 +88,9 @@ def _lib():
         L.eicos_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_last_update_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.eicos_batch_destroy.argtypes = [vp]
+        if hasattr(L, "eicos_batch_update_solve"):  # (round 6)
+            L.eicos_batch_update_solve.argtypes = [vp, dp, dp, dp, dp, dp, dp, ip]
+            L.eicos_batch_update_solve.restype = C.c_int
         if hasattr(L, "eicos_batch_ms_history"):  # (round 6; absent from a previous round's library)
             L.eicos_batch_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
             L.eicos_batch_ms_history.restype = C.c_int
@@ -198,7 +201,7 @@ def host_unregister(a):
     _chk(_lib().eicos_host_unregister(C.c_void_p(a.ctypes.data)))
 
 
-UPDATE_PATHS = {0: "none", 1: "pinned bounce", 2: "pinned source in place", 3: "peer GPU in place", 4: "staged peer copies"}
+UPDATE_PATHS = {0: "none", 1: "pinned bounce", 2: "pinned source in place", 3: "peer GPU in place", 4: "staged peer copies", 5: "fused into the solve"}
 
 
 class BatchSolver:
@@ -235,6 +238,22 @@ class BatchSolver:
         # zero-width groups are passed as NULL-safe dummies
         ptr = [(_dp(a) if (a is not None and a.size) else (_dp(np.zeros(1)) if a is not None else None)) for a in arrs]
         _chk(_lib().eicos_batch_update(self._h, first, count, *ptr))
+
+    def update_solve(self, Gpr=None, Apr=None, c=None, h=None, b=None, x_out=None):
+        """updateData + solve in one call (eicos_batch_update_solve): host arrays shaped [batch, ...] (None keeps the group).  With pinned /
+        registered arrays the solve kernel pulls every instance's inputs itself (no separate updateData launch) and writes x into a pinned
+        `x_out`.  Returns the exit codes."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (Gpr, Apr, c, h, b)]
+        pat = self.pat
+        for a, w in zip(arrs, (pat.nnzG, pat.nnzA, pat.n, pat.m, pat.p)):
+            if a is not None and a.size != self.batch * w:
+                raise ValueError(f"array has {a.size} elements, expected {self.batch}x{w}")
+        ptr = [(_dp(a) if (a is not None and a.size) else (_dp(np.zeros(1)) if a is not None else None)) for a in arrs]
+        if x_out is not None:
+            assert x_out.dtype == np.float64 and x_out.flags.c_contiguous and x_out.shape == (self.batch, pat.n)
+        codes = np.zeros(self.batch, np.int32)
+        _chk(_lib().eicos_batch_update_solve(self._h, *ptr, _dp(x_out) if (x_out is not None and x_out.size) else None, _ip(codes)))
+        return codes
 
     def update_device(self, dG=0, dA=0, dc=0, dh=0, db=0, first: int = 0, count: int | None = None):
         """Raw device pointers (ints, e.g. torch.Tensor.data_ptr()); 0 keeps the group."""

@@ -94,7 +94,7 @@ struct eicos_batch {
     // while the host copies chunk k out.  pin_ev[i]: the last GPU work that touches pin[i].
     double *pin[2] = {nullptr, nullptr}; size_t pin_doubles = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_busy[2] = {false, false};
-    int last_update_path = 0; // how the most recent host/peer updateData moved its inputs: 1 pinned bounce, 2 zero-copy (pinned source), 3 peer zero-copy, 4 peer staged copies
+    int last_update_path = 0; // how the most recent host/peer updateData moved its inputs: 1 pinned bounce, 2 zero-copy (pinned source), 3 peer zero-copy, 4 peer staged copies, 5 fused into the solve launch
     int *d_flag = nullptr;   // debug hooks
     double warm_shift = 0.; // > 0: warm start (eicos_batch_set_warm_start)
     double dyn_delta = 0., dyn_eps = 0.; // > 0: dynamic regularisation (eicos_batch_set_dynamic_regularization)
@@ -114,6 +114,7 @@ struct eicos_batch {
     int ub_len = 1;        // length of that array (plan slots + dummy, + the dense apex image)
     int bpc = 1, n_cu = 256; // workgroups per CU of the solve launch; CUs of the device
     int arith_profile = 0;   // eicos_set_arithmetic_profile at creation
+    UpdArgs fused{}; bool fused_pending = false; // eicos_batch_update_solve: the arrays the next solve launch pulls in itself
     TilePlan tiles;        // tile mode (Symbolic::tile): the dense-front plan
 };
 
@@ -1245,7 +1246,8 @@ int eicos_batch_solve_async(eicos_batch *h) {
     h->ring_step0[(h->n_solve_rec - 1) % eicos_batch::EV_RING] = h->update_timed ? h->ev_u0 : h->ev_s0;
     HIP_TRY(hipEventRecord(h->ev_s0, h->stream));
     HIP_TRY(solve_build(h->threads, h->ldsres, h->w2, h->ubl).launch(h->pslot, h->d_inst, h->d_work, h->batch, h->d_queue, h->d_queue + 16, h->grid, h->threads, h->nlds,
-                                                             h->dp.idx16, h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream));
+                                                             h->dp.idx16, h->order_min, h->warm_shift, h->dyn_delta, h->dyn_eps, h->dyn_lds, h->stream,
+                                                             h->fused_pending ? &h->fused : nullptr));
     HIP_TRY(hipEventRecord(h->ev_s1, h->stream));
     h->solve_timed = true;
     h->last_ordered = h->batch > h->order_min;
@@ -1321,6 +1323,56 @@ int eicos_batch_solve(eicos_batch *h, int *exitcodes) {
     if (rc != EICOS_OK) return rc;
     rc = eicos_batch_sync(h);
     if (rc != EICOS_OK) return rc;
+    if (exitcodes) {
+        std::vector<eicos_info> info(h->batch);
+        rc = eicos_batch_info(h, info.data());
+        if (rc != EICOS_OK) return rc;
+        for (int i = 0; i < h->batch; i++) exitcodes[i] = info[i].exitcode;
+    }
+    return EICOS_OK;
+}
+
+// updateData + solve in ONE call: the reference's updateData(double *...) followed by solve() (include/eicos.hpp:155-158) for the whole batch.
+// When every given array is memory the GPU addresses directly (pinned / registered host memory, or device memory) the updateData of an
+// instance is run by the solve kernel's own workgroup right before it solves that instance (kernels.hip: update_instance): the transfer over
+// PCIe is the workgroups' loads, spread over the launch and hidden behind the other workgroups' compute -- a separate updateData kernel can
+// only run BEFORE the solve (the registers and the LDS of a CU are fully owned by its resident solve workgroups), so its transfer time adds to
+// every step.  x_out (optional, [batch][n]): pinned host / device memory is written by the kernel as each instance finishes; pageable memory
+// is filled by eicos_batch_solution afterwards.  Anything else (pageable inputs, a handle without an LDS vector, vectors beyond the
+// in-register scaling accumulators) takes eicos_batch_update + eicos_batch_solve: same results, bit for bit, on every path.
+// Synchronous; exitcodes optional.
+int eicos_batch_update_solve(eicos_batch *h, const double *G, const double *A, const double *c, const double *hh, const double *b,
+                             double *x_out, int *exitcodes) {
+    if (!h) return fail(EICOS_E_INVALID, "NULL handle");
+    const DevPat &D = h->dp;
+    if (G && !hh && D.m > 0) return fail(EICOS_E_INVALID, "Gpr given without h");
+    if (A && !b && D.p > 0) return fail(EICOS_E_INVALID, "Apr given without b");
+    HIP_TRY(hipSetDevice(h->device));
+    const double *hv = G ? hh : nullptr, *bv = A ? b : nullptr; // (h is read only with Gpr, b only with Apr: reference src/eicos.cpp:2053-2074)
+    struct Arr { const double *src; size_t w; };
+    const Arr arr[5] = {{G, (size_t)D.nnzG}, {A, (size_t)D.nnzA}, {c, (size_t)D.n}, {hv, (size_t)D.m}, {bv, (size_t)D.p}};
+    auto gpu_addressable = [&](const void *ptr, size_t bytes) { const int k = pointer_kind(ptr); return k == 2 || (k == 1 && is_pinned_host(ptr, bytes)); };
+    bool fused = h->nlds >= 1 && D.n <= 8 * h->threads && D.p <= 8 * h->threads && D.m <= 16 * h->threads && env_knob("EICOS_FUSED_UPDATE", 1, 0, 1);
+    for (const Arr &a : arr) if (a.src && a.w && !gpu_addressable(a.src, (size_t)h->batch * a.w * sizeof(double))) fused = false;
+    const bool x_direct = x_out && D.n > 0 && gpu_addressable(x_out, (size_t)h->batch * D.n * sizeof(double));
+    int rc;
+    if (!fused) {
+        rc = eicos_batch_update(h, 0, h->batch, G, A, c, hh, b);
+        if (rc == EICOS_OK) rc = eicos_batch_solve_async(h);
+    } else {
+        h->last_update_path = 5;
+        rc = begin_update_timing(h); // (an empty updateData interval in the timing ring: the work is inside the solve launch)
+        if (rc != EICOS_OK) return rc;
+        HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true;
+        h->fused = UpdArgs{G, A, c, hv, bv, x_direct ? x_out : nullptr, 1};
+        h->fused_pending = true;
+        rc = eicos_batch_solve_async(h);
+        h->fused_pending = false;
+    }
+    if (rc != EICOS_OK) return rc;
+    rc = eicos_batch_sync(h);
+    if (rc != EICOS_OK) return rc;
+    if (x_out && D.n > 0 && !(fused && x_direct)) { rc = fetch_rows(h, x_out, D.i_x, D.n); if (rc != EICOS_OK) return rc; }
     if (exitcodes) {
         std::vector<eicos_info> info(h->batch);
         rc = eicos_batch_info(h, info.data());

@@ -3029,9 +3029,127 @@ __device__ __forceinline__ void solve_instance(int ps, gdbl_p I, gdbl_p W, doubl
     __syncthreads();
 }
 
+// The same updateData for patterns whose A and G values fit LDS (most: MPC02 needs 76 KB for the values + 48 KB for the
+// row / column maxima): ENTRY-parallel instead of thread-per-column.  The equilibrated working copy of the values and the
+// running maxima stay in LDS across the three sweeps, every pass is unit-stride over the entries, the maxima are integer
+// atomic maxima on the bit patterns of |a| (non-negative doubles order like their bit patterns: exact), and HBM sees
+// each input once plus the outputs.  Same arithmetic in the same order per entry as k_update (rows, then columns;
+// cone rows share the SUM of their row maxima; |a| < 1e-6 -> 1): bit-identical results.
+// LDS: [ xt (n) | at (p) | gt (m) | Av | Gv ] doubles.
+// LDSV = false (values too large for LDS, e.g. the dense-front config: 131 k entries): the same entry-parallel passes with
+// the working copy of the values IN PLACE in the instance slab (it is their destination anyway) and only the maxima in
+// LDS; every pass over the values then streams them from HBM with batched loads (for_t_pre), several workgroups per CU.
+// update_instance = the per-instance body: called by k_update_lds (one launch over a range of instances) and -- the fused path,
+// eicos_batch_update_solve -- by k_solve itself at the start of an instance's solve, the row / column maxima in the then idle sweep vector,
+// so that a batch handed over in (pinned) HOST memory is pulled over PCIe by the solve's own workgroups while other workgroups compute:
+// the registers and the LDS of a CU are fully owned by its resident solve workgroups, no other kernel could run beside them.
+// `q` = row of this instance in the input arrays (NULL = keep that group), I = its slab in HBM.
+typedef double EICOS_GLOBAL *hbm_p; // (global memory in every build: the LDS-resident build's gdbl_p is an LDS pointer)
+template <int T, bool LDSV>
+static __device__ __noinline__ __attribute__((not_tail_called)) void update_instance(int ps, hbm_p I, size_t q, const double *Gpr, const double *Apr, const double *cin,
+                                                                                      const double *hin, const double *bin) {
+    ps = uni(ps); I = uni_ptr(I);
+    const DevPat &P = c_pat[ps];
+    const int n = P.n, p = P.p, m = P.m, l = P.l, nnzA = P.nnzA, nnzG = P.nnzG;
+    double *xt = g_dyn, *at = xt + n, *gt = at + p;
+    unsigned long long *xtb = reinterpret_cast<unsigned long long *>(xt), *atb = reinterpret_cast<unsigned long long *>(at), *gtb = reinterpret_cast<unsigned long long *>(gt);
+    auto sq = [](double a) { return fabs(a) < 1e-6 ? 1. : sqrt(a); };
+    hbm_p Av = I + P.i_Av, Gv = I + P.i_Gv, cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
+    hbm_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
+    DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
+    const bool was_eq = ginfo->equilibrated != 0;
+    auto sA = [&] { if constexpr (LDSV) return gt + m; else return Av; }(); // working copy of the values: LDS, or in place
+    auto sG = [&] { if constexpr (LDSV) return gt + m + nnzA; else return Gv; }();
+    __syncthreads();
+    // un-equilibrate what is kept, overwrite what is given (ref :2053-2074, :389-404) -> working copy of the values
+    for_t_pre<T, 4>(nnzA, [&](int k) {
+        if (Apr) return V3{Apr[(size_t)q * nnzA + k], 1., 1.};
+        return was_eq ? V3{Av[k], ae[P.Air[k]], xe[P.Acol[k]]} : V3{Av[k], 1., 1.};
+    }, [&](int k, const V3 &r) { sA[k] = (Apr || !was_eq) ? r.a : r.a * (r.b * r.c); });
+    for_t_pre<T, 4>(nnzG, [&](int k) {
+        if (Gpr) return V3{Gpr[(size_t)q * nnzG + k], 1., 1.};
+        return was_eq ? V3{Gv[k], ge[P.Gir[k]], xe[P.Gcol[k]]} : V3{Gv[k], 1., 1.};
+    }, [&](int k, const V3 &r) { sG[k] = (Gpr || !was_eq) ? r.a : r.a * (r.b * r.c); });
+    FOR_T(j, n) cv[j] = cin ? cin[(size_t)q * n + j] : (was_eq ? cv[j] * xe[j] : cv[j]);
+    FOR_T(r, p) bv[r] = Apr ? bin[(size_t)q * p + r] : (was_eq ? bv[r] * ae[r] : bv[r]);
+    FOR_T(i, m) hv[i] = Gpr ? hin[(size_t)q * m + i] : (was_eq ? hv[i] * ge[i] : hv[i]);
+    __syncthreads();
+    // the accumulated scalings live in registers of the thread that owns the index (fixed FOR_T mapping); they are
+    // written once at the end.  Up to 8 indices per thread and vector: patterns beyond that take the generic kernel.
+    constexpr int OWN = 8;
+    double xacc[OWN], aacc[OWN], gacc[2 * OWN];
+#pragma unroll
+    for (int u = 0; u < OWN; u++) { xacc[u] = 1.; aacc[u] = 1.; gacc[2 * u] = 1.; gacc[2 * u + 1] = 1.; }
+    for (int it = 0; it < EQUIL_ITERS; it++) {
+        FOR_T(j, n) xtb[j] = 0ull;
+        FOR_T(r, p) atb[r] = 0ull;
+        FOR_T(i, m) gtb[i] = 0ull;
+        __syncthreads();
+        // column maxima over A and G, row maxima of A and of G: one pass over the entries
+        for_t_pre<T, 8>(nnzA, [&](int k) { return IIV{P.Acol[k], P.Air[k], sA[k]}; }, [&](int k, const IIV &r) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(r.a)); atomicMax(&xtb[r.i], b); atomicMax(&atb[r.j], b); });
+        for_t_pre<T, 8>(nnzG, [&](int k) { return IIV{P.Gcol[k], P.Gir[k], sG[k]}; }, [&](int k, const IIV &r) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(r.a)); atomicMax(&xtb[r.i], b); atomicMax(&gtb[r.j], b); });
+        __syncthreads();
+        FOR_T(j, n) xt[j] = sq(xt[j]);
+        FOR_T(r, p) at[r] = sq(at[r]);
+        FOR_T(i, l) gt[i] = sq(gt[i]); // cone rows: sqrt after the per-cone sum (ref :338-350)
+        __syncthreads();
+        FOR_T(c, P.nc) { // cone rows share the SUM of their row maxima
+            const int o = P.cone_off[c], d = P.cq[c];
+            double tot = 0.;
+            for (int k = 0; k < d; k++) tot += gt[o + k];
+            tot = sq(tot);
+            for (int k = 0; k < d; k++) gt[o + k] = tot;
+        }
+        __syncthreads();
+        // rows first, then columns -- same division order as the reference (:353-356)
+        for_t_pre<T, 8>(nnzA, [&](int k) { return IIV{P.Acol[k], P.Air[k], sA[k]}; }, [&](int k, const IIV &r) { sA[k] = (r.a / at[r.j]) / xt[r.i]; });
+        for_t_pre<T, 8>(nnzG, [&](int k) { return IIV{P.Gcol[k], P.Gir[k], sG[k]}; }, [&](int k, const IIV &r) { sG[k] = (r.a / gt[r.j]) / xt[r.i]; });
+#pragma unroll
+        for (int u = 0; u < OWN; u++) { // (compile-time register indices: the accumulators must not go to scratch)
+            const int j = threadIdx.x + u * T;
+            if (j < n) xacc[u] *= xt[j];
+            if (j < p) aacc[u] *= at[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) gacc[u] *= gt[i]; }
+        __syncthreads();
+    }
+    // write back: scalings, scaled c, b, h, the values
+#pragma unroll
+    for (int u = 0; u < OWN; u++) {
+        const int j = threadIdx.x + u * T;
+        if (j < n) { xe[j] = xacc[u]; cv[j] = cv[j] / xacc[u]; }
+        if (j < p) { ae[j] = aacc[u]; bv[j] = bv[j] / aacc[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) { ge[i] = gacc[u]; hv[i] = hv[i] / gacc[u]; } }
+    if constexpr (LDSV) {
+        FOR_T(k, nnzA) Av[k] = sA[k];
+        FOR_T(k, nnzG) Gv[k] = sG[k];
+    } else __syncthreads(); // (in place: the gathers below read entries other threads scaled)
+    // sliced-ELL value copies for the products, straight from the working copy; *_src is relative to Av (G values follow at i_Gv - i_Av)
+    const int grel = P.i_Gv - P.i_Av;
+    auto ell_copy = [&](hbm_p dst, gint_p src, int cnt) {
+        if constexpr (LDSV) for_t_pre<T, 8>(cnt, [&](int k) { return src[k]; }, [&](int k, int e) { dst[k] = e < 0 ? 0. : (e < grel ? sA[e] : sG[e - grel]); });
+        else for_t_pre<T, 8>(cnt, [&](int k) { const int e = src[k]; return IV1{e, Av[max(e, 0)]}; }, [&](int k, const IV1 &r) { dst[k] = r.i < 0 ? 0. : r.a; });
+    };
+    ell_copy(cagv, P.cag_src, P.cag_slots + 1);
+    ell_copy(rAv, P.rA_src, P.rA_slots + 1);
+    ell_copy(rGv, P.rG_src, P.rG_slots + 1);
+    if (P.gt_on) ell_copy(I + P.i_Gt, P.gt_src, P.gt_nt * 256); // G as dense tiles (tile-internal operand order)
+    if (threadIdx.x == 0) { // static-regularisation constants read by the factor program
+        hbm_p cst = I + P.i_cst;
+        cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 1.; // [3]: diagonal of the padding nodes (tile mode)
+        ginfo->equilibrated = 1;
+    }
+    __syncthreads();
+}
+
 template <int T, int NLDS, bool I16>
 __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
-    int ps, double *inst, double *work, int B, int *queue, const int *order, double warm, double dyn_delta, double dyn_eps) {
+    int ps, double *inst, double *work, int B, int *queue, const int *order, double warm, double dyn_delta, double dyn_eps, UpdArgs upd) {
     const DevPat &P = c_pat[ps];
 #if EICOS_LDSRES
     static_assert(NLDS >= 1, "LDS-resident variant: sweep vector + tables in LDS");
@@ -3064,6 +3182,9 @@ __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
     // `order` (batches larger than one instance per CU): instances sorted by the work their previous solve took, longest first.
     for (int g = blockIdx.x; g < B;) {
         const int id = order ? order[g] : g;
+        if constexpr (NLDS >= 1) { // fused updateData (launch.hpp: UpdArgs): the maxima live in the sweep vector, idle between two instances
+            if (upd.on) update_instance<T, false>(ps, (hbm_p)inst + (size_t)id * P.inst_stride, (size_t)id, upd.G, upd.A, upd.c, upd.h, upd.b);
+        }
 #if EICOS_LDSRES
         gdbl_p I = Il;
         {
@@ -3077,6 +3198,7 @@ __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
 #endif
         solve_instance<T, NLDS, I16>(ps, I, W, warm);
         __syncthreads();
+        if (upd.x) for (int j = threadIdx.x; j < P.n; j += T) upd.x[(size_t)id * P.n + j] = I[P.i_x + j]; // (fused path: the result straight to the caller's array)
 #if EICOS_LDSRES
         { // results, persistent per-instance state and (for the debug readbacks) the workspace go back to HBM
             double *Ig = inst + (size_t)id * P.inst_stride;
@@ -3217,119 +3339,14 @@ __global__ __launch_bounds__(T) void k_update(int ps, double *inst, int first, i
     }
 }
 
-// The same updateData for patterns whose A and G values fit LDS (most: MPC02 needs 76 KB for the values + 48 KB for the
-// row / column maxima): ENTRY-parallel instead of thread-per-column.  The equilibrated working copy of the values and the
-// running maxima stay in LDS across the three sweeps, every pass is unit-stride over the entries, the maxima are integer
-// atomic maxima on the bit patterns of |a| (non-negative doubles order like their bit patterns: exact), and HBM sees
-// each input once plus the outputs.  Same arithmetic in the same order per entry as k_update (rows, then columns;
-// cone rows share the SUM of their row maxima; |a| < 1e-6 -> 1): bit-identical results.
-// LDS: [ xt (n) | at (p) | gt (m) | Av | Gv ] doubles.
-// LDSV = false (values too large for LDS, e.g. the dense-front config: 131 k entries): the same entry-parallel passes with
-// the working copy of the values IN PLACE in the instance slab (it is their destination anyway) and only the maxima in
-// LDS; every pass over the values then streams them from HBM with batched loads (for_t_pre), several workgroups per CU.
+// (the entry-parallel updateData: update_instance, above k_solve, which calls it too)
 template <int T, bool LDSV>
 __global__ __launch_bounds__(T) void k_update_lds(int ps, double *inst, int first, int count,
                                                   const double *Gpr, const double *Apr, const double *cin,
                                                   const double *hin, const double *bin) {
     const DevPat &P = c_pat[ps];
-    const int n = P.n, p = P.p, m = P.m, l = P.l, nnzA = P.nnzA, nnzG = P.nnzG;
-    double *xt = g_dyn, *at = xt + n, *gt = at + p;
-    unsigned long long *xtb = reinterpret_cast<unsigned long long *>(xt), *atb = reinterpret_cast<unsigned long long *>(at), *gtb = reinterpret_cast<unsigned long long *>(gt);
-    auto sq = [](double a) { return fabs(a) < 1e-6 ? 1. : sqrt(a); };
-    for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        gdbl_p I = (gdbl_p)inst + (size_t)(first + q) * P.inst_stride;
-        gdbl_p Av = I + P.i_Av, Gv = I + P.i_Gv, cagv = I + P.i_cag, rAv = I + P.i_rA, rGv = I + P.i_rG;
-        gdbl_p cv = I + P.i_c, hv = I + P.i_h, bv = I + P.i_b, xe = I + P.i_xe, ae = I + P.i_ae, ge = I + P.i_ge;
-        DevInfo *ginfo = reinterpret_cast<DevInfo *>(I + P.i_info);
-        const bool was_eq = ginfo->equilibrated != 0;
-        auto sA = [&] { if constexpr (LDSV) return gt + m; else return Av; }(); // working copy of the values: LDS, or in place
-        auto sG = [&] { if constexpr (LDSV) return gt + m + nnzA; else return Gv; }();
-        __syncthreads();
-        // un-equilibrate what is kept, overwrite what is given (ref :2053-2074, :389-404) -> working copy of the values
-        for_t_pre<T, 4>(nnzA, [&](int k) {
-            if (Apr) return V3{Apr[(size_t)q * nnzA + k], 1., 1.};
-            return was_eq ? V3{Av[k], ae[P.Air[k]], xe[P.Acol[k]]} : V3{Av[k], 1., 1.};
-        }, [&](int k, const V3 &r) { sA[k] = (Apr || !was_eq) ? r.a : r.a * (r.b * r.c); });
-        for_t_pre<T, 4>(nnzG, [&](int k) {
-            if (Gpr) return V3{Gpr[(size_t)q * nnzG + k], 1., 1.};
-            return was_eq ? V3{Gv[k], ge[P.Gir[k]], xe[P.Gcol[k]]} : V3{Gv[k], 1., 1.};
-        }, [&](int k, const V3 &r) { sG[k] = (Gpr || !was_eq) ? r.a : r.a * (r.b * r.c); });
-        FOR_T(j, n) cv[j] = cin ? cin[(size_t)q * n + j] : (was_eq ? cv[j] * xe[j] : cv[j]);
-        FOR_T(r, p) bv[r] = Apr ? bin[(size_t)q * p + r] : (was_eq ? bv[r] * ae[r] : bv[r]);
-        FOR_T(i, m) hv[i] = Gpr ? hin[(size_t)q * m + i] : (was_eq ? hv[i] * ge[i] : hv[i]);
-        __syncthreads();
-        // the accumulated scalings live in registers of the thread that owns the index (fixed FOR_T mapping); they are
-        // written once at the end.  Up to 8 indices per thread and vector: patterns beyond that take the generic kernel.
-        constexpr int OWN = 8;
-        double xacc[OWN], aacc[OWN], gacc[2 * OWN];
-#pragma unroll
-        for (int u = 0; u < OWN; u++) { xacc[u] = 1.; aacc[u] = 1.; gacc[2 * u] = 1.; gacc[2 * u + 1] = 1.; }
-        for (int it = 0; it < EQUIL_ITERS; it++) {
-            FOR_T(j, n) xtb[j] = 0ull;
-            FOR_T(r, p) atb[r] = 0ull;
-            FOR_T(i, m) gtb[i] = 0ull;
-            __syncthreads();
-            // column maxima over A and G, row maxima of A and of G: one pass over the entries
-            for_t_pre<T, 8>(nnzA, [&](int k) { return IIV{P.Acol[k], P.Air[k], sA[k]}; }, [&](int k, const IIV &r) {
-                const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(r.a)); atomicMax(&xtb[r.i], b); atomicMax(&atb[r.j], b); });
-            for_t_pre<T, 8>(nnzG, [&](int k) { return IIV{P.Gcol[k], P.Gir[k], sG[k]}; }, [&](int k, const IIV &r) {
-                const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(r.a)); atomicMax(&xtb[r.i], b); atomicMax(&gtb[r.j], b); });
-            __syncthreads();
-            FOR_T(j, n) xt[j] = sq(xt[j]);
-            FOR_T(r, p) at[r] = sq(at[r]);
-            FOR_T(i, l) gt[i] = sq(gt[i]); // cone rows: sqrt after the per-cone sum (ref :338-350)
-            __syncthreads();
-            FOR_T(c, P.nc) { // cone rows share the SUM of their row maxima
-                const int o = P.cone_off[c], d = P.cq[c];
-                double tot = 0.;
-                for (int k = 0; k < d; k++) tot += gt[o + k];
-                tot = sq(tot);
-                for (int k = 0; k < d; k++) gt[o + k] = tot;
-            }
-            __syncthreads();
-            // rows first, then columns -- same division order as the reference (:353-356)
-            for_t_pre<T, 8>(nnzA, [&](int k) { return IIV{P.Acol[k], P.Air[k], sA[k]}; }, [&](int k, const IIV &r) { sA[k] = (r.a / at[r.j]) / xt[r.i]; });
-            for_t_pre<T, 8>(nnzG, [&](int k) { return IIV{P.Gcol[k], P.Gir[k], sG[k]}; }, [&](int k, const IIV &r) { sG[k] = (r.a / gt[r.j]) / xt[r.i]; });
-#pragma unroll
-            for (int u = 0; u < OWN; u++) { // (compile-time register indices: the accumulators must not go to scratch)
-                const int j = threadIdx.x + u * T;
-                if (j < n) xacc[u] *= xt[j];
-                if (j < p) aacc[u] *= at[j];
-            }
-#pragma unroll
-            for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) gacc[u] *= gt[i]; }
-            __syncthreads();
-        }
-        // write back: scalings, scaled c, b, h, the values
-#pragma unroll
-        for (int u = 0; u < OWN; u++) {
-            const int j = threadIdx.x + u * T;
-            if (j < n) { xe[j] = xacc[u]; cv[j] = cv[j] / xacc[u]; }
-            if (j < p) { ae[j] = aacc[u]; bv[j] = bv[j] / aacc[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < 2 * OWN; u++) { const int i = threadIdx.x + u * T; if (i < m) { ge[i] = gacc[u]; hv[i] = hv[i] / gacc[u]; } }
-        if constexpr (LDSV) {
-            FOR_T(k, nnzA) Av[k] = sA[k];
-            FOR_T(k, nnzG) Gv[k] = sG[k];
-        } else __syncthreads(); // (in place: the gathers below read entries other threads scaled)
-        // sliced-ELL value copies for the products, straight from the working copy; *_src is relative to Av (G values follow at i_Gv - i_Av)
-        const int grel = P.i_Gv - P.i_Av;
-        auto ell_copy = [&](gdbl_p dst, gint_p src, int cnt) {
-            if constexpr (LDSV) for_t_pre<T, 8>(cnt, [&](int k) { return src[k]; }, [&](int k, int e) { dst[k] = e < 0 ? 0. : (e < grel ? sA[e] : sG[e - grel]); });
-            else for_t_pre<T, 8>(cnt, [&](int k) { const int e = src[k]; return IV1{e, Av[max(e, 0)]}; }, [&](int k, const IV1 &r) { dst[k] = r.i < 0 ? 0. : r.a; });
-        };
-        ell_copy(cagv, P.cag_src, P.cag_slots + 1);
-        ell_copy(rAv, P.rA_src, P.rA_slots + 1);
-        ell_copy(rGv, P.rG_src, P.rG_slots + 1);
-        if (P.gt_on) ell_copy(I + P.i_Gt, P.gt_src, P.gt_nt * 256); // G as dense tiles (tile-internal operand order)
-        if (threadIdx.x == 0) { // static-regularisation constants read by the factor program
-            gdbl_p cst = I + P.i_cst;
-            cst[0] = DELTASTAT; cst[1] = -DELTASTAT; cst[2] = 0.; cst[3] = 1.; // [3]: diagonal of the padding nodes (tile mode)
-            ginfo->equilibrated = 1;
-        }
-        __syncthreads();
-    }
+    for (int q = blockIdx.x; q < count; q += gridDim.x)
+        update_instance<T, LDSV>(ps, (hbm_p)inst + (size_t)(first + q) * P.inst_stride, (size_t)q, Gpr, Apr, cin, hin, bin);
 }
 
 // Debug: factorise instance `i` with the KKT scaling block as it stands in memory (runs the solver's own stage).
@@ -3416,7 +3433,9 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
 }
 #endif
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
-                        int idx16, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st) {
+                        int idx16, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd_in) {
+    UpdArgs upd = upd_in ? *upd_in : UpdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (upd.on && nlds < 1) return hipErrorInvalidValue; // (the fused updateData keeps its maxima in the LDS sweep vector)
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // group queue of this launch
     if (e != hipSuccess) return e;
@@ -3433,7 +3452,7 @@ hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, i
     }
     return dispatch_solve(threads, nlds, idx16, [&](const void *fn) {
         void *args[] = {(void *)&ps, (void *)&inst, (void *)&work, (void *)&B, (void *)&queue, (void *)&order, (void *)&warm, (void *)&dyn_delta,
-                        (void *)&dyn_eps};
+                        (void *)&dyn_eps, (void *)&upd};
         return hipLaunchKernel(fn, dim3(grid), dim3(threads), args, dyn_lds, st);
     });
 }

@@ -4,8 +4,12 @@
 #include "device_types.hpp"
 
 namespace eicos {
+// Fused updateData (eicos_batch_update_solve): when `on`, every workgroup of the solve kernel first runs updateData for the instance it is
+// about to solve, reading row `instance` of these [batch][...] arrays (NULL = keep the group; device or pinned host memory), and -- x != NULL
+// -- writes the instance's solution to row `instance` of x [batch][n] when it is done.
+struct UpdArgs { const double *G, *A, *c, *h, *b; double *x; int on; };
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,
                          const double *c, const double *h, const double *b, double *scratch, int grid, size_t lds_bytes, int vals_in_lds, hipStream_t st);
 hipError_t update_set_max_lds();
@@ -18,7 +22,7 @@ int max_patterns();
 // LDS-resident variant of k_solve (kernels_ldsres.hip = kernels.hip compiled with EICOS_LDSRES): same arguments
 namespace ldsres {
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
@@ -26,7 +30,7 @@ hipError_t upload_pattern(int ps, const DevPat &P);
 // 256-thread k_solve with the register budget of two waves per SIMD (kernels_w2.hip = kernels.hip compiled with EICOS_W2)
 namespace w2 {
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
@@ -35,14 +39,14 @@ hipError_t upload_pattern(int ps, const DevPat &P);
 // compiled with EICOS_TSPLIT): the default namespace keeps the 256-thread one
 namespace t128 {
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
 } // namespace t128
 namespace t512 {
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
@@ -51,14 +55,14 @@ hipError_t upload_pattern(int ps, const DevPat &P);
 // with EICOS_UBL): launches of one workgroup per CU whose U fits the idle LDS
 namespace ubl256 {
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);
 } // namespace ubl256
 namespace ubl512 {
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
-                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st);
+                        int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t solve_occupancy(int threads, int nlds, int idx16, size_t dyn_lds, int *blocks_per_cu);
 hipError_t solve_set_max_lds(int threads, int nlds, int idx16, size_t dyn_lds);
 hipError_t upload_pattern(int ps, const DevPat &P);

@@ -123,6 +123,15 @@ int eicos_host_free(void *p);
 int eicos_host_register(void *p, size_t bytes);
 int eicos_host_unregister(void *p);
 int eicos_batch_last_update_path(eicos_batch *hd);
+/* updateData + solve in ONE synchronous call for the whole batch: replaces Solver::updateData(double *...) followed by Solver::solve()
+ * (reference include/eicos.hpp:155-158, src/eicos.cpp:2053-2082 + :848).  Same array conventions as eicos_batch_update (NULL = keep the group).
+ * When every given array is memory the GPU addresses directly -- eicos_host_alloc / eicos_host_register memory, or device memory -- each
+ * workgroup of the solve kernel runs updateData for the instance it is about to solve: the PCIe transfer is spread over the launch behind
+ * the other workgroups' compute instead of preceding it (path 5 of eicos_batch_last_update_path).  x_out: optional [batch][n] result array
+ * (pinned host / device memory is written by the kernel as instances finish).  Otherwise it is eicos_batch_update + eicos_batch_solve
+ * (+ eicos_batch_solution).  Results are bit-identical on every path.  exitcodes: optional [batch]. */
+int eicos_batch_update_solve(eicos_batch *hd, const double *Gpr, const double *Apr, const double *c, const double *h, const double *b,
+                             double *x_out, int *exitcodes);
 /* Same, DEVICE pointers (inputs already resident in HBM; no PCIe traffic). */
 int eicos_batch_update_device(eicos_batch *hd, int first, int count,
                               const double *dGpr, const double *dApr,

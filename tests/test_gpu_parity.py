@@ -1292,6 +1292,48 @@ def test_arithmetic_profile_one_gives_batch_independent_bits():
     assert dm["arithmetic_profile"] == 0
 
 
+@pytest.mark.parametrize("name,B", [("MPC02", 600), ("lp_afiro", 300), ("lp_bandm", 64), ("update_data", 40), ("MPC02", 40)])
+def test_fused_update_solve_is_bit_identical_to_update_then_solve(name, B):
+    # eicos_batch_update_solve: with pinned / registered host arrays the solve kernel's workgroups run updateData for the
+    # instance they are about to solve (the PCIe transfer hides behind the other workgroups' compute) and write x straight into a pinned
+    # result array; pageable arrays take update + solve.  Same bits on every path, also with kept groups and after a previous solve
+    # (the un-equilibration of kept groups), in the LDS-resident, U-in-LDS, two-per-CU queue and dual-solve launch shapes.
+    pat, sets = load_fixture(name)
+    if name.startswith("lp_"):
+        d = perturbed_batch(pat, sets[0], 0, B)
+    elif name == "MPC02":
+        d = feasible_batch(pat, sets[0], 0, B)
+    else:
+        d = dict(zip(("Gpr", "Apr", "c", "h", "b"), rep(sets[0], B)))
+    keys = ("Gpr", "Apr", "c", "h", "b")
+    g = eicos_amd.BatchSolver(pat, B)
+    g.update(*[d[k] for k in keys]); codes0 = g.solve(); x0 = g.solution(); ia0 = g.info_arrays(); y0, z0, s0 = g.duals()
+    # a second data set (c, h changed; G, A, b kept) through the classic calls
+    c2 = d["c"] * 1.01
+    g.update(None, None, c2, None, None); codes1 = g.solve(); x1 = g.solution()
+    g.close()
+    pins = {k: eicos_amd.PinnedArray(d[k].shape) for k in keys}
+    for k in keys:
+        pins[k].a[...] = d[k]
+    px = eicos_amd.PinnedArray((B, pat.n))
+    g = eicos_amd.BatchSolver(pat, B)
+    codes = g.update_solve(*[pins[k].a for k in keys], x_out=px.a)
+    assert g.last_update_path() == "fused into the solve"
+    ia = g.info_arrays(); y, z, s_ = g.duals()
+    assert np.array_equal(codes, codes0) and np.array_equal(px.a, x0) and np.array_equal(g.solution(), x0) and np.array_equal(ia["iter"], ia0["iter"])
+    assert np.array_equal(y, y0) and np.array_equal(z, z0) and np.array_equal(s_, s0) and np.array_equal(ia["pcost"], ia0["pcost"])
+    pc = eicos_amd.PinnedArray((B, pat.n)); pc.a[...] = c2
+    xb = np.zeros((B, pat.n))  # (pageable result array: fetched after the launch)
+    assert np.array_equal(g.update_solve(None, None, pc.a, None, None, x_out=xb), codes1) and np.array_equal(xb, x1)
+    assert g.last_update_path() == "fused into the solve"
+    # pageable inputs: the classic path inside the same call
+    assert np.array_equal(g.update_solve(*[d[k] for k in keys], x_out=px.a), codes0) and np.array_equal(px.a, x0)
+    assert g.last_update_path() == "pinned bounce"
+    g.close()
+    for pa in list(pins.values()) + [px, pc]:
+        pa.close()
+
+
 def test_launch_durations_are_kept_in_a_ring_of_events():
     # eicos_batch_ms_history: K steps enqueued back to back, every launch's duration read afterwards (bench.py's timed loop has no host
     # synchronisation inside); the ring holds 64, oldest first; "step" = updateData start -> solve end >= update + solve
