@@ -123,6 +123,9 @@ def _lib():
         L.eicos_multi_create.argtypes = [C.c_int] * 5 + [ip] * 5 + [C.c_int, ip, C.c_int, C.POINTER(vp)]
         L.eicos_multi_update.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
         L.eicos_multi_update_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        if hasattr(L, "eicos_multi_update_solve"):
+            L.eicos_multi_update_solve.argtypes = [vp, dp, dp, dp, dp, dp, dp, ip]
+            L.eicos_multi_update_solve.restype = C.c_int
         L.eicos_multi_solve.argtypes = [vp, ip]
         L.eicos_multi_solve_async.argtypes = [vp]
         L.eicos_multi_sync.argtypes = [vp]
@@ -201,7 +204,7 @@ def host_unregister(a):
     _chk(_lib().eicos_host_unregister(C.c_void_p(a.ctypes.data)))
 
 
-UPDATE_PATHS = {0: "none", 1: "pinned bounce", 2: "pinned source in place", 3: "peer GPU in place", 4: "staged peer copies", 5: "fused into the solve"}
+UPDATE_PATHS = {0: "none", 1: "pinned bounce", 2: "pinned source in place", 3: "peer GPU in place", 4: "staged peer copies", 5: "fused into the solve", 6: "fused into the solve, staged while it runs"}
 
 
 class BatchSolver:

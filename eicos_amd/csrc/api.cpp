@@ -115,6 +115,9 @@ struct eicos_batch {
     int bpc = 1, n_cu = 256; // workgroups per CU of the solve launch; CUs of the device
     int arith_profile = 0;   // eicos_set_arithmetic_profile at creation
     UpdArgs fused{}; bool fused_pending = false; // eicos_batch_update_solve: the arrays the next solve launch pulls in itself
+    // ... from pageable host memory: one pinned staging buffer for the whole batch (+ one ready flag per chunk), filled while the kernel runs
+    double *stage_pin = nullptr; size_t stage_pin_doubles = 0; unsigned *stage_flags = nullptr; int stage_nflags = 0; unsigned stage_seq = 0;
+    int *d_err = nullptr;
     TilePlan tiles;        // tile mode (Symbolic::tile): the dense-front plan
 };
 
@@ -894,6 +897,9 @@ int eicos_batch_destroy(eicos_batch *h) {
                       (void *)h->d_stage, (void *)h->d_flag})
         if (ptr) (void)hipFree(ptr);
     for (int i = 0; i < 2; i++) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
+    if (h->stage_pin) (void)hipHostFree(h->stage_pin);
+    if (h->stage_flags) (void)hipHostFree(h->stage_flags);
+    if (h->d_err) (void)hipFree(h->d_err);
     // the constant-memory descriptor slot is handed out again only after nothing can read it any more
     if (h->pslot >= 0) { std::lock_guard<std::mutex> lk(g_slot_mu); g_slot_used[h->device][h->pslot] = 0; }
     delete h;
@@ -1352,27 +1358,81 @@ int eicos_batch_update_solve(eicos_batch *h, const double *G, const double *A, c
     struct Arr { const double *src; size_t w; };
     const Arr arr[5] = {{G, (size_t)D.nnzG}, {A, (size_t)D.nnzA}, {c, (size_t)D.n}, {hv, (size_t)D.m}, {bv, (size_t)D.p}};
     auto gpu_addressable = [&](const void *ptr, size_t bytes) { const int k = pointer_kind(ptr); return k == 2 || (k == 1 && is_pinned_host(ptr, bytes)); };
-    bool fused = h->nlds >= 1 && D.n <= 8 * h->threads && D.p <= 8 * h->threads && D.m <= 16 * h->threads && env_knob("EICOS_FUSED_UPDATE", 1, 0, 1);
-    for (const Arr &a : arr) if (a.src && a.w && !gpu_addressable(a.src, (size_t)h->batch * a.w * sizeof(double))) fused = false;
+    const bool fused = h->nlds >= 1 && D.n <= 8 * h->threads && D.p <= 8 * h->threads && D.m <= 16 * h->threads && env_knob("EICOS_FUSED_UPDATE", 1, 0, 1);
+    // arrays the GPU cannot address (pageable memory) are STAGED: copied into the handle's pinned staging buffer while the kernel runs
+    bool staged[5] = {false, false, false, false, false};
+    size_t stage_need = 0;
+    for (int k = 0; k < 5; k++) if (arr[k].src && arr[k].w && !gpu_addressable(arr[k].src, (size_t)h->batch * arr[k].w * sizeof(double))) {
+        if (pointer_kind(arr[k].src) == 2) return fail(EICOS_E_INVALID, "an array straddles device memory");
+        staged[k] = true; stage_need += (size_t)h->batch * arr[k].w + 8;
+    }
+    const bool any_staged = stage_need > 0;
     const bool x_direct = x_out && D.n > 0 && gpu_addressable(x_out, (size_t)h->batch * D.n * sizeof(double));
     int rc;
-    if (!fused) {
-        rc = eicos_batch_update(h, 0, h->batch, G, A, c, hh, b);
+    if (!fused || (any_staged && !env_knob("EICOS_FUSED_STAGED", 1, 0, 1))) {
+        bool all_device = true; // (device arrays on a handle without the fused path: the device-pointer updateData)
+        for (int k = 0; k < 5; k++) if (arr[k].src && arr[k].w && pointer_kind(arr[k].src) != 2) all_device = false;
+        rc = all_device ? eicos_batch_update_device(h, 0, h->batch, G, A, c, hh, b) : eicos_batch_update(h, 0, h->batch, G, A, c, hh, b);
         if (rc == EICOS_OK) rc = eicos_batch_solve_async(h);
+        if (rc != EICOS_OK) return rc;
+        rc = eicos_batch_sync(h);
+        if (rc != EICOS_OK) return rc;
+        if (x_out && D.n > 0) { rc = fetch_rows(h, x_out, D.i_x, D.n); if (rc != EICOS_OK) return rc; }
     } else {
-        h->last_update_path = 5;
+        const double *ptr[5] = {G, A, c, hv, bv};
+        // chunks of ~12 MB over the staged arrays: the copy pool splits an array's share of a chunk into pieces of >= 1 MB over its threads, so
+        // a chunk must be large enough to keep them busy and small enough that the first workgroups start after a fraction of the whole copy
+        size_t per = 0;
+        for (int k = 0; k < 5; k++) if (staged[k]) per += arr[k].w;
+        const int chunk = any_staged ? (int)std::max<size_t>(8, std::min<size_t>((size_t)h->batch, (12u << 20) / std::max<size_t>(per * sizeof(double), 1))) : h->batch;
+        const int nchunks = (h->batch + chunk - 1) / chunk;
+        if (any_staged) {
+            if (stage_need > h->stage_pin_doubles) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                if (h->stage_pin) { (void)hipHostFree(h->stage_pin); h->stage_pin = nullptr; h->stage_pin_doubles = 0; }
+                HIP_TRY(hipHostMalloc((void **)&h->stage_pin, stage_need * sizeof(double), hipHostMallocDefault));
+                h->stage_pin_doubles = stage_need;
+            }
+            if (nchunks > h->stage_nflags) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                if (h->stage_flags) { (void)hipHostFree(h->stage_flags); h->stage_flags = nullptr; h->stage_nflags = 0; }
+                HIP_TRY(hipHostMalloc((void **)&h->stage_flags, (size_t)nchunks * sizeof(unsigned), hipHostMallocDefault));
+                std::memset(h->stage_flags, 0, (size_t)nchunks * sizeof(unsigned));
+                h->stage_nflags = nchunks; h->stage_seq = 0;
+            }
+            if (!h->d_err) { HIP_TRY(hipMalloc((void **)&h->d_err, sizeof(int))); HIP_TRY(hipMemset(h->d_err, 0, sizeof(int))); }
+            double *at = h->stage_pin;
+            for (int k = 0; k < 5; k++) if (staged[k]) { ptr[k] = at; at += (size_t)h->batch * arr[k].w + 8; }
+            h->stage_seq++;
+            if (h->stage_seq == 0) { std::memset(h->stage_flags, 0, (size_t)h->stage_nflags * sizeof(unsigned)); h->stage_seq = 1; } // (wrapped)
+        }
+        h->last_update_path = any_staged ? 6 : 5;
         rc = begin_update_timing(h); // (an empty updateData interval in the timing ring: the work is inside the solve launch)
         if (rc != EICOS_OK) return rc;
         HIP_TRY(hipEventRecord(h->ev_u1, h->stream)); h->update_timed = true;
-        h->fused = UpdArgs{G, A, c, hv, bv, x_direct ? x_out : nullptr, 1};
+        h->fused = UpdArgs{ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], x_direct ? x_out : nullptr, 1,
+                           any_staged ? h->stage_flags : nullptr, chunk, h->stage_seq, h->d_err};
         h->fused_pending = true;
         rc = eicos_batch_solve_async(h);
         h->fused_pending = false;
+        if (rc != EICOS_OK) return rc; // (nothing was launched: no workgroup waits for a flag)
+        if (any_staged) { // the kernel is running: copy chunk by chunk and release each chunk's flag behind its rows
+            CopyPool &pool = CopyPool::get();
+            for (int q = 0; q < nchunks; q++) {
+                const size_t r0 = (size_t)q * chunk, rows = std::min<size_t>((size_t)chunk, (size_t)h->batch - r0);
+                for (int k = 0; k < 5; k++) if (staged[k]) pool.copy(const_cast<double *>(ptr[k]) + r0 * arr[k].w, arr[k].src + r0 * arr[k].w, rows * arr[k].w * sizeof(double));
+                __atomic_store_n(&h->stage_flags[q], h->stage_seq, __ATOMIC_RELEASE); // (stream_copy ends with an sfence: the rows are visible before the flag)
+            }
+        }
+        rc = eicos_batch_sync(h);
+        if (rc != EICOS_OK) return rc;
+        if (any_staged) {
+            int err = 0;
+            HIP_TRY(hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
+            if (err) { HIP_TRY(hipMemset(h->d_err, 0, sizeof(int))); return fail(EICOS_E_HIP, "fused updateData: a workgroup timed out waiting for its staged rows"); }
+        }
+        if (x_out && D.n > 0 && !x_direct) { rc = fetch_rows(h, x_out, D.i_x, D.n); if (rc != EICOS_OK) return rc; }
     }
-    if (rc != EICOS_OK) return rc;
-    rc = eicos_batch_sync(h);
-    if (rc != EICOS_OK) return rc;
-    if (x_out && D.n > 0 && !(fused && x_direct)) { rc = fetch_rows(h, x_out, D.i_x, D.n); if (rc != EICOS_OK) return rc; }
     if (exitcodes) {
         std::vector<eicos_info> info(h->batch);
         rc = eicos_batch_info(h, info.data());

@@ -3183,7 +3183,21 @@ __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
     for (int g = blockIdx.x; g < B;) {
         const int id = order ? order[g] : g;
         if constexpr (NLDS >= 1) { // fused updateData (launch.hpp: UpdArgs): the maxima live in the sweep vector, idle between two instances
-            if (upd.on) update_instance<T, false>(ps, (hbm_p)inst + (size_t)id * P.inst_stride, (size_t)id, upd.G, upd.A, upd.c, upd.h, upd.b);
+            if (upd.on) {
+                if (upd.flags) { // staged host arrays: the host is still copying -- wait for the chunk that holds this instance (launch.hpp: UpdArgs)
+                    if (threadIdx.x == 0) {
+                        const unsigned *f = upd.flags + id / upd.chunk;
+                        const unsigned long long t0 = wall_clock64();
+                        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != upd.seq) {
+                            __builtin_amdgcn_s_sleep(127);
+                            if (wall_clock64() - t0 > 500000000ull) { atomicExch(upd.err, 1); break; } // (5 s of the 100 MHz clock: the host died or lost the plot)
+                        }
+                    }
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // (system scope: the rows this workgroup reads next were written by the host)
+                }
+                update_instance<T, false>(ps, (hbm_p)inst + (size_t)id * P.inst_stride, (size_t)id, upd.G, upd.A, upd.c, upd.h, upd.b);
+            }
         }
 #if EICOS_LDSRES
         gdbl_p I = Il;
@@ -3434,7 +3448,7 @@ template <class F> static auto dispatch_solve(int threads, int nlds, int idx16, 
 #endif
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds,
                         int idx16, int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd_in) {
-    UpdArgs upd = upd_in ? *upd_in : UpdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    UpdArgs upd = upd_in ? *upd_in : UpdArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, 0u, nullptr};
     if (upd.on && nlds < 1) return hipErrorInvalidValue; // (the fused updateData keeps its maxima in the LDS sweep vector)
     if (B <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st); // group queue of this launch

@@ -7,7 +7,10 @@ namespace eicos {
 // Fused updateData (eicos_batch_update_solve): when `on`, every workgroup of the solve kernel first runs updateData for the instance it is
 // about to solve, reading row `instance` of these [batch][...] arrays (NULL = keep the group; device or pinned host memory), and -- x != NULL
 // -- writes the instance's solution to row `instance` of x [batch][n] when it is done.
-struct UpdArgs { const double *G, *A, *c, *h, *b; double *x; int on; };
+// STAGED host arrays (pageable memory): the arrays are the handle's pinned staging buffer, which the host fills chunk by chunk WHILE the
+// kernel runs -- flags[instance / chunk] == seq once the chunk holding an instance has been copied (pinned, host-written); the workgroup polls
+// it before it touches the instance's rows (bounded: after ~5 s it gives up and raises *err).
+struct UpdArgs { const double *G, *A, *c, *h, *b; double *x; int on; const unsigned *flags; int chunk; unsigned seq; int *err; };
 hipError_t launch_solve(int ps, double *inst, double *work, int B, int *queue, int *order, int grid, int threads, int nlds, int idx16,
                         int order_min, double warm, double dyn_delta, double dyn_eps, size_t dyn_lds, hipStream_t st, const UpdArgs *upd = nullptr);
 hipError_t launch_update(int ps, double *inst, int first, int count, const double *Gpr, const double *Apr,

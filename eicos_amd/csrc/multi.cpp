@@ -224,6 +224,17 @@ int eicos_multi_solve(eicos_multi *mh, int *exitcodes) {
     return EICOS_OK;
 }
 
+// updateData + solve in one call over every shard (eicos_batch_update_solve per shard on its rows, the shards concurrently)
+int eicos_multi_update_solve(eicos_multi *mh, const double *G, const double *A, const double *c, const double *hh, const double *b,
+                             double *x_out, int *exitcodes) {
+    if (!mh) return mfail(EICOS_E_INVALID, "NULL handle");
+    return for_shards(mh, [&](int s) {
+        const size_t r = (size_t)mh->first[s];
+        return eicos_batch_update_solve(mh->shard[s], at(G, r, mh->nnzG), at(A, r, mh->nnzA), at(c, r, mh->n), at(hh, r, mh->m), at(b, r, mh->p),
+                                        x_out ? x_out + r * (size_t)mh->n : nullptr, exitcodes ? exitcodes + r : nullptr);
+    });
+}
+
 int eicos_multi_solution(eicos_multi *mh, double *x) {
     if (!mh || !x) return mfail(EICOS_E_INVALID, "NULL argument");
     if (mh->n == 0) return EICOS_OK;

@@ -150,6 +150,17 @@ namespace EiCOS
             for (int i = 0; i < batch_; i++) out[i] = static_cast<exitcode>(codes[i]);
             return out;
         }
+        // updateData(...) + solve() in ONE call (reference include/eicos.hpp:155-158 back to back): with arrays from hostAlloc / hostRegister the
+        // solve kernel's workgroups pull every instance's inputs over PCIe themselves, behind each other's compute, and write x into a pinned
+        // `x_out` ([batch][n], optional) as instances finish; plain arrays take updateData + solve.  Same results on every path.
+        std::vector<exitcode> solve(const double *Gpr, const double *Apr, const double *c, const double *h, const double *b, double *x_out = nullptr)
+        {
+            std::vector<int> codes(batch_);
+            mcheck(eicos_multi_update_solve(h_, Gpr, Apr, c, h, b, x_out, codes.data()), "eicos_multi_update_solve");
+            std::vector<exitcode> out(batch_);
+            for (int i = 0; i < batch_; i++) out[i] = static_cast<exitcode>(codes[i]);
+            return out;
+        }
         void solveAsync() { mcheck(eicos_multi_solve_async(h_), "eicos_multi_solve_async"); } // enqueue on every shard's stream
         void sync() { mcheck(eicos_multi_sync(h_), "eicos_multi_sync"); }
         std::vector<double> solution() const

@@ -127,9 +127,11 @@ int eicos_batch_last_update_path(eicos_batch *hd);
  * (reference include/eicos.hpp:155-158, src/eicos.cpp:2053-2082 + :848).  Same array conventions as eicos_batch_update (NULL = keep the group).
  * When every given array is memory the GPU addresses directly -- eicos_host_alloc / eicos_host_register memory, or device memory -- each
  * workgroup of the solve kernel runs updateData for the instance it is about to solve: the PCIe transfer is spread over the launch behind
- * the other workgroups' compute instead of preceding it (path 5 of eicos_batch_last_update_path).  x_out: optional [batch][n] result array
- * (pinned host / device memory is written by the kernel as instances finish).  Otherwise it is eicos_batch_update + eicos_batch_solve
- * (+ eicos_batch_solution).  Results are bit-identical on every path.  exitcodes: optional [batch]. */
+ * the other workgroups' compute instead of preceding it (path 5 of eicos_batch_last_update_path).  PAGEABLE arrays are staged: the kernel is
+ * launched at once and the host copies the arrays chunk by chunk into a pinned staging buffer of the handle WHILE it runs, releasing one
+ * flag per chunk; a workgroup polls the flag of the chunk that holds its instance (path 6).  x_out: optional [batch][n] result array
+ * (pinned host / device memory is written by the kernel as instances finish).  Handles without an LDS vector (patterns too large for LDS)
+ * run eicos_batch_update + eicos_batch_solve (+ eicos_batch_solution).  Results are bit-identical on every path.  exitcodes: optional [batch]. */
 int eicos_batch_update_solve(eicos_batch *hd, const double *Gpr, const double *Apr, const double *c, const double *h, const double *b,
                              double *x_out, int *exitcodes);
 /* Same, DEVICE pointers (inputs already resident in HBM; no PCIe traffic). */
@@ -224,6 +226,9 @@ int eicos_multi_create(int n, int m, int p, int l, int ncones, const int *q,
  * shards in parallel -- one persistent host thread per shard, started by eicos_multi_create */
 int eicos_multi_update(eicos_multi *mh, int first, int count, const double *Gpr, const double *Apr,
                        const double *c, const double *h, const double *b);
+/* updateData + solve in one synchronous call (eicos_batch_update_solve on every shard, concurrently; whole batch; x_out / exitcodes optional) */
+int eicos_multi_update_solve(eicos_multi *mh, const double *Gpr, const double *Apr, const double *c, const double *h, const double *b,
+                             double *x_out, int *exitcodes);
 /* updateData from arrays resident in the HBM of ONE GPU (src_device): shards on that GPU read them in place; the others read their rows
  * in place as well, over xGMI (peer access is enabled between the listed devices at creation), or -- without peer access -- pull them with
  * staged hipMemcpyPeerAsync copies on their own streams: the "batch scatter" of north_star without a collective.

@@ -1100,7 +1100,8 @@ def test_cpp_batch_solver_over_a_device_list(tmp_path):
                            "-L", lib, "-leicos_amd", "-Wl,-rpath," + lib, "-o", exe])
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "MPC02.epb"), "48", "0,0"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "2 shard(s)" in out.stdout and "1 shard(s)" in out.stdout and "bit-identical" in out.stdout and "48 / 48 optimal" in out.stdout, out.stdout
+    assert "2 shard(s)" in out.stdout and "1 shard(s)" in out.stdout and "single-device results: bit-identical" in out.stdout and "48 / 48 optimal" in out.stdout, out.stdout
+    assert "one-call solve on pinned arrays vs updateData + solve: bit-identical" in out.stdout, out.stdout  # (eicos_multi_update_solve: fused per shard)
 
 
 def test_ecos_shim_runs_a_reference_style_test(tmp_path):
@@ -1326,9 +1327,16 @@ def test_fused_update_solve_is_bit_identical_to_update_then_solve(name, B):
     xb = np.zeros((B, pat.n))  # (pageable result array: fetched after the launch)
     assert np.array_equal(g.update_solve(None, None, pc.a, None, None, x_out=xb), codes1) and np.array_equal(xb, x1)
     assert g.last_update_path() == "fused into the solve"
-    # pageable inputs: the classic path inside the same call
+    # pageable inputs: staged -- the host copies them into the handle's pinned staging buffer while the kernel runs, one flag per chunk
     assert np.array_equal(g.update_solve(*[d[k] for k in keys], x_out=px.a), codes0) and np.array_equal(px.a, x0)
-    assert g.last_update_path() == "pinned bounce"
+    assert g.last_update_path() == "fused into the solve, staged while it runs"
+    # ... mixed: G, A pinned, the small arrays pageable; and again (the flags carry a sequence number per call)
+    for _ in range(2):
+        xb[...] = 0.0
+        assert np.array_equal(g.update_solve(pins["Gpr"].a, pins["Apr"].a, d["c"], d["h"], d["b"], x_out=xb), codes0) and np.array_equal(xb, x0)
+    assert g.last_update_path() == "fused into the solve, staged while it runs"
+    # kept groups from pageable memory (c only): the un-equilibrated G, A of the handle, exactly as in the two-call sequence above
+    assert np.array_equal(g.update_solve(None, None, c2, None, None, x_out=xb), codes1) and np.array_equal(xb, x1)
     g.close()
     for pa in list(pins.values()) + [px, pc]:
         pa.close()
