@@ -25,7 +25,7 @@ for case in range(ncase):
     if l + sum(q) == 0:
         l = 3
     dens = float(rng.choice([0.05, 0.15, 0.3, 0.6])) / scale
-    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL", "EICOS_FAC_DEFER", "EICOS_W2", "EICOS_CONE_ORDER"):
+    for k in ("EICOS_THREADS", "EICOS_NLDS", "EICOS_IDX16", "EICOS_TILES", "EICOS_LDSRES", "EICOS_DUAL", "EICOS_FAC_DEFER", "EICOS_W2", "EICOS_CONE_ORDER", "EICOS_UBL"):
         os.environ.pop(k, None)
     var = {}
     if rng.random() < 0.7:
@@ -52,6 +52,11 @@ for case in range(ncase):
         var["EICOS_W2"] = "0"
     if rng.random() < 0.4:
         var["EICOS_CONE_ORDER"] = str(rng.choice([0, 1]))
+    # round 6 (drawn last: the variants of earlier rounds' seeds stay what they were): the U-in-LDS build off; the one-call fused
+    # updateData + solve (FUZZ_FUSED=1: pageable arrays -> staged while the kernel runs) instead of update + solve
+    if rng.random() < 0.3:
+        var["EICOS_UBL"] = "0"
+    fused_call = bool(os.environ.get("FUZZ_FUSED")) and rng.random() < 0.5
     os.environ.update(var)
     try:
         pat, base = random_socp_pattern(n, p, l, q, density=dens, seed=seed0 + case)
@@ -60,8 +65,12 @@ for case in range(ncase):
         g = eicos_amd.BatchSolver(pat, B)
         if os.environ.get("FUZZ_DYNREG"):
             g.set_dynamic_regularization(2e-7, 1e-13)
-        g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
-        codes = g.solve(); ia = g.info_arrays(); x = g.solution()
+        if fused_call:
+            x = np.zeros((B, pat.n))
+            codes = g.update_solve(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"], x_out=x); ia = g.info_arrays()
+        else:
+            g.update(d["Gpr"], d["Apr"], d["c"], d["h"], d["b"])
+            codes = g.solve(); ia = g.info_arrays(); x = g.solution()
         msg = []
         for i in range(B):
             o = OracleSolver(pat, Values(d["Gpr"][i], d["Apr"][i], d["c"][i], d["h"][i], d["b"][i]))
