@@ -490,7 +490,7 @@ def prev_round_legs(local_rank):
             env["EICOS_AMD_LIB"] = lib
         env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(local_rank))
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--legs-json"], env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--legs-json"], env=env, capture_output=True, text=True, timeout=300)
             out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             out[tag] = str(e)[:120]

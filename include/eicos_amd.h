@@ -119,7 +119,11 @@ int eicos_batch_update(eicos_batch *hd, int first, int count,
 void *eicos_host_alloc(size_t bytes); /* pinned host memory the GPU addresses directly; NULL on failure */
 int eicos_host_free(void *p);
 /* ... or pin arrays the caller already owns IN PLACE (hipHostRegister): they then take the pinned path as well.  Registering costs about
- * as much as a few bounce copies of the same bytes -- worth it for arrays reused across calls; unregister before freeing them. */
+ * as much as a few bounce copies of the same bytes -- worth it for arrays reused across calls; unregister before freeing them.  An array is
+ * read or written in place only when its WHOLE extent is pinned (first byte, last byte and a probe every 2 MB are checked per call; anything
+ * else takes the bounce path -- never a GPU page fault).  Registering a base pointer that is already registered returns EICOS_OK when the
+ * existing registration covers [p, p + bytes) and EICOS_E_INVALID when it is smaller (the runtime would map nothing new); a registration
+ * belongs to whoever made it: eicos_host_unregister(p) ends it for every user of that memory.  paths 5 / 6: eicos_batch_update_solve below. */
 int eicos_host_register(void *p, size_t bytes);
 int eicos_host_unregister(void *p);
 int eicos_batch_last_update_path(eicos_batch *hd);
