@@ -1715,8 +1715,17 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
           bar();
         }
     };
+#ifdef EICOS_TILE_TICKS // (dev builds: forward against backward sweep, thread 0's clock, on the trace slots of the factor's inner timers)
+    unsigned long long tq_ = threadIdx.x == 0 ? wall_clock64() : 0ull;
+#endif
     sweep(P.tl_fops, P.tl_fptr, P.tl_fsplit, LC, DL, std::false_type{}); // forward: block rows, levels up
+#ifdef EICOS_TILE_TICKS
+    if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[TK_FW1] += t1_ - tq_; tq_ = t1_; }
+#endif
     sweep(P.tl_bops, P.tl_bptr, P.tl_bsplit, LR, DL, std::true_type{});  // backward: block columns, levels down
+#ifdef EICOS_TILE_TICKS
+    if (threadIdx.x == 0) g_S.tick[TK_FB] += wall_clock64() - tq_;
+#endif
 }
 
 // ---------------- G in dense tiles: G x and G' z in ONE pass over the values (DevPat::gt_on, host: api.cpp) ----------------
