@@ -3198,7 +3198,9 @@ __global__ __launch_bounds__(T, (waves_per_eu<T>())) void k_solve(
                         const unsigned *f = upd.flags + id / upd.chunk;
                         const unsigned long long t0 = wall_clock64();
                         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != upd.seq) {
-                            __builtin_amdgcn_s_sleep(127);
+                            // a poll is a read over PCIe: ~30 us between two (a chunk arrives every ~250 us) -- 512 workgroups polling every
+                            // 4 us were 10 GB/s of link traffic beside the rows the other workgroups are pulling
+                            for (int r = 0; r < 8; r++) __builtin_amdgcn_s_sleep(127);
                             if (wall_clock64() - t0 > 500000000ull) { atomicExch(upd.err, 1); break; } // (5 s of the 100 MHz clock: the host died or lost the plot)
                         }
                     }
