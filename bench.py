@@ -346,7 +346,7 @@ def host_e2e(pat, sets, B, local_rank, device_value, steps=12, warmup=3):
     pinned = []
     try:
         registered = []
-        for variant in ("pageable", "pageable_fused", "registered", "pinned", "pinned_fused"):
+        for variant in ("pageable", "registered", "pinned", "pinned_fused"):
             try:
                 if variant == "registered":  # the caller's own (numpy) arrays pinned in place once: eicos_host_register
                     arrs = {k: np.ascontiguousarray(data[k]).copy() for k in keys}
@@ -357,8 +357,6 @@ def host_e2e(pat, sets, B, local_rank, device_value, steps=12, warmup=3):
                             registered.append(a)
                 elif variant == "pinned_fused":
                     pass  # (the arrays of the "pinned" variant, through eicos_batch_update_solve)
-                elif variant == "pageable_fused":
-                    pass  # (the plain numpy arrays of the "pageable" variant, through eicos_batch_update_solve)
                 elif variant == "pinned":
                     arrs = {}
                     for k in keys:
@@ -373,7 +371,7 @@ def host_e2e(pat, sets, B, local_rank, device_value, steps=12, warmup=3):
                     arrs, x = {k: data[k] for k in keys}, np.zeros((B, pat.n))
 
                 def step():
-                    if variant in ("pinned_fused", "pageable_fused"):  # ONE call: the solve kernel pulls every instance's inputs itself (pageable arrays: staged by the host while it runs)
+                    if variant == "pinned_fused":  # ONE call: the solve kernel pulls every instance's inputs itself and writes x into the pinned result array
                         solver.update_solve(arrs["Gpr"], arrs["Apr"], arrs["c"], arrs["h"], arrs["b"], x_out=x)
                         return
                     solver.update(arrs["Gpr"], arrs["Apr"], arrs["c"], arrs["h"], arrs["b"])
@@ -701,7 +699,7 @@ def main():
                 r3 = lambda v: float(f"{v:.4g}")
                 summary["host_e2e"] = {"batch": B, "in_MB": r3(he["bytes_in_per_step"] / 1e6), "out_MB": r3(he["bytes_out_per_step"] / 1e6),
                                        **{v: {"value": r3(he[v]["value"]), "x_device_resident": r3(he[v]["vs_device_resident"]), "update_ms": r3(he[v]["update_ms"]),
-                                              "path": he[v]["update_path"]} for v in ("pageable", "pageable_fused", "registered", "pinned", "pinned_fused") if v in he}}
+                                              "path": he[v]["update_path"]} for v in ("pageable", "registered", "pinned", "pinned_fused") if v in he}}
             except Exception as e:  # noqa: BLE001
                 summary["host_e2e"] = {"error": str(e)[:200]}
             if not args.no_prev_round:

@@ -1344,8 +1344,9 @@ int eicos_batch_solve(eicos_batch *h, int *exitcodes) {
 // PCIe is the workgroups' loads, spread over the launch and hidden behind the other workgroups' compute -- a separate updateData kernel can
 // only run BEFORE the solve (the registers and the LDS of a CU are fully owned by its resident solve workgroups), so its transfer time adds to
 // every step.  x_out (optional, [batch][n]): pinned host / device memory is written by the kernel as each instance finishes; pageable memory
-// is filled by eicos_batch_solution afterwards.  Anything else (pageable inputs, a handle without an LDS vector, vectors beyond the
-// in-register scaling accumulators) takes eicos_batch_update + eicos_batch_solve: same results, bit for bit, on every path.
+// is filled by eicos_batch_solution afterwards.  Anything else (pageable inputs -- unless staging is switched on, below --, a handle without an
+// LDS vector, vectors beyond the in-register scaling accumulators) takes eicos_batch_update + eicos_batch_solve: same results, bit for bit, on
+// every path.
 // Synchronous; exitcodes optional.
 int eicos_batch_update_solve(eicos_batch *h, const double *G, const double *A, const double *c, const double *hh, const double *b,
                              double *x_out, int *exitcodes) {
@@ -1369,7 +1370,10 @@ int eicos_batch_update_solve(eicos_batch *h, const double *G, const double *A, c
     const bool any_staged = stage_need > 0;
     const bool x_direct = x_out && D.n > 0 && gpu_addressable(x_out, (size_t)h->batch * D.n * sizeof(double));
     int rc;
-    if (!fused || (any_staged && !env_knob("EICOS_FUSED_STAGED", 1, 0, 1))) {
+    // (staging pageable arrays while the kernel runs is OFF by default: measured on five boxes against the bounce pipeline + solve it is
+    // +5.7 ... -6.2 % -- the host's copy is the pace either way, and on a box with slow host cores the kernel's own PCIe pulls and flag polls
+    // slow that copy further; EICOS_FUSED_STAGED=1 under EICOS_EXPERIMENT=1 turns it on: docs/HISTORY.md A.11 item 9)
+    if (!fused || (any_staged && !env_knob("EICOS_FUSED_STAGED", 0, 0, 1))) {
         bool all_device = true; // (device arrays on a handle without the fused path: the device-pointer updateData)
         for (int k = 0; k < 5; k++) if (arr[k].src && arr[k].w && pointer_kind(arr[k].src) != 2) all_device = false;
         rc = all_device ? eicos_batch_update_device(h, 0, h->batch, G, A, c, hh, b) : eicos_batch_update(h, 0, h->batch, G, A, c, hh, b);

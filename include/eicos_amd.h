@@ -131,9 +131,10 @@ int eicos_batch_last_update_path(eicos_batch *hd);
  * (reference include/eicos.hpp:155-158, src/eicos.cpp:2053-2082 + :848).  Same array conventions as eicos_batch_update (NULL = keep the group).
  * When every given array is memory the GPU addresses directly -- eicos_host_alloc / eicos_host_register memory, or device memory -- each
  * workgroup of the solve kernel runs updateData for the instance it is about to solve: the PCIe transfer is spread over the launch behind
- * the other workgroups' compute instead of preceding it (path 5 of eicos_batch_last_update_path).  PAGEABLE arrays are staged: the kernel is
- * launched at once and the host copies the arrays chunk by chunk into a pinned staging buffer of the handle WHILE it runs, releasing one
- * flag per chunk; a workgroup polls the flag of the chunk that holds its instance (path 6).  x_out: optional [batch][n] result array
+ * the other workgroups' compute instead of preceding it (path 5 of eicos_batch_last_update_path).  PAGEABLE arrays take the bounce
+ * pipeline of eicos_batch_update, then the solve (an experiment switch stages them instead -- the kernel is launched at once and the host
+ * copies the arrays chunk by chunk into a pinned staging buffer WHILE it runs, one flag per chunk, path 6: faster on some hosts, slower on
+ * others, off by default).  x_out: optional [batch][n] result array
  * (pinned host / device memory is written by the kernel as instances finish).  Handles without an LDS vector (patterns too large for LDS)
  * run eicos_batch_update + eicos_batch_solve (+ eicos_batch_solution).  Results are bit-identical on every path.  exitcodes: optional [batch]. */
 int eicos_batch_update_solve(eicos_batch *hd, const double *Gpr, const double *Apr, const double *c, const double *h, const double *b,

@@ -1294,7 +1294,7 @@ def test_arithmetic_profile_one_gives_batch_independent_bits():
 
 
 @pytest.mark.parametrize("name,B", [("MPC02", 600), ("lp_afiro", 300), ("lp_bandm", 64), ("update_data", 40), ("MPC02", 40)])
-def test_fused_update_solve_is_bit_identical_to_update_then_solve(name, B):
+def test_fused_update_solve_is_bit_identical_to_update_then_solve(name, B, monkeypatch):
     # eicos_batch_update_solve: with pinned / registered host arrays the solve kernel's workgroups run updateData for the
     # instance they are about to solve (the PCIe transfer hides behind the other workgroups' compute) and write x straight into a pinned
     # result array; pageable arrays take update + solve.  Same bits on every path, also with kept groups and after a previous solve
@@ -1327,7 +1327,11 @@ def test_fused_update_solve_is_bit_identical_to_update_then_solve(name, B):
     xb = np.zeros((B, pat.n))  # (pageable result array: fetched after the launch)
     assert np.array_equal(g.update_solve(None, None, pc.a, None, None, x_out=xb), codes1) and np.array_equal(xb, x1)
     assert g.last_update_path() == "fused into the solve"
-    # pageable inputs: staged -- the host copies them into the handle's pinned staging buffer while the kernel runs, one flag per chunk
+    # pageable inputs: update (bounce pipeline) + solve inside the same call ...
+    assert np.array_equal(g.update_solve(*[d[k] for k in keys], x_out=px.a), codes0) and np.array_equal(px.a, x0)
+    assert g.last_update_path() == "pinned bounce"
+    # ... or, switched on, staged: the host copies them into the handle's pinned staging buffer while the kernel runs, one flag per chunk
+    monkeypatch.setenv("EICOS_FUSED_STAGED", "1")
     assert np.array_equal(g.update_solve(*[d[k] for k in keys], x_out=px.a), codes0) and np.array_equal(px.a, x0)
     assert g.last_update_path() == "fused into the solve, staged while it runs"
     # ... mixed: G, A pinned, the small arrays pageable; and again (the flags carry a sequence number per call)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6 campaign (fresh seeds) on the round's final library: the U-in-LDS build (small batches run one workgroup per CU: most cases take it),
 # half of the cases through the one-call fused updateData + solve (pageable arrays: staged while the kernel runs).
-export TMPDIR=/tmp FUZZ_FUSED=1
+export TMPDIR=/tmp FUZZ_FUSED=1 EICOS_FUSED_STAGED=1
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 {
