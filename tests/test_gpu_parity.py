@@ -1408,6 +1408,19 @@ def test_bench_emits_the_contract_json_line():
         assert e["steps"] == 2 and e["value_kernel"] >= e["value"] > 0 and len(e["step_ms"]) == 3 and e["step_ms"][0] <= e["step_ms"][1] <= e["step_ms"][2]
 
 
+def test_bench_legs_json_is_what_prev_round_parses():
+    # `bench.py --legs-json` (the child process behind config.summary.prev_round: every leg of the default line, GPU part only, on the library
+    # EICOS_AMD_LIB names): one json object, [value, value_kernel] per leg, every leg timed >= 10 steps
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--legs-json"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert set(d) == {"headline", "soc", "dense_front_b512", "lp_afiro_b256", "lp_bandm_b256", "lp_25fv47_b256", "mpc_b512", "mpc_b4096"}
+    for k, v in d.items():
+        assert isinstance(v, list) and len(v) == 2 and v[1] >= v[0] > 0, (k, v)
+
+
 def test_bench_multi_flag_drives_the_product_multi_gpu_layer():
     # bench.py --multi IDS: the benchmark step from ONE process through eicos_multi_* (device list {0, 0} on this box)
     import json, os, subprocess, sys
