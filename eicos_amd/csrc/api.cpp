@@ -351,6 +351,8 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     EllPlan pcag = build_ell_plan(cag_ptr, S.n, h->threads), prA = build_ell_plan(S.At_ptr, S.p, h->threads),
             prG = build_ell_plan(Gt_ptr_used, S.m, h->threads);
     D.cag_ns = (int)pcag.sl.size(); D.rA_ns = (int)prA.sl.size(); D.rG_ns = (int)prG.sl.size();
+    {   auto real = [](const std::vector<SliceMeta> &sl) { int c = (int)sl.size(); while (c > 0 && sl[(size_t)c - 1].cnt == 0) c--; return c; };
+        D.cag_ns_r = real(pcag.sl); D.rA_ns_r = real(prA.sl); D.rG_ns_r = real(prG.sl); }
     D.cag_slots = pcag.slots; D.rA_slots = prA.slots; D.rG_slots = prG.slots;
     D.i_cag = L.add((size_t)pcag.slots + 8); D.i_rA = L.add((size_t)prA.slots + 8); D.i_rG = L.add((size_t)prG.slots + 8);
     D.gt_on = GT.on; D.gt_nrb = GT.nrb; D.gt_nt = GT.nt; D.gt_W = GT.W;
@@ -432,6 +434,12 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     if (!tile1) { planF = build_tri_plan(S, h->threads, true, solo_ok); planB = build_tri_plan(S, h->threads, false, solo_ok); }
     else { planF.idx.assign(1, NV); planB.idx.assign(1, NV); planF.pos.assign(S.nnzL, 0); planB.pos.assign(S.nnzL, 0); }
     D.nfs = planF.n_wide; D.nbs = planB.n_wide; D.nfs_solo = planF.n_solo; D.nbs_solo = planB.n_solo; D.nfs_ext = planF.n_ext; D.nUF = planF.slots; D.nUB = planB.slots;
+    {   // the real slices of every section: its length without the trailing padding (empty slices)
+        auto real = [](const std::vector<SliceMeta> &sl, int first, int count) { while (count > 0 && sl[(size_t)first + count - 1].cnt == 0) count--; return count; };
+        // forward plan = [wide | solo | ext], backward plan = [solo | wide] (plans.cpp)
+        D.nfs_r = real(planF.sl, 0, planF.n_wide); D.nfs_solo_r = real(planF.sl, planF.n_wide, planF.n_solo); D.nfs_ext_r = real(planF.sl, planF.n_wide + planF.n_solo, planF.n_ext);
+        D.nbs_solo_r = real(planB.sl, 0, planB.n_solo); D.nbs_r = real(planB.sl, planB.n_solo, planB.n_wide);
+    }
     // every section of a sweep plan is a whole number of queue-depth trips (tri_sweep's remainder loop executes full trips)
     if (D.nfs % TRI_DEPTH || D.nbs % TRI_DEPTH || D.nfs_ext % TRI_DEPTH || D.nfs_solo % TRI_DEPTH_SOLO || D.nbs_solo % TRI_DEPTH_SOLO) {
         delete h; return fail(EICOS_E_INVALID, "internal: a section of a sweep plan is not padded to its queue depth");

@@ -135,6 +135,8 @@ struct DevPat {
     const PackedSlice EICOS_GLOBAL *fsl; const PackedSlice EICOS_GLOBAL *bsl;
     int nfs, nbs, nUF, nUB;   // nfs / nbs = slices of the workgroup-wide part of the forward / backward plan
     int nfs_solo, nbs_solo;   // single-wavefront part (top of the tree): fsl = [wide | solo], bsl = [solo | wide]
+    // the REAL slices of every section (the counts above include the empty slices the host pads a section with: never stepped through)
+    int nfs_r, nbs_r, nfs_solo_r, nbs_solo_r, nfs_ext_r, cag_ns_r, rA_ns_r, rG_ns_r;
     int meta_lds; // 1: the slice tables are staged in LDS behind the NLDS vectors, at these slice offsets:
     int lm_f, lm_b, lm_cag, lm_rA, lm_rG, lm_fac, lm_total; // lm_fac < 0: factor table stays in global memory
     gint_p f_idx, b_idx;

@@ -492,9 +492,9 @@ template <bool I16> __device__ __forceinline__ void load_indices(int (&ni)[ELL_K
 // `pre(row)` loads whatever the epilogue needs per row (rhs entry, destination index, ...); it is issued with the
 // slice's index/value loads, ELL_DEPTH slices ahead, so that `epi(row, sum, pre(row))` starts no global load itself.
 template <int T, bool I16, class SM, class V, class X, class Pre, class Epi>
-__device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, V eval, X x, int dummy_slot,
+__device__ __forceinline__ void ell_dots(const SM *sm, int ns, int nr, gint_p eidx, gint_p eidx16, int d16, V eval, X x, int dummy_slot,
                                          Pre &&pre, Epi &&epi) {
-    if (ns == 0) return; // no rows
+    if (nr == 0) return; // no rows  (ns: slices incl. the host's padding, nr: the real ones -- see tri_sweep)
     const int t = threadIdx.x;
     using R = decltype(pre(0));
     int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX]; R qr[ELL_DEPTH]; Sl qm[ELL_DEPTH]; // (qm: the slice's decoded descriptor, SGPRs)
@@ -546,13 +546,13 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
         else if (act && (t & ((1 << m.lg) - 1)) == 0) epi(m.row0 + (t >> m.lg), acc, cr);
     };
     int s0 = 0;
-    for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
+    for (; s0 + ELL_TRIP <= nr; s0 += ELL_TRIP) {
 #pragma unroll
         for (int u = 0; u < ELL_TRIP; u++) step(u % ELL_DEPTH, s0 + u);
     }
-    for (; s0 < ns; s0 += ELL_DEPTH) {
+    for (; s0 < nr; s0 += ELL_DEPTH) { // (stopping at the last real slice)
 #pragma unroll
-        for (int u = 0; u < ELL_DEPTH; u++) step(u, s0 + u);
+        for (int u = 0; u < ELL_DEPTH; u++) { if (s0 + u < nr) step(u, s0 + u); }
     }
 }
 
@@ -560,9 +560,9 @@ __device__ __forceinline__ void ell_dots(const SM *sm, int ns, gint_p eidx, gint
 // the matrix values are loaded once, the gathered vector x is KI-interleaved; `pre(k, row)` / `epi(k, row, sum, pre)` get the
 // number of the right-hand side.
 template <int T, bool I16, int KI, bool SHARED, class SM, class X, class Pre, class Epi>
-__device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, const gcdbl_p (&eval)[KI], X x, int dummy_slot,
+__device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, int nr, gint_p eidx, gint_p eidx16, int d16, const gcdbl_p (&eval)[KI], X x, int dummy_slot,
                                            Pre &&pre, Epi &&epi) {
-    if (ns == 0) return; // no rows
+    if (nr == 0) return; // no rows
     const int t = threadIdx.x;
     using R = decltype(pre(0, 0));
     int qi[ELL_DEPTH][ELL_KMAX]; double qv[ELL_DEPTH][ELL_KMAX][KI]; R qr[ELL_DEPTH][KI]; Sl qm[ELL_DEPTH]; // (qm: the slice's decoded descriptor, SGPRs)
@@ -629,13 +629,13 @@ __device__ __forceinline__ void ell_dots_k(const SM *sm, int ns, gint_p eidx, gi
         }
     };
     int s0 = 0;
-    for (; s0 + ELL_TRIP <= ns; s0 += ELL_TRIP) {
+    for (; s0 + ELL_TRIP <= nr; s0 += ELL_TRIP) {
 #pragma unroll
         for (int u = 0; u < ELL_TRIP; u++) step(u % ELL_DEPTH, s0 + u);
     }
-    for (; s0 < ns; s0 += ELL_DEPTH) {
+    for (; s0 < nr; s0 += ELL_DEPTH) { // (stopping at the last real slice)
 #pragma unroll
-        for (int u = 0; u < ELL_DEPTH; u++) step(u, s0 + u);
+        for (int u = 0; u < ELL_DEPTH; u++) { if (s0 + u < nr) step(u, s0 + u); }
     }
 }
 
@@ -661,11 +661,14 @@ __device__ __forceinline__ void lds_barrier() {
 // wait at the caller's barrier instead of issuing a full slice of masked-off instructions per level.
 // VSH (dual right-hand sides of ONE instance): the vector ws is KI-interleaved, the factor (eval, invD) is a single one.
 template <int T, bool FORWARD, bool LDSBAR, bool SOLO, bool I16, int KI, bool VSH = false, class SM, class EV, class WS>
-__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gint_p eidx16, int d16, EV eval, gcdbl_p invD, WS ws,
+__device__ __forceinline__ void tri_sweep(const SM *sm, int ns, int nr, gint_p eidx, gint_p eidx16, int d16, EV eval, gcdbl_p invD, WS ws,
                                           int dummy_slot) {
     // KI = 2 (with VSH): the two right-hand sides of a dual solve -- one factor, the sweep vector ws 2-interleaved, so every
     // gather / store of the pair is one 16-byte LDS access
-    if (ns == 0) { if (!SOLO) __syncthreads(); return; }
+    // ns = slices of this section of the plan INCLUDING the empty ones the host pads it with (to a multiple of the queue depth: the refills
+    // past the end stay inside the table), nr = the real ones: the padding is never stepped through -- on a small pattern a padded slice was a
+    // full step of the dependent chain (lp_afiro: three of the five steps of its forward sweep)
+    if (nr == 0) { if (!SOLO) __syncthreads(); return; }
     const int t = threadIdx.x;
     // the narrow tree top (SOLO, one wavefront) runs short steps: the same lead time needs a deeper queue than the workgroup-wide levels
     constexpr int DEPTH = SOLO ? TRI_DEPTH_SOLO : TRI_DEPTH;
@@ -753,13 +756,13 @@ __device__ __forceinline__ void tri_sweep(const SM *sm, int ns, gint_p eidx, gin
     
     };
     int s0 = 0;
-    for (; s0 + TRIP <= ns; s0 += TRIP) {
+    for (; s0 + TRIP <= nr; s0 += TRIP) {
 #pragma unroll
         for (int u = 0; u < TRIP; u++) step(u % DEPTH, s0 + u);
     }
-    for (; s0 < ns; s0 += DEPTH) { // remainder in trips of the queue depth (the host pads every section of a plan to a multiple of it)
+    for (; s0 < nr; s0 += DEPTH) { // remainder in trips of the queue depth, stopping at the last real slice
 #pragma unroll
-        for (int u = 0; u < DEPTH; u++) step(u, s0 + u);
+        for (int u = 0; u < DEPTH; u++) { if (s0 + u < nr) step(u, s0 + u); }
     }
     if (!SOLO) __syncthreads();
 }
@@ -1844,14 +1847,14 @@ static __device__ __noinline__ __attribute__((not_tail_called)) int stage_resid(
     gdbl_p gxv = W + P.w_gx, gzv = W + P.w_gz;
     if (gt) g_tile_products<T, 1>(P, I + P.i_Gt, P.gt_col, [&](int c, int) { return c < 0 ? 0. : wx[c]; }, [&](int i, int) { return wz[i]; },
                                   W + P.w_gpart, gxv, gzv);
-    ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_idx_yz, P.cag_yz16, P.cag_d16, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j], gt ? gxv[j] : 0.}; },
+    ell_dots<T, I16>(tab_cag, P.cag_ns, P.cag_ns_r, P.cag_idx_yz, P.cag_yz16, P.cag_d16, cagv, wy, P.cag_slots, [&](int j) { return Pre2{cv[j], wx[j], gt ? gxv[j] : 0.}; },
                 [&](int j, double s, const Pre2 &pr) { // -G'z - A'y: (y,z) contiguous
         const double hr = -(s + pr.g), c_ = pr.a, xj = pr.b;
         const double r = hr - tau * c_;
         rhs2k[j] = r; // (rx, only ever read as the x part of RHSaffine)
         r8[0] += hr * hr; r8[1] += r * r; r8[2] += c_ * xj; r8[3] += xj * xj;
     });
-    ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_idx, P.rA_16, P.rA_d16, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r], 0.}; },
+    ell_dots<T, I16>(tab_rA, P.rA_ns, P.rA_ns_r, P.rA_idx, P.rA_16, P.rA_d16, rAv, wx, P.rA_slots, [&](int r) { return Pre2{bv[r], wy[r], 0.}; },
                 [&](int r, double s, const Pre2 &pr) {
         const double b_ = pr.a, yr = pr.b;
         const double rr = s - tau * b_;
@@ -1860,7 +1863,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) int stage_resid(
     });
     blk_reduce<OpSum, T, 8>(phase, r8);
     double q6[6] = {0, 0, 0, 0, 0, 0}; // hresz2 rz2 hz nz2 ns2 gap
-    ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_idx, P.rG_16, P.rG_d16, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i], gt ? gzv[i] : 0.}; },
+    ell_dots<T, I16>(tab_rG, P.rG_ns, P.rG_ns_r, P.rG_idx, P.rG_16, P.rG_d16, rGv, wx, P.rG_slots, [&](int i) { return Pre3{wsl[i], wz[i], hv[i], gt ? gzv[i] : 0.}; },
                 [&](int i, double s, const Pre3 &pr) {
         const double si = pr.a, zi = pr.b, h_ = pr.c;
         const double hr = si + (s + pr.g), r = hr - tau * h_;
@@ -2292,28 +2295,28 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         if (P.tile == 1) { // dense fronts: tile mat-vecs over the block levels (single-instance workgroups only)
             if constexpr (NLDS >= 1) tile_solve<T, true, KI>(P, Wg, SV); else tile_solve<T, false, KI>(P, Wg, SV);
         } else if constexpr (NLDS >= 1) { // slice tables staged in LDS behind the vectors (k_solve prologue)
-            tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
+            tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f, P.nfs, P.nfs_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF); // barriers at level starts + end
             if (P.tile == 2) { // hybrid: levels below the cut, the top block's rows against them, both tile sweeps on the block, back down
                 {
-                    if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.nfs_solo_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
-                    tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.nfs_ext_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     tile_solve<T, true, KI>(P, Wg, SV);
-                    if (wave0) tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                    if (wave0) tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.nbs_solo_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (apex_on<T>(P)) { // dense apex: the narrow levels below it on wavefront 0, its rows against everything below (all wavefronts), the apex, back down
                 if (P.nfs_solo) {
-                    if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    if (wave0) tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.nfs_solo_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
                 }
-                tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, true, true, false, I16, KI, DUAL>(tabs + P.lm_f + P.nfs + P.nfs_solo, P.nfs_ext, P.nfs_ext_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                 if (wave0) {
 #ifdef EICOS_SOLO_TICKS
                     tick(TK_LDL);
 #endif
                     if (P.apex_lds >= 0) apex_solve_lds<KI>(P, invD, SV);
                     else if constexpr (EICOS_UBL == 0) apex_solve<KI>(P, UF, UB, invD, SV); // (UBL handles always carry the LDS image: api.cpp)
-                    tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                    tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.nbs_solo_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
 #ifdef EICOS_SOLO_TICKS
                     tick(TK_FWD);
 #endif
@@ -2322,41 +2325,41 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
 #ifdef EICOS_SOLO_TICKS
                 tick(TK_LDL);
 #endif
-                tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, true, true, I16, KI, DUAL>(tabs + P.lm_f + P.nfs, P.nfs_solo, P.nfs_solo_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, true, true, I16, KI, DUAL>(tabs + P.lm_b, P.nbs_solo, P.nbs_solo_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
 #ifdef EICOS_SOLO_TICKS
                 tick(TK_FWD); // (dev builds: the narrow tree top of both sweeps, wavefront 0 alone, shows up as "fwd" in the phase timers)
 #endif
             }
             __syncthreads();
-            tri_sweep<T, false, true, false, I16, KI, DUAL>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            tri_sweep<T, false, true, false, I16, KI, DUAL>(tabs + P.lm_b + P.nbs_solo, P.nbs, P.nbs_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
         } else {
-            tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl, P.nfs, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+            tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl, P.nfs, P.nfs_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
             if (P.tile == 2) {
                 {
-                    if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.nfs_solo_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
-                    tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.nfs_ext_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     tile_solve<T, false, KI>(P, Wg, SV);
-                    if (wave0) tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                    if (wave0) tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.nbs_solo_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (apex_on<T>(P)) {
                 if (P.nfs_solo) {
-                    if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                    if (wave0) tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.nfs_solo_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                     __syncthreads();
                 }
-                tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, true, false, false, I16, KI, DUAL>(P.fsl + P.nfs + P.nfs_solo, P.nfs_ext, P.nfs_ext_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
                 if (wave0) {
                     apex_solve<KI>(P, UF, UB, invD, SV);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (slab vector: the apex's stores before the gathers of the levels below)
-                    tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                    tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.nbs_solo_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
                 }
             } else if (wave0) {
-                tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
-                tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+                tri_sweep<T, true, false, true, I16, KI, DUAL>(P.fsl + P.nfs, P.nfs_solo, P.nfs_solo_r, P.f_idx, P.f_idx16, P.f_d16, UF, invD, SV, P.nUF);
+                tri_sweep<T, false, false, true, I16, KI, DUAL>(P.bsl, P.nbs_solo, P.nbs_solo_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
             }
             __syncthreads();
-            tri_sweep<T, false, false, false, I16, KI, DUAL>(P.bsl + P.nbs_solo, P.nbs, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
+            tri_sweep<T, false, false, false, I16, KI, DUAL>(P.bsl + P.nbs_solo, P.nbs, P.nbs_r, P.b_idx, P.b_idx16, P.b_d16, UB, invD, SV, P.nUB);
         }
         // x = first solve / x += dx_ref (ref :1602); an instance that has stopped keeps its iterate
         if constexpr (NLDS == 1) { // the LDS vector becomes X again: previous iterate (slab copy Xg) + increment
@@ -2389,21 +2392,21 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void kkt_solve(i
         gdbl_p gxv = Wg + P.w_gx, gzv = Wg + P.w_gz;
         if (gt) g_tile_products<T, KI>(P, I0 + P.i_Gt, P.gt_colk, [&](int c, int k) { return X[c * KI + k]; },
                                        [&](int i, int k) { return X[P.gt_zslot[i] * KI + k]; }, Wg + P.w_gpart, gxv, gzv);
-        ell_dots_k<T, I16, KI, DUAL>(tab_cag, P.cag_ns, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
+        ell_dots_k<T, I16, KI, DUAL>(tab_cag, P.cag_ns, P.cag_ns_r, P.cag_idx_k, P.cag_k16, P.cag_d16, cagv, X, P.cag_slots,
                     [&](int k, int j) { return PreK{ld_u32(bx[k], j), 0., ld_u32(P.ipx, j), 0, gt ? gxv[j * KI + k] : 0.}; },
                     [&](int k, int j, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - (s + pr.g) - DELTASTAT * X[o * KI + k]; // ex = bx - G'dz - A'dy - delta dx
             stE(o, k, e); nex[k] = fmax(nex[k], fabs(e));
         });
-        ell_dots_k<T, I16, KI, DUAL>(tab_rA, P.rA_ns, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
+        ell_dots_k<T, I16, KI, DUAL>(tab_rA, P.rA_ns, P.rA_ns_r, P.rA_idx_k, P.rA_k16, P.rA_d16, rAv, X, P.rA_slots,
                     [&](int k, int r) { return PreK{ld_u32(by[k], r), 0., ld_u32(P.ipy, r), 0, 0.}; },
                     [&](int k, int r, double s, const PreK &pr) {
             const int o = pr.o;
             const double e = pr.b - s + DELTASTAT * X[o * KI + k]; // ey = by - A dx + delta dy
             stE(o, k, e); ney[k] = fmax(ney[k], fabs(e));
         });
-        ell_dots_k<T, I16, KI, DUAL>(tab_rG, P.rG_ns, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
+        ell_dots_k<T, I16, KI, DUAL>(tab_rG, P.rG_ns, P.rG_ns_r, P.rG_idx_k, P.rG_k16, P.rG_d16, rGv, X, P.rG_slots,
                     [&](int k, int i) { return PreK{ld_u32(bz[k], i), ld_u32(lpv[k], i < l ? i : 0), ld_u32(P.ipz, i), ld_u32(P.zdsign, i), gt ? gzv[i * KI + k] : 0.}; },
                     [&](int k, int i, double s, const PreK &pr) {
             const int o = pr.o;
