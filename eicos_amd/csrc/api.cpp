@@ -646,7 +646,7 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     TileSweeps TSW;
     if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_STRIP);
     put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
-    put(D.tl_fsplit, TSW.fsplit); put(D.tl_bsplit, TSW.bsplit);
+    put(D.tl_fsplit, TSW.fsplit); put(D.tl_bsplit, TSW.bsplit); put(D.tl_fend, TSW.fend); put(D.tl_bend, TSW.bend);
     TileFactorOps TFO;
     if (tile) {
         // pure tile mode: tiles of the K image no KKT entry lands in (targets that exist through fill only) start from zero without

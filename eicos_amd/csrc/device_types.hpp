@@ -184,6 +184,7 @@ struct DevPat {
     gint_p tl_trow, tl_tcol, tl_tc_ptr, tl_tr_ptr, tl_tr_tile; // tiles: block row / column; CSC pointer; CSR view
     gint_p tl_fops, tl_bops, tl_fptr, tl_bptr; // per-wavefront flat schedules of the two sweeps (tiles.hpp: TileSweeps), int4 per op; ptr: [(level * 2 + phase) * NW + wave]
     gint_p tl_fsplit, tl_bsplit;               // per level (sweep order): 1 = the level has split blocks, i.e. a second phase behind a barrier
+    gint_p tl_fend, tl_bend;                   // [(level * 2 + phase) * NW + wave]: end of the range's REAL operations (the rest of the range is padding: never executed)
     int tl_part;                               // offset (doubles) of the TILE_PARTS partial-sum slots (16 x KI_MAX doubles each) in the dynamic LDS
     gint_p tl_facops, tl_facptr;               // per-wavefront flat schedule of the factorisation's accumulation phase (TileFactorOps)
     gint_p tl_ident;               // per block: 1 = the diagonal tile of L is the identity (skipped by the sweeps)

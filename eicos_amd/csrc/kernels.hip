@@ -1632,15 +1632,16 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
     // flight across block boundaries (they do not depend on ws).
     // A level has a second phase when it holds SPLIT blocks (device_types.hpp: TOP_PART): phase 0 = tiles, whole blocks and the parts of
     // split blocks (partial sums -> LDS slots), barrier, phase 1 = the split blocks' diagonal operations (partial sums added in slot order).
-    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gint_p split_g, gcdbl_p val, gcdbl_p dia, auto bwd) {
+    auto sweep = [&](gint_p ops_i, gint_p ptr_g, gint_p end_g, gint_p split_g, gcdbl_p val, gcdbl_p dia, auto bwd) {
         constexpr bool scale = decltype(bwd)::value; // backward: x_J = L_JJ^-T (y_J / D_J - ...), forward: y_J = L_JJ^-1 (b_J - ...)
         cint4_p ops = (cint4_p)(unsigned long long)ops_i;
-        cint_p ptr = as_const(ptr_g), split = as_const(split_g);
+        cint_p ptr = as_const(ptr_g), endr = as_const(end_g), split = as_const(split_g);
         for (int v = 0; v < P.nblev; v++) {
           const int nph = split[v] ? 2 : 1; // (workgroup-uniform: a scalar load)
           for (int ph = 0; ph < nph; ph++) {
             if (ph) bar(); // the partial sums of phase 0 are in LDS
             const int o0 = ptr[(v * 2 + ph) * NW + wave], o1 = ptr[(v * 2 + ph) * NW + wave + 1]; // (o1 - o0) is a multiple of TILE_STRIP
+            const int o1r = endr[(v * 2 + ph) * NW + wave]; // end of the REAL operations: [o1r, o1) is padding for the queue's refills, never executed
             d4_t qv[TILE_PF];
             // unconditional: a conditional load would force s_waitcnt vmcnt(0) at every join and serialise the queue
             auto load = [&](int o, d4_t &x) {
@@ -1654,9 +1655,7 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
 #pragma unroll
                 for (int u = 0; u < TILE_PF; u++) load(o0 + u, qv[u]);
             }
-            for (int o = o0; o < o1; o += TILE_STRIP) {
-#pragma unroll
-                for (int uu = 0; uu < TILE_STRIP; uu++) {
+            auto op_step = [&](const int uu, const int o) __attribute__((always_inline)) {
                     const int u = uu % TILE_PF;
                     const i4_t op = ops[o + uu];
                     const d4_t cv = qv[u];
@@ -1712,7 +1711,16 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                         }
                         if (lane < 16) stK<NR>(ws, vb * 16 + lane, res);
                     }
-                }
+            };
+            int o = o0;
+            for (; o + TILE_STRIP <= o1r; o += TILE_STRIP) { // whole trips of real operations (the loads inside are unconditional)
+#pragma unroll
+                for (int uu = 0; uu < TILE_STRIP; uu++) op_step(uu, o);
+            }
+            if (o < o1r) { // the last, partial trip stops at the last real operation (a small block system -- the top block of a hybrid pattern: seven
+                           // levels of one block each on lp_bandm -- spent 42 % of its critical path on padding)
+#pragma unroll
+                for (int uu = 0; uu < TILE_STRIP; uu++) if (o + uu < o1r) op_step(uu, o);
             }
           }
           bar();
@@ -1721,11 +1729,11 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
 #ifdef EICOS_TILE_TICKS // (dev builds: forward against backward sweep, thread 0's clock, on the trace slots of the factor's inner timers)
     unsigned long long tq_ = threadIdx.x == 0 ? wall_clock64() : 0ull;
 #endif
-    sweep(P.tl_fops, P.tl_fptr, P.tl_fsplit, LC, DL, std::false_type{}); // forward: block rows, levels up
+    sweep(P.tl_fops, P.tl_fptr, P.tl_fend, P.tl_fsplit, LC, DL, std::false_type{}); // forward: block rows, levels up
 #ifdef EICOS_TILE_TICKS
     if (threadIdx.x == 0) { const unsigned long long t1_ = wall_clock64(); g_S.tick[TK_FW1] += t1_ - tq_; tq_ = t1_; }
 #endif
-    sweep(P.tl_bops, P.tl_bptr, P.tl_bsplit, LR, DL, std::true_type{});  // backward: block columns, levels down
+    sweep(P.tl_bops, P.tl_bptr, P.tl_bend, P.tl_bsplit, LR, DL, std::true_type{});  // backward: block columns, levels down
 #ifdef EICOS_TILE_TICKS
     if (threadIdx.x == 0) g_S.tick[TK_FB] += wall_clock64() - tq_;
 #endif

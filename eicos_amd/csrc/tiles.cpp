@@ -141,8 +141,8 @@ TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
     TileSweeps W;
     W.NW = NW;
     const bool allow_split = !(getenv("EICOS_EXPERIMENT") && getenv("EICOS_TILE_SPLIT") && !strcmp(getenv("EICOS_EXPERIMENT"), "1") && !strcmp(getenv("EICOS_TILE_SPLIT"), "0"));
-    auto build = [&](bool fwd, std::vector<int> &ops, std::vector<int> &ptr, std::vector<int> &split) {
-        ptr.assign(1, 0);
+    auto build = [&](bool fwd, std::vector<int> &ops, std::vector<int> &ptr, std::vector<int> &endr, std::vector<int> &split) {
+        ptr.assign(1, 0); endr.clear();
         split.assign(T.nblev, 0);
         for (int step = 0; step < T.nblev; step++) {
             const int v = fwd ? step : T.nblev - 1 - step;
@@ -178,7 +178,8 @@ TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
             }
             // pad to a multiple of `pf` operations with products against the all-zero vector block nb: the kernel's software
             // pipeline then has no conditional around its loads (a conditional load defeats the s_waitcnt counting)
-            auto close_segment = [&]() { while (((int)ops.size() / 4 - ptr.back()) % pf) ops.insert(ops.end(), {0, T.nb, 0, 0}); ptr.push_back((int)ops.size() / 4); };
+            // (the padding is there for the refills of the kernel's queue only: it stops at `endr`, the end of the real operations)
+            auto close_segment = [&]() { endr.push_back((int)ops.size() / 4); while (((int)ops.size() / 4 - ptr.back()) % pf) ops.insert(ops.end(), {0, T.nb, 0, 0}); ptr.push_back((int)ops.size() / 4); };
             for (int w = 0; w < NW; w++) { // phase 0
                 for (int i : mine[w]) {
                     const Item &it = items[i];
@@ -201,8 +202,8 @@ TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
             split[step] = closing.empty() ? 0 : 1;
         }
     };
-    build(true, W.fops, W.fptr, W.fsplit);
-    build(false, W.bops, W.bptr, W.bsplit);
+    build(true, W.fops, W.fptr, W.fend, W.fsplit);
+    build(false, W.bops, W.bptr, W.bend, W.bsplit);
     // every tile exactly once, every block closed exactly once, partial slots written before they are read (by construction; checked)
     for (int pass = 0; pass < 2; pass++) {
         const std::vector<int> &ops = pass ? W.bops : W.fops, &ptr = pass ? W.bptr : W.fptr;

@@ -58,6 +58,7 @@ struct TileSweeps {
     int NW = 0;
     std::vector<int> fops, bops;       // 4 ints per op
     std::vector<int> fptr, bptr;       // [nblev * 2 * NW + 1]: op range of (level, phase, wave), levels in sweep order (forward: up, backward: down)
+    std::vector<int> fend, bend;       // [nblev * 2 * NW]: end of the REAL operations of that range (what follows, up to the next range, is padding)
     std::vector<int> fsplit, bsplit;   // [nblev]
 };
 TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf /* list lengths are padded to a multiple of pf */);
