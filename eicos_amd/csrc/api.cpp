@@ -644,7 +644,8 @@ static int batch_create_impl(int n, int m, int p, int l, int ncones, const int *
     put(D.tl_blev, TP.blev_ptr); put(D.tl_tgt_lev, TP.tgt_lev_ptr); put(D.tl_tgt, TP.tgt); put(D.tl_tp, TP.tp_ptr);
     put(D.tl_pa, TP.pa); put(D.tl_pb, TP.pb); put(D.tl_pk, TP.pk); put(D.tl_fin_lev, TP.fin_lev_ptr); put(D.tl_fin, TP.fin);
     TileSweeps TSW;
-    if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_STRIP);
+    // (hybrid patterns whose vectors certainly live in LDS -- a serially swept block system relies on the in-order LDS accesses of one wavefront)
+    if (tile) TSW = build_tile_sweeps(TP, h->threads / 64, TILE_STRIP, (S.tile == 2 && TP.N16 <= 4096) ? env_int("EICOS_TILE_SERIAL_MAX", 48, 0, 100000) : 0);
     put(D.tl_fops, TSW.fops); put(D.tl_bops, TSW.bops); put(D.tl_fptr, TSW.fptr); put(D.tl_bptr, TSW.bptr);
     put(D.tl_fsplit, TSW.fsplit); put(D.tl_bsplit, TSW.bsplit); put(D.tl_fend, TSW.fend); put(D.tl_bend, TSW.bend);
     TileFactorOps TFO;

@@ -1710,6 +1710,9 @@ __device__ __forceinline__ void tile_solve(const DevPat &P, gdbl_p W, WS ws0) {
                             });
                         }
                         if (lane < 16) stK<NR>(ws, vb * 16 + lane, res);
+                        // (a vector in the workspace slab: a serially swept block system -- tiles.cpp -- reads this block's entries from the SAME
+                        // wavefront's next operations with no barrier in between: its stores must have landed)
+                        if constexpr (!LDSBAR) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     }
             };
             int o = o0;

@@ -137,13 +137,32 @@ TileFactorOps build_tile_factor_ops(const TilePlan &T, int NW, int pf, const std
     return F;
 }
 
-TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf) {
+TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf, int serial_max) {
     TileSweeps W;
     W.NW = NW;
+    // A SMALL block system (the dense top of a hybrid pattern: lp_bandm's is a chain of seven blocks, one per level) is swept by ONE wavefront
+    // as one flat list in dependency order: a wavefront's LDS accesses execute in order, so no barrier separates its levels and its tile queue
+    // runs across them -- level by level the same system costs a barrier and a cold start of the queue per level while seven wavefronts wait.
+    // Same operations on the same operands in the same order per block: bit-identical.  (Needs the sweep vector in LDS: api.cpp.)
+    W.serial = (T.nt + T.nb) <= serial_max ? 1 : 0;
     const bool allow_split = !(getenv("EICOS_EXPERIMENT") && getenv("EICOS_TILE_SPLIT") && !strcmp(getenv("EICOS_EXPERIMENT"), "1") && !strcmp(getenv("EICOS_TILE_SPLIT"), "0"));
     auto build = [&](bool fwd, std::vector<int> &ops, std::vector<int> &ptr, std::vector<int> &endr, std::vector<int> &split) {
         ptr.assign(1, 0); endr.clear();
         split.assign(T.nblev, 0);
+        auto close_range = [&]() { endr.push_back((int)ops.size() / 4); while (((int)ops.size() / 4 - ptr.back()) % pf) ops.insert(ops.end(), {0, T.nb, 0, 0}); ptr.push_back((int)ops.size() / 4); };
+        if (W.serial) {
+            for (int step = 0; step < T.nblev; step++) {
+                const int v = fwd ? step : T.nblev - 1 - step;
+                for (int B = T.blev_ptr[v]; B < T.blev_ptr[v + 1]; B++) {
+                    if (fwd) for (int e = T.tr_ptr[B]; e < T.tr_ptr[B + 1]; e++) { const int t = T.tr_tile[e]; ops.insert(ops.end(), {t, T.t_col[t], B, 0}); }
+                    else for (int t = T.tc_ptr[B]; t < T.tc_ptr[B + 1]; t++) ops.insert(ops.end(), {t, T.t_row[t], B, 0});
+                    ops.insert(ops.end(), {T.ident[B] ? 0 : B, B, 0, TOP_DIAG | (T.ident[B] ? TOP_IDENT : 0)});
+                }
+            }
+            close_range(); // (level 0, phase 0, wavefront 0) holds everything; every other range is empty
+            for (int r = 1; r < T.nblev * 2 * NW; r++) close_range();
+            return;
+        }
         for (int step = 0; step < T.nblev; step++) {
             const int v = fwd ? step : T.nblev - 1 - step;
             const int b0 = T.blev_ptr[v], b1 = T.blev_ptr[v + 1];

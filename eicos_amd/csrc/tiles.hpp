@@ -56,12 +56,13 @@ struct TilePlan {
 // (the split blocks' diagonal operations); split[level] = 1 when phase 1 is not empty.
 struct TileSweeps {
     int NW = 0;
+    int serial = 0;                    // 1: a small block system, swept by wavefront 0 alone as one flat list (tiles.cpp)
     std::vector<int> fops, bops;       // 4 ints per op
     std::vector<int> fptr, bptr;       // [nblev * 2 * NW + 1]: op range of (level, phase, wave), levels in sweep order (forward: up, backward: down)
     std::vector<int> fend, bend;       // [nblev * 2 * NW]: end of the REAL operations of that range (what follows, up to the next range, is padding)
     std::vector<int> fsplit, bsplit;   // [nblev]
 };
-TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf /* list lengths are padded to a multiple of pf */);
+TileSweeps build_tile_sweeps(const TilePlan &T, int NW, int pf /* list lengths are padded to a multiple of pf */, int serial_max = 0 /* tiles + blocks up to which the system is swept serially */);
 
 // Per-wavefront schedule of the factorisation's accumulation phase (T_IJ = K_IJ - sum_K L_IK D_K L_JK'): the targets of a
 // level are dealt to the wavefronts (most pairs first) and every wavefront gets ONE flat list of operations per level -- per
